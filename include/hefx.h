@@ -1,0 +1,141 @@
+/*
+ * hefx.h -- C-ABI of the MI355X (gfx950) CKKS ciphertext-arithmetic engine.
+ *
+ * Drop-in boundary for the hot path of MarwanNour/SEAL-FYP-Logistic-Regression.  The reference has no
+ * FFI layer of its own: its boundary is the C++ class API of Microsoft SEAL 3.4.5's `seal::Evaluator`
+ * (`#include "seal/seal.h"`, /root/reference/helper.h:4; CMake target SEAL::seal,
+ * /root/reference/CMakeLists.txt:25-41).  Every entry point below names the Evaluator member it
+ * replaces and the reference call sites that reach it; include/seal/seal.h is the C++ shim that maps
+ * the class API onto these calls.
+ *
+ * Conventions
+ *  - Payload layout is SEAL's: a ciphertext of `size` polys at a level with L
+ *    data primes is size*L*N uint64 words, word (p*L + j)*N + i = coefficient i of poly p mod q_j,
+ *    canonical in [0,q_j), ALWAYS in NTT form.  A plaintext is L*N words.  A key-switching key is
+ *    (k-1)*2*k*N words: [digit i][component c][key-level row m][N]  (k = number of primes incl. the
+ *    special prime P = primes[k-1]).
+ *  - All `d_*` pointers are DEVICE pointers (hefx_malloc or any hipMalloc'd memory of the same
+ *    device).  Pointer ARRAYS (`const uint64_t *const *`) are HOST arrays of device pointers.
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream).  Calls are asynchronous on
+ *    that stream; only hefx_download / hefx_stream_sync / hefx_check_* block.
+ *  - Return value: 0 = HEFX_OK, negative = error; hefx_last_error() gives the thread-local message.
+ *  - Level/scale/parms_id bookkeeping, NAF decomposition of rotation steps and SEAL's validity checks
+ *    live ABOVE this ABI (in the shim); this layer is pure uint64 RNS arithmetic.
+ *  - There is no CPU fallback: without a HIP device every call fails with HEFX_ERR_HIP.
+ */
+#ifndef HEFX_H
+#define HEFX_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEFX_OK 0
+#define HEFX_ERR_INVALID (-1)     /* bad argument (maps to std::invalid_argument in the shim) */
+#define HEFX_ERR_HIP (-2)         /* HIP runtime / device failure */
+#define HEFX_ERR_UNSUPPORTED (-3) /* parameter set outside what the kernels are built for */
+#define HEFX_ERR_TRANSPARENT (-4) /* result ciphertext is transparent (std::logic_error in the shim) */
+
+typedef struct hefx_context hefx_context;
+
+const char *hefx_last_error(void);
+/* "gfx950" build id + version string */
+const char *hefx_version(void);
+/* number of visible HIP devices (0 if none / no runtime) */
+int hefx_device_count(void);
+
+/* ---- context: replaces SEALContext::Create(parms) + the Evaluator's NTT tables
+ *      (/root/reference/linear_transformation2.cpp:229-237, helper.h:239-240).
+ *      N = poly_modulus_degree in {1024..16384, 32768}; primes = coeff_modulus (last = special prime). */
+int hefx_context_create(uint32_t poly_degree, const uint64_t *primes, int k, int device, hefx_context **out);
+void hefx_context_destroy(hefx_context *ctx);
+uint32_t hefx_poly_degree(const hefx_context *ctx);
+int hefx_prime_count(const hefx_context *ctx);
+uint64_t hefx_prime(const hefx_context *ctx, int j);
+/* minimal primitive 2N-th root used for prime j (SEAL try_minimal_primitive_root) */
+uint64_t hefx_psi(const hefx_context *ctx, int j);
+
+/* ---- device memory + transfers (Ciphertext/Plaintext/key payload ownership stays with the caller) */
+int hefx_malloc(hefx_context *ctx, size_t bytes, void **d_ptr);
+int hefx_free(hefx_context *ctx, void *d_ptr);
+int hefx_upload(hefx_context *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
+int hefx_download(hefx_context *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream); /* blocks */
+int hefx_copy(hefx_context *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
+int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
+int hefx_stream_sync(hefx_context *ctx, void *stream);
+
+/* ---- K1/K2: negacyclic NTT over RNS rows (SEAL util::ntt_negacyclic_harvey / inverse_...; reached from
+ *      every rotate/relinearize/rescale and from encode/encrypt/decrypt).  In-place over `npoly` polys of
+ *      `nrows` rows each; row r uses prime index mod_first + r. */
+int hefx_ntt_forward(hefx_context *ctx, uint64_t *d_data, int npoly, int nrows, int mod_first, void *stream);
+int hefx_ntt_inverse(hefx_context *ctx, uint64_t *d_data, int npoly, int nrows, int mod_first, void *stream);
+
+/* ---- K4/K10: Evaluator::add / sub / negate / add_plain (helper.h:219,231,247,259,275,319,464,475;
+ *      logistic_regression_ckks.cpp:288,341-342; polynomial.cpp:210).  `count` contiguous ciphertexts. */
+int hefx_add(hefx_context *ctx, int L, int size, int count, const uint64_t *d_a, const uint64_t *d_b,
+             uint64_t *d_out, void *stream);
+int hefx_sub(hefx_context *ctx, int L, int size, int count, const uint64_t *d_a, const uint64_t *d_b,
+             uint64_t *d_out, void *stream);
+int hefx_negate(hefx_context *ctx, int L, int size, int count, const uint64_t *d_a, uint64_t *d_out,
+                void *stream);
+int hefx_add_plain(hefx_context *ctx, int L, int size, const uint64_t *d_ct, const uint64_t *d_pt,
+                   uint64_t *d_out, void *stream);
+/* Evaluator::add_many (helper.h:231,259,275,319): out = sum of n ciphertexts (one n-way reduction). */
+int hefx_add_many(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_in, uint64_t *d_out,
+                  void *stream);
+
+/* ---- K3/K11: Evaluator::multiply_plain (helper.h:250,256,271,347), multiply (helper.h:222,228,432;
+ *      matrix_multiplication.cpp:104,127), square (vector_ops.cpp:269; 4_ckks.cpp:114).
+ *      multiply_plain records "transparent" (all polys beyond c0 zero) in a device flag; read it with
+ *      hefx_check_transparent (blocks), which returns HEFX_ERR_TRANSPARENT if any call since the last
+ *      check produced a transparent result. */
+int hefx_multiply_plain(hefx_context *ctx, int L, int size, int count, const uint64_t *d_ct,
+                        const uint64_t *d_pt, uint64_t *d_out, void *stream);
+int hefx_check_transparent(hefx_context *ctx, void *stream);
+/* size 2 x size 2 -> size 3 */
+int hefx_multiply(hefx_context *ctx, int L, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out3,
+                  void *stream);
+int hefx_square(hefx_context *ctx, int L, const uint64_t *d_a, uint64_t *d_out3, void *stream);
+
+/* ---- K5/K6/K7: Evaluator::apply_galois_inplace = Galois permutation + key switch (one term of
+ *      rotate_vector; helper.h:216,227,244,255,316,352,455,474; 5_rotation.cpp:215).
+ *      d_key is the Galois key of `galois_elt` (the shim picks it: GaloisKeys index (elt-1)/2).
+ *      in and out may alias. */
+int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_t galois_elt,
+                      const uint64_t *d_key, uint64_t *d_ct_out, void *stream);
+/* n independent (ciphertext, element, key) triples in one launch sequence. */
+int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
+                            const uint32_t *galois_elts, const uint64_t *const *d_keys,
+                            uint64_t *const *d_ct_out, void *stream);
+/* the hot-loop body of Linear_Transform_Plain (helper.h:255-256): out_i = rotate(ct_i, elt_i) (.) pt_i with
+ * a directly keyed element, multiply_plain fused into the key-switch epilogue.  This is the unit
+ * BASELINE.json's metric counts. */
+int hefx_rotate_multiply_plain_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
+                                     const uint32_t *galois_elts, const uint64_t *const *d_keys,
+                                     const uint64_t *const *d_pts, uint64_t *const *d_ct_out, void *stream);
+
+/* ---- Evaluator::relinearize_inplace (helper.h:440,541; polynomial.cpp:92,187): size 3 -> 2. */
+int hefx_relinearize(hefx_context *ctx, int L, const uint64_t *d_ct3, const uint64_t *d_relin_key,
+                     uint64_t *d_ct2, void *stream);
+int hefx_relinearize_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct3,
+                           const uint64_t *d_relin_key, uint64_t *const *d_ct2, void *stream);
+
+/* ---- K8: Evaluator::rescale_to_next_inplace (matrix_multiplication.cpp:71-72; helper.h:441,543):
+ *      L rows -> L-1 rows per poly, SEAL 3.4.x floor variant (App. A.9).  `count` contiguous cts. */
+int hefx_rescale_to_next(hefx_context *ctx, int L, int size, int count, const uint64_t *d_in, uint64_t *d_out,
+                         void *stream);
+/* ---- K9: Evaluator::mod_switch_to_next / mod_switch_to for CKKS ct and pt (matrix_multiplication.cpp:112):
+ *      drop trailing RNS rows, L_in -> L_out, npoly polys. */
+int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint64_t *d_in, uint64_t *d_out,
+                  void *stream);
+
+/* ---- multi-GPU tail (no reference call site): after an RCCL sum all-reduce of uint64
+ *      partial ciphertexts (<= `addends` canonical addends per word), bring every word back to [0,q_j). */
+int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, int addends, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEFX_H */

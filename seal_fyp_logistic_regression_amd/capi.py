@@ -1,0 +1,112 @@
+"""ctypes binding of the C-ABI in include/hefx.h (libhefx.so, gfx950 HIP kernels).
+
+This is the only place Python touches the engine.  There is no CPU fallback: if libhefx.so is missing
+or no HIP device is present, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import _build
+
+HEFX_OK = 0
+HEFX_ERR_INVALID = -1
+HEFX_ERR_HIP = -2
+HEFX_ERR_UNSUPPORTED = -3
+HEFX_ERR_TRANSPARENT = -4
+
+
+class HefxError(RuntimeError):
+    """HIP/device failure or unsupported parameter set."""
+
+
+class TransparentCiphertextError(RuntimeError):
+    """SEAL: std::logic_error("result ciphertext is transparent")."""
+
+
+_lib = None
+
+_vp, _u64, _u32, _i, _sz = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int, C.c_size_t
+_pp = C.POINTER(C.c_void_p)
+
+_SIGS = {
+    "hefx_last_error": (C.c_char_p, []),
+    "hefx_version": (C.c_char_p, []),
+    "hefx_device_count": (_i, []),
+    "hefx_context_create": (_i, [_u32, C.POINTER(_u64), _i, _i, _pp]),
+    "hefx_context_destroy": (None, [_vp]),
+    "hefx_poly_degree": (_u32, [_vp]),
+    "hefx_prime_count": (_i, [_vp]),
+    "hefx_prime": (_u64, [_vp, _i]),
+    "hefx_psi": (_u64, [_vp, _i]),
+    "hefx_malloc": (_i, [_vp, _sz, _pp]),
+    "hefx_free": (_i, [_vp, _vp]),
+    "hefx_upload": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hefx_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hefx_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hefx_memset_zero": (_i, [_vp, _vp, _sz, _vp]),
+    "hefx_stream_sync": (_i, [_vp, _vp]),
+    "hefx_ntt_forward": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "hefx_ntt_inverse": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "hefx_add": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hefx_sub": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hefx_negate": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hefx_add_plain": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "hefx_add_many": (_i, [_vp, _i, _i, _i, _pp, _vp, _vp]),
+    "hefx_multiply_plain": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "hefx_check_transparent": (_i, [_vp, _vp]),
+    "hefx_multiply": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "hefx_square": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "hefx_apply_galois": (_i, [_vp, _i, _vp, _u32, _vp, _vp, _vp]),
+    "hefx_apply_galois_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _vp]),
+    "hefx_rotate_multiply_plain_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
+    "hefx_relinearize": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
+    "hefx_relinearize_batch": (_i, [_vp, _i, _i, _pp, _vp, _pp, _vp]),
+    "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+}
+
+EXPORTED_SYMBOLS = sorted(_SIGS)
+
+
+def library_path() -> str:
+    return _build.SO
+
+
+def lib():
+    """Loads libhefx.so (must have been built: python -c 'import __graft_entry__ as g; g.build()')."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise HefxError(f"{path} is missing: build the HIP extension first (__graft_entry__.build())")
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
+    for name, (res, args) in _SIGS.items():
+        f = getattr(L, name)
+        f.restype = res
+        f.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> None:
+    if rc == HEFX_OK:
+        return
+    msg = lib().hefx_last_error().decode()
+    if rc == HEFX_ERR_INVALID:
+        raise ValueError(msg)  # SEAL: std::invalid_argument
+    if rc == HEFX_ERR_TRANSPARENT:
+        raise TransparentCiphertextError(msg)
+    raise HefxError(f"hefx error {rc}: {msg}")
+
+
+def ptr_array(ptrs):
+    arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+    return arr
+
+
+def u32_array(vals):
+    return (C.c_uint32 * len(vals))(*[int(v) for v in vals])

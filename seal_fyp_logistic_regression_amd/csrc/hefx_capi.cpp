@@ -1,0 +1,613 @@
+// hefx_capi.cpp -- host side of the C-ABI declared in include/hefx.h: context (prime validation,
+// minimal primitive roots, twiddle/constant tables uploaded once to HBM), Galois gather-table cache,
+// scratch management and the chunked launch sequences.  No CPU arithmetic fallback exists: every
+// compute entry point dispatches HIP kernels from hefx_kernels.hip or fails.
+#include "../../include/hefx.h"
+
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "hefx_internal.h"
+
+using namespace hefx;
+typedef unsigned __int128 u128;
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string &msg)
+{
+    g_err = msg;
+    return code;
+}
+static int hipfail(hipError_t e, const char *what)
+{
+    return fail(HEFX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(expr)                                  \
+    do {                                              \
+        hipError_t _e = (expr);                       \
+        if (_e != hipSuccess) return hipfail(_e, #expr); \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// host number theory (context creation only; independent of oracle/)
+// ---------------------------------------------------------------------------------------------
+static inline u64 h_mulmod(u64 a, u64 b, u64 q) { return (u64)(((u128)a * b) % q); }
+static u64 h_powmod(u64 a, u64 e, u64 q)
+{
+    u64 r = 1 % q;
+    a %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = h_mulmod(r, a, q);
+        a = h_mulmod(a, a, q);
+    }
+    return r;
+}
+static inline u64 h_invmod(u64 a, u64 q) { return h_powmod(a, q - 2, q); }
+static inline u64 h_shoup(u64 w, u64 q) { return (u64)(((u128)w << 64) / q); }
+
+static bool h_is_prime(u64 n)
+{
+    if (n < 2) return false;
+    static const u64 bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (u64 p : bases) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    u64 d = n - 1;
+    int r = 0;
+    while (!(d & 1)) d >>= 1, ++r;
+    for (u64 a : bases) {
+        u64 x = h_powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool composite = true;
+        for (int i = 1; i < r && composite; ++i) {
+            x = h_mulmod(x, x, n);
+            if (x == n - 1) composite = false;
+        }
+        if (composite) return false;
+    }
+    return true;
+}
+
+// smallest element of exact order 2N (SEAL try_minimal_primitive_root)
+static u64 h_min_primitive_root(u64 two_n, u64 q)
+{
+    const u64 cof = (q - 1) / two_n;
+    u64 root = 0;
+    for (u64 g = 2; g < 1000 && !root; ++g) {
+        u64 c = h_powmod(g, cof, q);
+        if (h_powmod(c, two_n / 2, q) == q - 1) root = c;
+    }
+    if (!root) return 0;
+    const u64 sq = h_mulmod(root, root, q);
+    u64 best = root, cur = root;
+    for (u64 i = 0; i < two_n / 2; ++i) {
+        if (cur < best) best = cur;
+        cur = h_mulmod(cur, sq, q);
+    }
+    return best;
+}
+
+static inline uint32_t h_bitrev(uint32_t x, int bits)
+{
+    uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) r = (r << 1) | ((x >> i) & 1);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct hefx_context {
+    int device = 0;
+    uint32_t n = 0;
+    int logn = 0;
+    int k = 0;
+    std::vector<u64> primes, psi;
+    DevTables T{};
+    void *d_tables = nullptr;  // one allocation holding tw, itw, mods, invmod, halfmod
+    std::mutex mu;
+    std::unordered_map<uint32_t, uint32_t *> perm;  // Galois element -> device gather table
+    // scratch (grown on demand, reused across calls so it stays cache-resident)
+    u64 *scratch = nullptr;
+    size_t scratch_words = 0;
+    int chunk = 16;
+    int *d_flag = nullptr;  // [0] transparent count, [1] per-call "non-zero seen"
+    bool transparent_check = false;
+};
+
+static int ensure_scratch(hefx_context *c, size_t words)
+{
+    if (c->scratch_words >= words) return HEFX_OK;
+    if (c->scratch) {
+        HIPCHK(hipDeviceSynchronize());
+        HIPCHK(hipFree(c->scratch));
+        c->scratch = nullptr;
+        c->scratch_words = 0;
+    }
+    HIPCHK(hipMalloc((void **)&c->scratch, words * sizeof(u64)));
+    c->scratch_words = words;
+    return HEFX_OK;
+}
+
+extern "C" const char *hefx_last_error(void) { return g_err.c_str(); }
+extern "C" const char *hefx_version(void) { return "hefx 0.1 (gfx950, HIP)"; }
+
+extern "C" int hefx_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes, int k, int device,
+                                   hefx_context **out)
+{
+    if (!out || !primes) return fail(HEFX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int logn = 0;
+    while ((1u << logn) < poly_degree) ++logn;
+    if ((1u << logn) != poly_degree) return fail(HEFX_ERR_INVALID, "poly_degree must be a power of two");
+    if (logn < 10 || logn > 14)
+        return fail(HEFX_ERR_UNSUPPORTED, "poly_degree must be in [1024, 16384] in this build");
+    if (k < 1 || k > 62) return fail(HEFX_ERR_INVALID, "prime count out of range");
+    const u64 two_n = 2ull * poly_degree;
+    for (int j = 0; j < k; ++j) {
+        const u64 q = primes[j];
+        if (q >> 61) return fail(HEFX_ERR_INVALID, "primes must be below 2^61");
+        if (q % two_n != 1) return fail(HEFX_ERR_INVALID, "prime is not 1 mod 2N");
+        if (!h_is_prime(q)) return fail(HEFX_ERR_INVALID, "coeff modulus is not prime");
+        for (int i = 0; i < j; ++i)
+            if (primes[i] == q) return fail(HEFX_ERR_INVALID, "primes must be distinct");
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(HEFX_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(HEFX_ERR_INVALID, "bad device index");
+    HIPCHK(hipSetDevice(device));
+
+    hefx_context *c = new hefx_context();
+    c->device = device;
+    c->n = poly_degree;
+    c->logn = logn;
+    c->k = k;
+    c->primes.assign(primes, primes + k);
+    c->psi.resize(k);
+    if (const char *e = getenv("HEFX_CHUNK")) {
+        int v = atoi(e);
+        if (v >= 1 && v <= KS_MAX_CHUNK) c->chunk = v;
+    }
+
+    const size_t n = poly_degree;
+    const size_t tw_bytes = sizeof(ulonglong2) * n * k;
+    const size_t mods_bytes = sizeof(ModConst) * k;
+    const size_t inv_bytes = sizeof(ulonglong2) * k * k;
+    const size_t half_bytes = sizeof(u64) * k * k;
+    const size_t total = 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes;
+    std::vector<unsigned char> host(total);
+    ulonglong2 *tw = reinterpret_cast<ulonglong2 *>(host.data());
+    ulonglong2 *itw = tw + n * k;
+    ModConst *mods = reinterpret_cast<ModConst *>(itw + n * k);
+    ulonglong2 *invmod = reinterpret_cast<ulonglong2 *>(mods + k);
+    u64 *halfmod = reinterpret_cast<u64 *>(invmod + (size_t)k * k);
+
+    for (int j = 0; j < k; ++j) {
+        const u64 q = primes[j];
+        const u64 psi = h_min_primitive_root(two_n, q);
+        if (!psi) {
+            delete c;
+            return fail(HEFX_ERR_INVALID, "no primitive 2N-th root found");
+        }
+        c->psi[j] = psi;
+        const u64 ipsi = h_invmod(psi, q);
+        u64 p = 1, ip = 1;
+        for (size_t i = 0; i < n; ++i) {
+            const uint32_t r = h_bitrev((uint32_t)i, logn);
+            tw[(size_t)j * n + r] = make_ulonglong2(p, h_shoup(p, q));
+            itw[(size_t)j * n + r] = make_ulonglong2(ip, h_shoup(ip, q));
+            p = h_mulmod(p, psi, q);
+            ip = h_mulmod(ip, ipsi, q);
+        }
+        ModConst &m = mods[j];
+        m.q = q;
+        const u128 ratio = ~(u128)0 / q;  // floor((2^128-1)/q) == floor(2^128/q) since q is odd > 1
+        m.r0 = (u64)ratio;
+        m.r1 = (u64)(ratio >> 64);
+        m.ninv = h_invmod(n % q, q);
+        m.ninv_s = h_shoup(m.ninv, q);
+        m.ilw = h_mulmod(itw[(size_t)j * n + 1].x, m.ninv, q);
+        m.ilw_s = h_shoup(m.ilw, q);
+        m.pad = 0;
+    }
+    for (int l = 0; l < k; ++l)
+        for (int j = 0; j < k; ++j) {
+            if (l == j) {
+                invmod[(size_t)l * k + j] = make_ulonglong2(0, 0);
+                halfmod[(size_t)l * k + j] = 0;
+                continue;
+            }
+            const u64 q = primes[j];
+            const u64 inv = h_invmod(primes[l] % q, q);
+            invmod[(size_t)l * k + j] = make_ulonglong2(inv, h_shoup(inv, q));
+            halfmod[(size_t)l * k + j] = (primes[l] >> 1) % q;
+        }
+
+    hipError_t e = hipMalloc(&c->d_tables, total);
+    if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
+    if (e != hipSuccess) {
+        if (c->d_tables) (void)hipFree(c->d_tables);
+        delete c;
+        return hipfail(e, "context table upload");
+    }
+    unsigned char *base = static_cast<unsigned char *>(c->d_tables);
+    c->T.tw = reinterpret_cast<const ulonglong2 *>(base);
+    c->T.itw = reinterpret_cast<const ulonglong2 *>(base + tw_bytes);
+    c->T.mods = reinterpret_cast<const ModConst *>(base + 2 * tw_bytes);
+    c->T.invmod = reinterpret_cast<const ulonglong2 *>(base + 2 * tw_bytes + mods_bytes);
+    c->T.halfmod = reinterpret_cast<const u64 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes);
+    c->T.k = k;
+    c->T.logn = logn;
+    *out = c;
+    return HEFX_OK;
+}
+
+extern "C" void hefx_context_destroy(hefx_context *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    for (auto &kv : c->perm) (void)hipFree(kv.second);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->d_flag) (void)hipFree(c->d_flag);
+    if (c->d_tables) (void)hipFree(c->d_tables);
+    delete c;
+}
+
+extern "C" uint32_t hefx_poly_degree(const hefx_context *c) { return c ? c->n : 0; }
+extern "C" int hefx_prime_count(const hefx_context *c) { return c ? c->k : 0; }
+extern "C" uint64_t hefx_prime(const hefx_context *c, int j) { return (c && j >= 0 && j < c->k) ? c->primes[j] : 0; }
+extern "C" uint64_t hefx_psi(const hefx_context *c, int j) { return (c && j >= 0 && j < c->k) ? c->psi[j] : 0; }
+
+// ---------------------------------------------------------------------------------------------
+// memory helpers
+// ---------------------------------------------------------------------------------------------
+#define CTXCHK(c)                                                \
+    do {                                                         \
+        if (!(c)) return fail(HEFX_ERR_INVALID, "null context"); \
+    } while (0)
+
+extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
+{
+    CTXCHK(c);
+    if (!d_ptr) return fail(HEFX_ERR_INVALID, "null out pointer");
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    return HEFX_OK;
+}
+extern "C" int hefx_free(hefx_context *c, void *d_ptr)
+{
+    CTXCHK(c);
+    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    return HEFX_OK;
+}
+extern "C" int hefx_upload(hefx_context *c, void *d_dst, const void *h_src, size_t bytes, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));  // the host buffer may be pageable / transient
+    return HEFX_OK;
+}
+extern "C" int hefx_download(hefx_context *c, void *h_dst, const void *d_src, size_t bytes, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_copy(hefx_context *c, void *d_dst, const void *d_src, size_t bytes, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipMemsetAsync(d_dst, 0, bytes, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_stream_sync(hefx_context *c, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// argument checks
+// ---------------------------------------------------------------------------------------------
+static int check_level(const hefx_context *c, int L)
+{
+    // data levels use q_0..q_{L-1}; the special prime (index k-1) is never a data prime unless k == 1
+    if (L < 1 || L > c->k) return fail(HEFX_ERR_INVALID, "level L out of range");
+    return HEFX_OK;
+}
+static int check_ks_level(const hefx_context *c, int L)
+{
+    if (c->k < 2) return fail(HEFX_ERR_INVALID, "key switching needs a special prime (k >= 2)");
+    if (L < 1 || L > c->k - 1) return fail(HEFX_ERR_INVALID, "key-switch level L must be in [1, k-1]");
+    return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// NTT
+// ---------------------------------------------------------------------------------------------
+static int ntt_common(hefx_context *c, bool inv, uint64_t *d, int npoly, int nrows, int mod_first, void *stream)
+{
+    CTXCHK(c);
+    if (!d || npoly < 1 || nrows < 1 || mod_first < 0 || mod_first + nrows > c->k)
+        return fail(HEFX_ERR_INVALID, "bad NTT arguments");
+    HIPCHK(launch_ntt(c->T, inv, (u64 *)d, npoly, nrows, mod_first, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_ntt_forward(hefx_context *c, uint64_t *d, int npoly, int nrows, int mod_first, void *stream)
+{
+    return ntt_common(c, false, d, npoly, nrows, mod_first, stream);
+}
+extern "C" int hefx_ntt_inverse(hefx_context *c, uint64_t *d, int npoly, int nrows, int mod_first, void *stream)
+{
+    return ntt_common(c, true, d, npoly, nrows, mod_first, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// element-wise
+// ---------------------------------------------------------------------------------------------
+static int ew_common(hefx_context *c, EwOp op, int L, int size, int count, const uint64_t *a, const uint64_t *b,
+                     uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (size < 1 || count < 1 || !a || !out) return fail(HEFX_ERR_INVALID, "bad element-wise arguments");
+    if ((op == EW_ADD || op == EW_SUB || op == EW_MULPLAIN || op == EW_ADDPLAIN) && !b)
+        return fail(HEFX_ERR_INVALID, "missing second operand");
+    HIPCHK(launch_elementwise(c->T, op, L, size, count, (const u64 *)a, (const u64 *)b, (u64 *)out, c->d_flag,
+                              (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_add(hefx_context *c, int L, int size, int count, const uint64_t *a, const uint64_t *b,
+                        uint64_t *out, void *stream)
+{
+    return ew_common(c, EW_ADD, L, size, count, a, b, out, stream);
+}
+extern "C" int hefx_sub(hefx_context *c, int L, int size, int count, const uint64_t *a, const uint64_t *b,
+                        uint64_t *out, void *stream)
+{
+    return ew_common(c, EW_SUB, L, size, count, a, b, out, stream);
+}
+extern "C" int hefx_negate(hefx_context *c, int L, int size, int count, const uint64_t *a, uint64_t *out,
+                           void *stream)
+{
+    return ew_common(c, EW_NEG, L, size, count, a, nullptr, out, stream);
+}
+extern "C" int hefx_add_plain(hefx_context *c, int L, int size, const uint64_t *ct, const uint64_t *pt,
+                              uint64_t *out, void *stream)
+{
+    return ew_common(c, EW_ADDPLAIN, L, size, 1, ct, pt, out, stream);
+}
+extern "C" int hefx_reduce_canonical(hefx_context *c, int L, int size, uint64_t *d, int addends, void *stream)
+{
+    (void)addends;  // barrett64 handles any 64-bit word; callers guarantee the sum did not wrap
+    return ew_common(c, EW_REDUCE, L, size, 1, d, nullptr, d, stream);
+}
+
+// flag[1] == 0 after a multiply_plain means nothing beyond c0 was non-zero: count it in flag[0]
+__global__ void transparent_finalize_kernel(int *flag)
+{
+    if (flag[1] == 0) flag[0] += 1;
+    flag[1] = 0;
+}
+
+extern "C" int hefx_multiply_plain(hefx_context *c, int L, int size, int count, const uint64_t *ct,
+                                   const uint64_t *pt, uint64_t *out, void *stream)
+{
+    int rc = ew_common(c, EW_MULPLAIN, L, size, count, ct, pt, out, stream);
+    if (rc) return rc;
+    if (size > 1) {
+        hipLaunchKernelGGL(transparent_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->d_flag);
+        HIPCHK(hipGetLastError());
+    }
+    return HEFX_OK;
+}
+
+extern "C" int hefx_check_transparent(hefx_context *c, void *stream)
+{
+    CTXCHK(c);
+    int h[2] = {0, 0};
+    HIPCHK(hipMemcpyAsync(h, c->d_flag, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+    if (h[0]) {
+        HIPCHK(hipMemsetAsync(c->d_flag, 0, 2 * sizeof(int), (hipStream_t)stream));
+        return fail(HEFX_ERR_TRANSPARENT, "result ciphertext is transparent");
+    }
+    return HEFX_OK;
+}
+
+extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint64_t *const *in, uint64_t *out,
+                             void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (n < 1 || size < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad add_many arguments");
+    for (int base = 0; base < n; base += ADD_MANY_GROUP) {
+        PtrGroup g{};
+        const int cnt = (n - base < ADD_MANY_GROUP) ? n - base : ADD_MANY_GROUP;
+        for (int i = 0; i < cnt; ++i) {
+            if (!in[base + i]) return fail(HEFX_ERR_INVALID, "null ciphertext in add_many");
+            g.p[i] = (const u64 *)in[base + i];
+        }
+        HIPCHK(launch_add_many(c->T, L, size, g, cnt, base > 0, (u64 *)out, (hipStream_t)stream));
+    }
+    return HEFX_OK;
+}
+
+extern "C" int hefx_multiply(hefx_context *c, int L, const uint64_t *a, const uint64_t *b, uint64_t *out3,
+                             void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (!a || !b || !out3) return fail(HEFX_ERR_INVALID, "null operand");
+    HIPCHK(launch_multiply(c->T, L, (const u64 *)a, (const u64 *)b, (u64 *)out3, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_square(hefx_context *c, int L, const uint64_t *a, uint64_t *out3, void *stream)
+{
+    return hefx_multiply(c, L, a, a, out3, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Galois tables: out[i] = in[ bitrev(((elt*(2*bitrev(i)+1)) mod 2N - 1)/2) ]
+// ---------------------------------------------------------------------------------------------
+static int get_perm(hefx_context *c, uint32_t elt, const uint32_t **out)
+{
+    if (!(elt & 1) || elt >= 2 * c->n) return fail(HEFX_ERR_INVALID, "Galois element must be odd and < 2N");
+    std::lock_guard<std::mutex> lk(c->mu);
+    auto it = c->perm.find(elt);
+    if (it != c->perm.end()) {
+        *out = it->second;
+        return HEFX_OK;
+    }
+    std::vector<uint32_t> tab(c->n);
+    const uint32_t mask = 2 * c->n - 1;
+    for (uint32_t i = 0; i < c->n; ++i) {
+        const uint32_t raw = (uint32_t)(((uint64_t)elt * (2 * h_bitrev(i, c->logn) + 1)) & mask);
+        tab[i] = h_bitrev((raw - 1) >> 1, c->logn);
+    }
+    uint32_t *d = nullptr;
+    HIPCHK(hipMalloc((void **)&d, sizeof(uint32_t) * c->n));
+    hipError_t e = hipMemcpy(d, tab.data(), sizeof(uint32_t) * c->n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        (void)hipFree(d);
+        return hipfail(e, "Galois table upload");
+    }
+    c->perm[elt] = d;
+    *out = d;
+    return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// key switching
+// ---------------------------------------------------------------------------------------------
+static size_t ks_words_per_item(const hefx_context *c, int L)
+{
+    return (size_t)c->n * ((size_t)L + (size_t)L * (L + 1) + 2 * (size_t)(L + 1) + 2);
+}
+
+static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
+                  const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
+                  uint64_t *const *ct_out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
+    if (!relin && (!elts || !keys)) return fail(HEFX_ERR_INVALID, "missing Galois elements / keys");
+    if (relin && !single_key) return fail(HEFX_ERR_INVALID, "missing relinearization key");
+    std::lock_guard<std::mutex> *lk = nullptr;
+    (void)lk;
+    const int chunk = c->chunk;
+    const size_t per = ks_words_per_item(c, L);
+    if (int rc = ensure_scratch(c, per * (size_t)(n < chunk ? n : chunk))) return rc;
+    const size_t N = c->n;
+    for (int base = 0; base < n; base += chunk) {
+        const int cnt = (n - base < chunk) ? n - base : chunk;
+        KsBatch B{};
+        for (int i = 0; i < cnt; ++i) {
+            KsItem &it = B.it[i];
+            it.c_in = (const u64 *)ct_in[base + i];
+            it.c_out = (u64 *)ct_out[base + i];
+            if (!it.c_in || !it.c_out) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
+            it.pt = pts ? (const u64 *)pts[base + i] : nullptr;
+            if (relin) {
+                it.key = (const u64 *)single_key;
+                it.perm = nullptr;
+            } else {
+                if (it.c_in == it.c_out)
+                    return fail(HEFX_ERR_INVALID, "apply_galois input and output must not alias");
+                it.key = (const u64 *)keys[base + i];
+                if (!it.key) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
+                if (int rc = get_perm(c, elts[base + i], &it.perm)) return rc;
+            }
+        }
+        KsScratch S;
+        S.d = c->scratch;
+        S.x = S.d + (size_t)cnt * L * N;
+        S.acc = S.x + (size_t)cnt * L * (L + 1) * N;
+        S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, B, relin, S, (hipStream_t)stream));
+    }
+    return HEFX_OK;
+}
+
+extern "C" int hefx_apply_galois(hefx_context *c, int L, const uint64_t *ct_in, uint32_t elt, const uint64_t *key,
+                                 uint64_t *ct_out, void *stream)
+{
+    return ks_run(c, L, 1, false, &ct_in, &elt, &key, nullptr, nullptr, &ct_out, stream);
+}
+extern "C" int hefx_apply_galois_batch(hefx_context *c, int L, int n, const uint64_t *const *ct_in,
+                                       const uint32_t *elts, const uint64_t *const *keys, uint64_t *const *ct_out,
+                                       void *stream)
+{
+    return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, nullptr, ct_out, stream);
+}
+extern "C" int hefx_rotate_multiply_plain_batch(hefx_context *c, int L, int n, const uint64_t *const *ct_in,
+                                                const uint32_t *elts, const uint64_t *const *keys,
+                                                const uint64_t *const *pts, uint64_t *const *ct_out, void *stream)
+{
+    if (!pts) return fail(HEFX_ERR_INVALID, "missing plaintexts");
+    for (int i = 0; i < n; ++i)
+        if (!pts[i]) return fail(HEFX_ERR_INVALID, "null plaintext pointer in batch");
+    return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, pts, ct_out, stream);
+}
+extern "C" int hefx_relinearize(hefx_context *c, int L, const uint64_t *ct3, const uint64_t *key, uint64_t *ct2,
+                                void *stream)
+{
+    return ks_run(c, L, 1, true, &ct3, nullptr, nullptr, key, nullptr, &ct2, stream);
+}
+extern "C" int hefx_relinearize_batch(hefx_context *c, int L, int n, const uint64_t *const *ct3,
+                                      const uint64_t *key, uint64_t *const *ct2, void *stream)
+{
+    return ks_run(c, L, n, true, ct3, nullptr, nullptr, key, nullptr, ct2, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// rescale / mod drop
+// ---------------------------------------------------------------------------------------------
+extern "C" int hefx_rescale_to_next(hefx_context *c, int L, int size, int count, const uint64_t *in, uint64_t *out,
+                                    void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (L < 2) return fail(HEFX_ERR_INVALID, "cannot rescale at the last level");
+    if (size < 1 || count < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad rescale arguments");
+    if (in == out) return fail(HEFX_ERR_INVALID, "rescale input and output must not alias");
+    if (int rc = ensure_scratch(c, (size_t)c->n * size * count)) return rc;
+    HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, c->scratch, (hipStream_t)stream));
+    return HEFX_OK;
+}
+
+extern "C" int hefx_mod_drop(hefx_context *c, int L_in, int L_out, int npoly, const uint64_t *in, uint64_t *out,
+                             void *stream)
+{
+    CTXCHK(c);
+    if (L_out < 1 || L_out > L_in || L_in > c->k || npoly < 1 || !in || !out)
+        return fail(HEFX_ERR_INVALID, "bad mod_drop arguments");
+    const size_t row = (size_t)c->n * sizeof(u64);
+    HIPCHK(hipMemcpy2DAsync(out, row * L_out, in, row * L_in, row * L_out, npoly, hipMemcpyDeviceToDevice,
+                            (hipStream_t)stream));
+    return HEFX_OK;
+}

@@ -1,0 +1,65 @@
+// hefx_internal.h -- structures shared between the host side (hefx_capi.cpp) and the gfx950 kernels
+// (hefx_kernels.hip).  Not part of the public ABI (that is include/hefx.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "hefx_modarith.cuh"
+
+namespace hefx {
+
+// Device-resident constant tables of one context (all pointers are device pointers).
+struct DevTables {
+    const ulonglong2 *tw;      // [k][N]  forward twiddles {w, floor(w*2^64/q)}, w[bitrev(i)] = psi^i
+    const ulonglong2 *itw;     // [k][N]  inverse twiddles, itw[idx] = tw[idx]^-1
+    const ModConst *mods;      // [k]
+    const ulonglong2 *invmod;  // [k][k]  invmod[l*k+j] = {q_l^-1 mod q_j, Shoup companion} (l != j)
+    const u64 *halfmod;        // [k][k]  (q_l >> 1) mod q_j
+    int k;
+    int logn;
+};
+
+// One key-switch work item (a rotation term or a relinearisation).
+struct KsItem {
+    const u64 *c_in;   // source ciphertext, [2][L][N] (rotation) or [3][L][N] (relinearisation)
+    const u64 *key;    // [k-1][2][k][N]
+    const uint32_t *perm;  // Galois gather table (N entries) or nullptr for relinearisation
+    const u64 *pt;     // optional plaintext [L][N] multiplied into the result (fused multiply_plain)
+    u64 *c_out;        // [2][L][N]
+};
+
+constexpr int KS_MAX_CHUNK = 32;
+struct KsBatch {
+    KsItem it[KS_MAX_CHUNK];
+};
+
+// Scratch layout for one chunk of key-switch items, in units of N words per item.
+struct KsScratch {
+    u64 *d;    // [chunk][L][N]        digits in coefficient form
+    u64 *x;    // [chunk][L][L+1][N]   digit i transformed to modulus slot jj (jj==L: special prime)
+    u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
+    u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
+};
+
+constexpr int ADD_MANY_GROUP = 48;
+struct PtrGroup {
+    const u64 *p[ADD_MANY_GROUP];
+};
+
+// ---- launchers implemented in hefx_kernels.hip; all asynchronous on `s`; return hipError_t ----
+hipError_t launch_ntt(const DevTables &T, bool inverse, u64 *data, int npoly, int nrows, int mod_first,
+                      hipStream_t s);
+enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MULPLAIN = 3, EW_ADDPLAIN = 4, EW_REDUCE = 5 };
+// generic element-wise op over `count` ciphertexts of `size` polys and L rows. b may be null (NEG/REDUCE).
+// For MULPLAIN/ADDPLAIN b is a plaintext [L][N] (per ciphertext stride 0).
+hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int count, const u64 *a,
+                              const u64 *b, u64 *out, int *flag, hipStream_t s);
+hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
+                           u64 *out, hipStream_t s);
+hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
+hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+                                  const KsScratch &scr, hipStream_t s);
+hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
+                          hipStream_t s);
+
+}  // namespace hefx

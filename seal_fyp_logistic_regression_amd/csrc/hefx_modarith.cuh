@@ -1,0 +1,64 @@
+// hefx_modarith.cuh -- 64-bit modular arithmetic for gfx950 lanes.
+//
+// gfx950 has no native 64x64 multiply: everything below lowers to v_mad_u64_u32 / v_mul_lo_u32 /
+// v_mul_hi_u32 chains.  All public results of the library are canonical residues in [0,q), so any
+// exact reduction reproduces SEAL 3.4.5's bits; laziness is internal only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace hefx {
+
+typedef unsigned long long u64;
+
+// Per-modulus constants, one 64-byte record per RNS prime (uniform per workgroup -> scalar loads).
+struct ModConst {
+    u64 q;
+    u64 r0, r1;        // floor(2^128/q) = r1*2^64 + r0   (Barrett)
+    u64 ninv, ninv_s;  // N^-1 mod q and its Shoup companion floor(ninv*2^64/q)
+    u64 ilw, ilw_s;    // (psi^-1 twiddle of the last inverse stage) * N^-1, and Shoup companion
+    u64 pad;
+};
+
+__device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
+
+// x*w mod q in [0,2q), ws = floor(w*2^64/q); valid for ANY 64-bit x (Harvey/Shoup).
+__device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) * q; }
+
+__device__ __forceinline__ u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+
+__device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
+__device__ __forceinline__ u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }
+__device__ __forceinline__ u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
+
+// any 64-bit x -> [0,q); r1 = floor(2^64/q)
+__device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 r1) { return csub(x - mulhi64(x, r1) * q, q); }
+
+// (hi:lo) < q*2^64 -> [0,q)
+__device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, const ModConst &m)
+{
+    u64 carry = mulhi64(lo, m.r0);
+    u64 t_lo = lo * m.r1, t_hi = mulhi64(lo, m.r1);
+    u64 tmp1 = t_lo + carry;
+    u64 tmp3 = t_hi + (tmp1 < carry);
+    u64 u_lo = hi * m.r0, u_hi = mulhi64(hi, m.r0);
+    u64 s = tmp1 + u_lo;
+    u64 carry2 = u_hi + (s < u_lo);
+    u64 qhat = hi * m.r1 + tmp3 + carry2;
+    return csub(lo - qhat * m.q, m.q);
+}
+
+__device__ __forceinline__ u64 mulmod(u64 a, u64 b, const ModConst &m)
+{
+    return barrett128(a * b, mulhi64(a, b), m);
+}
+
+// 128-bit accumulate acc += a*b
+__device__ __forceinline__ void mac128(u64 &lo, u64 &hi, u64 a, u64 b)
+{
+    u64 pl = a * b, ph = mulhi64(a, b);
+    lo += pl;
+    hi += ph + (lo < pl);
+}
+
+}  // namespace hefx

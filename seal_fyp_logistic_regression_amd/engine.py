@@ -1,0 +1,226 @@
+"""Thin object layer over the C-ABI: device buffers + one method per hefx_* entry point.
+
+Payloads are flat uint64 arrays in SEAL's layout ([size][L][N], NTT form, canonical residues).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence
+
+import numpy as np
+
+from . import capi
+
+
+class DeviceArray:
+    """A uint64 device buffer owned by an Engine (hefx_malloc/hefx_free)."""
+
+    __slots__ = ("engine", "ptr", "shape", "_owned")
+
+    def __init__(self, engine: "Engine", shape, ptr: Optional[int] = None):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        if ptr is None:
+            p = C.c_void_p()
+            capi.check(capi.lib().hefx_malloc(engine._h, self.nbytes, C.byref(p)))
+            self.ptr = p.value
+            self._owned = True
+        else:
+            self.ptr = int(ptr)
+            self._owned = False
+
+    @property
+    def nwords(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    @property
+    def nbytes(self) -> int:
+        return self.nwords * 8
+
+    def upload(self, host: np.ndarray, stream=None) -> "DeviceArray":
+        h = np.ascontiguousarray(host, dtype=np.uint64)
+        if h.size != self.nwords:
+            raise ValueError(f"upload size mismatch: {h.size} vs {self.nwords}")
+        capi.check(capi.lib().hefx_upload(self.engine._h, self.ptr, h.ctypes.data, self.nbytes, stream))
+        return self
+
+    def download(self, stream=None) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.uint64)
+        capi.check(capi.lib().hefx_download(self.engine._h, out.ctypes.data, self.ptr, self.nbytes, stream))
+        return out
+
+    def view(self, offset_words: int, shape) -> "DeviceArray":
+        """Non-owning window into this buffer (keeps the parent alive through .engine only)."""
+        v = DeviceArray(self.engine, shape, ptr=self.ptr + 8 * int(offset_words))
+        return v
+
+    def free(self):
+        if self._owned and self.ptr and self.engine._h:
+            capi.lib().hefx_free(self.engine._h, self.ptr)
+        self.ptr = 0
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Engine:
+    """One CKKS parameter set on one GPU: N, primes[0..k-1] (last = special prime)."""
+
+    def __init__(self, poly_degree: int, primes: Sequence[int], device: int = 0):
+        self.N = int(poly_degree)
+        self.primes = [int(p) for p in primes]
+        self.k = len(self.primes)
+        self.device = device
+        self._h = None
+        arr = (C.c_uint64 * self.k)(*self.primes)
+        h = C.c_void_p()
+        capi.check(capi.lib().hefx_context_create(self.N, arr, self.k, device, C.byref(h)))
+        self._h = h.value
+
+    def close(self):
+        if self._h:
+            capi.lib().hefx_context_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- memory
+    def empty(self, *shape) -> DeviceArray:
+        return DeviceArray(self, shape)
+
+    def zeros(self, *shape, stream=None) -> DeviceArray:
+        a = DeviceArray(self, shape)
+        capi.check(capi.lib().hefx_memset_zero(self._h, a.ptr, a.nbytes, stream))
+        return a
+
+    def to_device(self, host: np.ndarray, stream=None) -> DeviceArray:
+        h = np.ascontiguousarray(host, dtype=np.uint64)
+        return DeviceArray(self, h.shape).upload(h, stream)
+
+    def copy(self, src: DeviceArray, stream=None) -> DeviceArray:
+        dst = DeviceArray(self, src.shape)
+        capi.check(capi.lib().hefx_copy(self._h, dst.ptr, src.ptr, src.nbytes, stream))
+        return dst
+
+    def sync(self, stream=None):
+        capi.check(capi.lib().hefx_stream_sync(self._h, stream))
+
+    def psi(self, j: int) -> int:
+        return int(capi.lib().hefx_psi(self._h, j))
+
+    # ---- NTT (in place)
+    def ntt_forward(self, buf: DeviceArray, npoly: int, nrows: int, mod_first: int = 0, stream=None):
+        capi.check(capi.lib().hefx_ntt_forward(self._h, buf.ptr, npoly, nrows, mod_first, stream))
+
+    def ntt_inverse(self, buf: DeviceArray, npoly: int, nrows: int, mod_first: int = 0, stream=None):
+        capi.check(capi.lib().hefx_ntt_inverse(self._h, buf.ptr, npoly, nrows, mod_first, stream))
+
+    # ---- element-wise; ciphertext arrays are [count?][size][L][N]
+    def _out(self, like: DeviceArray, out):
+        return out if out is not None else DeviceArray(self, like.shape)
+
+    def add(self, L, size, a, b, out=None, count=1, stream=None):
+        out = self._out(a, out)
+        capi.check(capi.lib().hefx_add(self._h, L, size, count, a.ptr, b.ptr, out.ptr, stream))
+        return out
+
+    def sub(self, L, size, a, b, out=None, count=1, stream=None):
+        out = self._out(a, out)
+        capi.check(capi.lib().hefx_sub(self._h, L, size, count, a.ptr, b.ptr, out.ptr, stream))
+        return out
+
+    def negate(self, L, size, a, out=None, count=1, stream=None):
+        out = self._out(a, out)
+        capi.check(capi.lib().hefx_negate(self._h, L, size, count, a.ptr, out.ptr, stream))
+        return out
+
+    def add_plain(self, L, size, ct, pt, out=None, stream=None):
+        out = self._out(ct, out)
+        capi.check(capi.lib().hefx_add_plain(self._h, L, size, ct.ptr, pt.ptr, out.ptr, stream))
+        return out
+
+    def add_many(self, L, size, cts: Sequence[DeviceArray], out=None, stream=None):
+        out = self._out(cts[0], out)
+        arr = capi.ptr_array([c.ptr for c in cts])
+        capi.check(capi.lib().hefx_add_many(self._h, L, size, len(cts), arr, out.ptr, stream))
+        return out
+
+    def multiply_plain(self, L, size, ct, pt, out=None, count=1, stream=None):
+        out = self._out(ct, out)
+        capi.check(capi.lib().hefx_multiply_plain(self._h, L, size, count, ct.ptr, pt.ptr, out.ptr, stream))
+        return out
+
+    def check_transparent(self, stream=None):
+        capi.check(capi.lib().hefx_check_transparent(self._h, stream))
+
+    def multiply(self, L, a, b, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (3, L, self.N))
+        capi.check(capi.lib().hefx_multiply(self._h, L, a.ptr, b.ptr, out.ptr, stream))
+        return out
+
+    def square(self, L, a, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (3, L, self.N))
+        capi.check(capi.lib().hefx_square(self._h, L, a.ptr, out.ptr, stream))
+        return out
+
+    # ---- key switching
+    def apply_galois(self, L, ct, elt, key, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        capi.check(capi.lib().hefx_apply_galois(self._h, L, ct.ptr, int(elt), key.ptr, out.ptr, stream))
+        return out
+
+    def apply_galois_batch(self, L, cts, elts, keys, outs=None, stream=None):
+        n = len(cts)
+        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        capi.check(capi.lib().hefx_apply_galois_batch(
+            self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
+            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
+    def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs=None, stream=None):
+        n = len(cts)
+        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        capi.check(capi.lib().hefx_rotate_multiply_plain_batch(
+            self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
+            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([p.ptr for p in pts]),
+            capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
+    def relinearize(self, L, ct3, key, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        capi.check(capi.lib().hefx_relinearize(self._h, L, ct3.ptr, key.ptr, out.ptr, stream))
+        return out
+
+    def relinearize_batch(self, L, ct3s, key, outs=None, stream=None):
+        n = len(ct3s)
+        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        capi.check(capi.lib().hefx_relinearize_batch(
+            self._h, L, n, capi.ptr_array([c.ptr for c in ct3s]), key.ptr,
+            capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
+    def rescale_to_next(self, L, size, ct, out=None, count=1, stream=None):
+        if out is None:
+            shape = (size, L - 1, self.N) if count == 1 else (count, size, L - 1, self.N)
+            out = DeviceArray(self, shape)
+        capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, count, ct.ptr, out.ptr, stream))
+        return out
+
+    def mod_drop(self, L_in, L_out, npoly, x, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (npoly, L_out, self.N))
+        capi.check(capi.lib().hefx_mod_drop(self._h, L_in, L_out, npoly, x.ptr, out.ptr, stream))
+        return out
+
+    def reduce_canonical(self, L, size, buf, addends=8, stream=None):
+        capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
+        return buf

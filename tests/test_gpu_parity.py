@@ -1,0 +1,214 @@
+"""GPU parity: every hefx_* compute entry point (through the C-ABI, ctypes) against the CPU oracle on the
+same seeded inputs.  Bar: bit-exact uint64 RNS coefficients."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_b.json")))
+SETS = {s["name"]: s for s in GOLD["sets"]}
+
+
+def _mk(name):
+    from oracle import oracle as O
+    from seal_fyp_logistic_regression_amd import Engine
+    s = SETS[name]
+    primes = [int(p, 16) for p in s["primes"]]
+    return O.Oracle(s["N"], primes), Engine(s["N"], primes), primes
+
+
+@pytest.fixture(scope="module")
+def c2():
+    return _mk("C2")
+
+
+@pytest.fixture(scope="module")
+def c3():
+    return _mk("C3")
+
+
+@pytest.mark.parametrize("n,bits", [(1024, [60, 40, 30]), (2048, [60, 40, 30]), (4096, [60, 36, 60]),
+                                    (8192, [60, 40, 60]), (16384, [60, 40, 50, 60])])
+def test_ntt_forward_inverse_bit_exact(n, bits):
+    from oracle import oracle as O
+    from seal_fyp_logistic_regression_amd import Engine
+    primes = O.coeff_modulus_create(n, bits)
+    o, e = O.Oracle(n, primes), Engine(n, primes)
+    for j in range(len(primes)):
+        assert e.psi(j) == o.psi(j)
+    k = len(primes)
+    a = o.uniform(k, 3, 42 + n)  # [3][k][n]
+    want = np.stack([np.stack([o.ntt_fwd(j, a[p, j]) for j in range(k)]) for p in range(3)])
+    d = e.to_device(a)
+    e.ntt_forward(d, 3, k, 0)
+    got = d.download()
+    assert (got == want).all()
+    e.ntt_inverse(d, 3, k, 0)
+    assert (d.download() == a).all()
+    # edge values: zeros, q-1 everywhere, single one
+    edge = np.zeros((1, k, n), dtype=np.uint64)
+    for j in range(k):
+        edge[0, j, :] = primes[j] - 1
+    want = np.stack([o.ntt_fwd(j, edge[0, j]) for j in range(k)])[None]
+    d = e.to_device(edge)
+    e.ntt_forward(d, 1, k, 0)
+    assert (d.download() == want).all()
+    # sub-range of moduli (mod_first > 0)
+    sub = np.ascontiguousarray(a[0, 1:])
+    d = e.to_device(sub)
+    e.ntt_forward(d, 1, k - 1, 1)
+    assert (d.download() == np.stack([o.ntt_fwd(j, a[0, j]) for j in range(1, k)])).all()
+
+
+def test_elementwise_ops(c2):
+    o, e, primes = c2
+    L = 3
+    a, b = o.uniform(L, 2, 1), o.uniform(L, 2, 2)
+    pt = o.uniform(L, 1, 3)[0]
+    da, db, dp = e.to_device(a), e.to_device(b), e.to_device(pt)
+    assert (e.add(L, 2, da, db).download() == o.add(a, b)).all()
+    assert (e.sub(L, 2, da, db).download() == o.sub(a, b)).all()
+    assert (e.negate(L, 2, da).download() == o.negate(a)).all()
+    assert (e.add_plain(L, 2, da, dp).download() == o.add_plain(a, pt)).all()
+    assert (e.multiply_plain(L, 2, da, dp).download() == o.multiply_plain(a, pt)).all()
+    e.check_transparent()
+    m = e.multiply(L, da, db).download()
+    assert (m == o.multiply(a, b)).all()
+    assert (e.square(L, da).download() == o.multiply(a, a)).all()
+    # size-3 operands (Linear_Transform_Cipher sums size-3 results, helper.h:231)
+    a3, b3 = o.uniform(L, 3, 4), o.uniform(L, 3, 5)
+    assert (e.add(L, 3, e.to_device(a3), e.to_device(b3)).download() == o.add(a3, b3)).all()
+    # lower level + contiguous batch of 4 ciphertexts
+    a2 = o.uniform(2, 8, 6).reshape(4, 2, 2, o.N)
+    b2 = o.uniform(2, 8, 7).reshape(4, 2, 2, o.N)
+    got = e.add(2, 2, e.to_device(a2), e.to_device(b2), count=4).download()
+    want = np.stack([o.add(a2[i], b2[i]) for i in range(4)])
+    assert (got == want).all()
+    # negate of zero stays zero
+    z = np.zeros((2, L, o.N), dtype=np.uint64)
+    assert (e.negate(L, 2, e.to_device(z)).download() == 0).all()
+
+
+def test_transparent_result_is_reported(c2):
+    from seal_fyp_logistic_regression_amd import capi
+    o, e, _ = c2
+    L = 3
+    a = o.uniform(L, 2, 1)
+    zero = np.zeros((L, o.N), dtype=np.uint64)
+    e.multiply_plain(L, 2, e.to_device(a), e.to_device(zero))
+    with pytest.raises(capi.TransparentCiphertextError):
+        e.check_transparent()
+    e.check_transparent()  # flag was cleared
+
+
+def test_add_many(c2):
+    o, e, _ = c2
+    L = 3
+    cts = [o.uniform(L, 2, 100 + i) for i in range(53)]  # > one pointer group
+    want = cts[0]
+    for c in cts[1:]:
+        want = o.add(want, c)
+    got = e.add_many(L, 2, [e.to_device(c) for c in cts]).download()
+    assert (got == want).all()
+    assert (e.add_many(L, 2, [e.to_device(cts[0])]).download() == cts[0]).all()
+
+
+def _rand_key(o, seed):
+    return o.uniform(o.k, 2 * (o.k - 1), seed).reshape(o.k - 1, 2, o.k, o.N)
+
+
+@pytest.mark.parametrize("setname", ["C2", "C3", "rot5"])
+def test_apply_galois_bit_exact(setname):
+    from oracle import oracle as O
+    o, e, primes = _mk(setname)
+    Ltop = o.k - 1
+    key = _rand_key(o, 7)
+    dkey = e.to_device(key)
+    for L in sorted({Ltop, max(1, Ltop - 1), 1}):
+        ct = o.uniform(L, 2, 11 + L)
+        for step in (1, -1, 4):
+            elt = O.galois_elt_from_step(o.N, step)
+            want = o.apply_galois(ct, elt, key)
+            got = e.apply_galois(L, e.to_device(ct), elt, dkey).download()
+            assert (got == want).all(), (setname, L, step)
+    # conjugation element 2N-1
+    ct = o.uniform(Ltop, 2, 99)
+    want = o.apply_galois(ct, 2 * o.N - 1, key)
+    assert (e.apply_galois(Ltop, e.to_device(ct), 2 * o.N - 1, dkey).download() == want).all()
+
+
+def test_rotate_multiply_plain_batch_bit_exact(c3):
+    from oracle import oracle as O
+    o, e, _ = c3
+    L = 5
+    n = 19  # > one chunk, ragged tail
+    keys = {s: _rand_key(o, 1000 + s) for s in (1, 2)}
+    dkeys = {s: e.to_device(k) for s, k in keys.items()}
+    cts = [o.uniform(L, 2, 200 + i) for i in range(n)]
+    pts = [o.uniform(L, 1, 300 + i)[0] for i in range(n)]
+    steps = [1 + (i % 2) for i in range(n)]
+    elts = [O.galois_elt_from_step(o.N, s) for s in steps]
+    outs = e.rotate_multiply_plain_batch(L, [e.to_device(c) for c in cts], elts, [dkeys[s] for s in steps],
+                                         [e.to_device(p) for p in pts])
+    for i in range(n):
+        want = o.rotate_mulplain(cts[i], elts[i], keys[steps[i]], pts[i])
+        assert (outs[i].download() == want).all(), i
+    # the unfused path gives the same bits
+    i = 3
+    r = e.apply_galois(L, e.to_device(cts[i]), elts[i], dkeys[steps[i]])
+    got = e.multiply_plain(L, 2, r, e.to_device(pts[i])).download()
+    assert (got == outs[i].download()).all()
+
+
+def test_relinearize_and_rescale_bit_exact(c3):
+    o, e, primes = c3
+    for L in (5, 2):
+        key = _rand_key(o, 5)
+        a, b = o.uniform(L, 2, 1), o.uniform(L, 2, 2)
+        m = o.multiply(a, b)
+        want = o.relinearize(m, key)
+        got = e.relinearize(L, e.to_device(m), e.to_device(key)).download()
+        assert (got == want).all()
+        outs = e.relinearize_batch(L, [e.to_device(m), e.to_device(o.multiply(b, b))], e.to_device(key))
+        assert (outs[0].download() == want).all()
+        assert (outs[1].download() == o.relinearize(o.multiply(b, b), key)).all()
+        rs = e.rescale_to_next(L, 2, e.to_device(want)).download()
+        assert rs.shape == (2, L - 1, o.N)
+        assert (rs == o.rescale(want)).all()
+        rs3 = e.rescale_to_next(L, 3, e.to_device(m)).download()
+        assert (rs3 == o.rescale(m)).all()
+    md = e.mod_drop(5, 3, 2, e.to_device(a if a.shape[1] == 5 else o.uniform(5, 2, 1))).download()
+    assert md.shape == (2, 3, o.N)
+
+
+def test_mod_drop_and_reduce(c3):
+    o, e, primes = c3
+    a = o.uniform(5, 2, 1)
+    assert (e.mod_drop(5, 3, 2, e.to_device(a)).download() == a[:, :3]).all()
+    # sum of 8 canonical words then canonicalise == 8 modular adds
+    parts = [o.uniform(5, 2, 50 + i) for i in range(8)]
+    raw = np.zeros_like(parts[0])
+    want = np.zeros_like(parts[0])
+    for p in parts:
+        raw = raw + p
+        want = o.add(want, p)
+    d = e.to_device(raw)
+    e.reduce_canonical(5, 2, d, addends=8)
+    assert (d.download() == want).all()
+
+
+def test_invalid_arguments_raise(c2):
+    o, e, _ = c2
+    a = e.to_device(o.uniform(3, 2, 1))
+    key = e.to_device(_rand_key(o, 1))
+    with pytest.raises(ValueError):
+        e.apply_galois(3, a, 4, key)  # even Galois element
+    with pytest.raises(ValueError):
+        e.apply_galois(4, a, 3, key)  # level above top data level
+    with pytest.raises(ValueError):
+        e.apply_galois(3, a, 3, key, out=a)  # aliasing
+    with pytest.raises(ValueError):
+        e.rescale_to_next(1, 2, a)
