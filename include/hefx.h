@@ -102,7 +102,7 @@ int hefx_square(hefx_context *ctx, int L, const uint64_t *d_a, uint64_t *d_out3,
 /* ---- K5/K6/K7: Evaluator::apply_galois_inplace = Galois permutation + key switch (one term of
  *      rotate_vector; helper.h:216,227,244,255,316,352,455,474; 5_rotation.cpp:215).
  *      d_key is the Galois key of `galois_elt` (the shim picks it: GaloisKeys index (elt-1)/2).
- *      in and out may alias. */
+ *      in and out may alias (rotate_vector_inplace). */
 int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_t galois_elt,
                       const uint64_t *d_key, uint64_t *d_ct_out, void *stream);
 /* n independent (ciphertext, element, key) triples in one launch sequence. */
@@ -134,6 +134,19 @@ int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint6
 /* ---- multi-GPU tail (no reference call site): after an RCCL sum all-reduce of uint64
  *      partial ciphertexts (<= `addends` canonical addends per word), bring every word back to [0,q_j). */
 int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, int addends, void *stream);
+
+/* ---- measurement helpers (no reference counterpart; the reference times with std::chrono around the L3
+ *      call, e.g. linear_transformation2.cpp:363-365).  HIP events recorded on the stream the kernels use. */
+int hefx_event_create(hefx_context *ctx, void **event);
+int hefx_event_destroy(hefx_context *ctx, void *event);
+int hefx_event_record(hefx_context *ctx, void *event, void *stream);
+int hefx_event_elapsed_ms(hefx_context *ctx, void *event_start, void *event_stop, float *ms); /* blocks */
+/* Between begin and end every key-switch chunk runs serially on the caller's stream with an event between
+ * its five launches; end returns the summed duration per launch kind (see hefx_profile_stage_name) and the
+ * number of chunks, so average launch duration = stage_ms[k] / launches. */
+int hefx_profile_begin(hefx_context *ctx);
+int hefx_profile_end(hefx_context *ctx, double *stage_ms /* [5] */, uint64_t *launches);
+const char *hefx_profile_stage_name(int k);
 
 #ifdef __cplusplus
 }

@@ -66,6 +66,13 @@ _SIGS = {
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "hefx_event_create": (_i, [_vp, _pp]),
+    "hefx_event_destroy": (_i, [_vp, _vp]),
+    "hefx_event_record": (_i, [_vp, _vp, _vp]),
+    "hefx_event_elapsed_ms": (_i, [_vp, _vp, _vp, C.POINTER(C.c_float)]),
+    "hefx_profile_begin": (_i, [_vp]),
+    "hefx_profile_end": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(_u64)]),
+    "hefx_profile_stage_name": (C.c_char_p, [_i]),
 }
 
 EXPORTED_SYMBOLS = sorted(_SIGS)

@@ -115,9 +115,15 @@ struct hefx_context {
     // scratch (grown on demand, reused across calls so it stays cache-resident)
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
-    int chunk = 16;
+    int chunk = 32;
     int *d_flag = nullptr;  // [0] transparent count, [1] per-call "non-zero seen"
-    bool transparent_check = false;
+    hipStream_t streams[2] = {nullptr, nullptr};  // internal streams for chunk pipelining
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    bool use_streams = true;
+    // profiling session (hefx_profile_begin/end): per-chunk event sextets, serial on the caller's stream
+    bool profiling = false;
+    std::vector<hipEvent_t> prof_events;
+    size_t prof_used = 0;
 };
 
 static int ensure_scratch(hefx_context *c, size_t words)
@@ -240,6 +246,12 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
+    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+        e = hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[s], hipEventDisableTiming);
+    }
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    if (const char *ev = getenv("HEFX_STREAMS")) c->use_streams = atoi(ev) != 0;
     if (e != hipSuccess) {
         if (c->d_tables) (void)hipFree(c->d_tables);
         delete c;
@@ -263,6 +275,12 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     for (auto &kv : c->perm) (void)hipFree(kv.second);
+    for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
+    for (int s = 0; s < 2; ++s) {
+        if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
+        if (c->ev_join[s]) (void)hipEventDestroy(c->ev_join[s]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -505,9 +523,13 @@ static int get_perm(hefx_context *c, uint32_t elt, const uint32_t **out)
 // ---------------------------------------------------------------------------------------------
 static size_t ks_words_per_item(const hefx_context *c, int L)
 {
-    return (size_t)c->n * ((size_t)L + (size_t)L * (L + 1) + 2 * (size_t)(L + 1) + 2);
+    // d: L, x: L(L+1), acc: 2(L+1), u: 2, p0: L   (units of N words)
+    return (size_t)c->n * ((size_t)L + (size_t)L * (L + 1) + 2 * (size_t)(L + 1) + 2 + (size_t)L);
 }
 
+// Chunks of a batch alternate between two internal streams (each with its own scratch half) so that the
+// small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
+// the next; the caller's stream is forked before and joined after.
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
                   uint64_t *const *ct_out, void *stream)
@@ -517,13 +539,21 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
     if (!relin && (!elts || !keys)) return fail(HEFX_ERR_INVALID, "missing Galois elements / keys");
     if (relin && !single_key) return fail(HEFX_ERR_INVALID, "missing relinearization key");
-    std::lock_guard<std::mutex> *lk = nullptr;
-    (void)lk;
     const int chunk = c->chunk;
     const size_t per = ks_words_per_item(c, L);
-    if (int rc = ensure_scratch(c, per * (size_t)(n < chunk ? n : chunk))) return rc;
+    const int nchunks = (n + chunk - 1) / chunk;
+    const bool two = nchunks > 1 && c->use_streams && !c->profiling;
+    const size_t half_words = per * (size_t)(n < chunk ? n : chunk);
+    if (int rc = ensure_scratch(c, half_words * (two ? 2 : 1))) return rc;
+    hipStream_t user = (hipStream_t)stream;
+    if (two) {
+        HIPCHK(hipEventRecord(c->ev_fork, user));
+        HIPCHK(hipStreamWaitEvent(c->streams[0], c->ev_fork, 0));
+        HIPCHK(hipStreamWaitEvent(c->streams[1], c->ev_fork, 0));
+    }
     const size_t N = c->n;
-    for (int base = 0; base < n; base += chunk) {
+    int ci = 0;
+    for (int base = 0; base < n; base += chunk, ++ci) {
         const int cnt = (n - base < chunk) ? n - base : chunk;
         KsBatch B{};
         for (int i = 0; i < cnt; ++i) {
@@ -533,22 +563,45 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             if (!it.c_in || !it.c_out) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
             it.pt = pts ? (const u64 *)pts[base + i] : nullptr;
             if (relin) {
+                if (it.c_in == it.c_out)
+                    return fail(HEFX_ERR_INVALID, "relinearize input and output must not alias");
                 it.key = (const u64 *)single_key;
                 it.perm = nullptr;
             } else {
-                if (it.c_in == it.c_out)
-                    return fail(HEFX_ERR_INVALID, "apply_galois input and output must not alias");
                 it.key = (const u64 *)keys[base + i];
                 if (!it.key) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
-                if (int rc = get_perm(c, elts[base + i], &it.perm)) return rc;
+                // kernels scatter through LDS: dest = table_{g^-1}[src]  (perm_g's inverse permutation)
+                const uint32_t g = elts[base + i];
+                if (!(g & 1) || g >= 2 * c->n) return fail(HEFX_ERR_INVALID, "Galois element must be odd and < 2N");
+                uint32_t ginv = g;  // Newton iteration for the inverse modulo 2^32, then reduce mod 2N
+                for (int it2 = 0; it2 < 5; ++it2) ginv *= 2u - g * ginv;
+                ginv &= 2 * c->n - 1;
+                if (int rc = get_perm(c, ginv, &it.perm)) return rc;
             }
         }
         KsScratch S;
-        S.d = c->scratch;
+        S.d = c->scratch + (two ? (size_t)(ci & 1) * half_words : 0);
         S.x = S.d + (size_t)cnt * L * N;
         S.acc = S.x + (size_t)cnt * L * (L + 1) * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, B, relin, S, (hipStream_t)stream));
+        S.p0 = S.u + (size_t)cnt * 2 * N;
+        hipEvent_t *ev = nullptr;
+        if (c->profiling) {
+            while (c->prof_events.size() < c->prof_used + 6) {
+                hipEvent_t e;
+                HIPCHK(hipEventCreate(&e));
+                c->prof_events.push_back(e);
+            }
+            ev = &c->prof_events[c->prof_used];
+            c->prof_used += 6;
+        }
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, B, relin, S, two ? c->streams[ci & 1] : user, ev));
+    }
+    if (two) {
+        for (int s = 0; s < 2; ++s) {
+            HIPCHK(hipEventRecord(c->ev_join[s], c->streams[s]));
+            HIPCHK(hipStreamWaitEvent(user, c->ev_join[s], 0));
+        }
     }
     return HEFX_OK;
 }
@@ -610,4 +663,69 @@ extern "C" int hefx_mod_drop(hefx_context *c, int L_in, int L_out, int npoly, co
     HIPCHK(hipMemcpy2DAsync(out, row * L_out, in, row * L_in, row * L_out, npoly, hipMemcpyDeviceToDevice,
                             (hipStream_t)stream));
     return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// timing helpers: HIP events on the stream the kernels are launched on
+// ---------------------------------------------------------------------------------------------
+extern "C" int hefx_event_create(hefx_context *c, void **ev)
+{
+    CTXCHK(c);
+    if (!ev) return fail(HEFX_ERR_INVALID, "null out pointer");
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void *)e;
+    return HEFX_OK;
+}
+extern "C" int hefx_event_destroy(hefx_context *c, void *ev)
+{
+    CTXCHK(c);
+    if (ev) HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return HEFX_OK;
+}
+extern "C" int hefx_event_record(hefx_context *c, void *ev, void *stream)
+{
+    CTXCHK(c);
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_event_elapsed_ms(hefx_context *c, void *ev_start, void *ev_stop, float *ms)
+{
+    CTXCHK(c);
+    if (!ms) return fail(HEFX_ERR_INVALID, "null out pointer");
+    HIPCHK(hipEventSynchronize((hipEvent_t)ev_stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)ev_start, (hipEvent_t)ev_stop));
+    return HEFX_OK;
+}
+
+extern "C" int hefx_profile_begin(hefx_context *c)
+{
+    CTXCHK(c);
+    HIPCHK(hipDeviceSynchronize());
+    c->profiling = true;
+    c->prof_used = 0;
+    return HEFX_OK;
+}
+extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *launches)
+{
+    CTXCHK(c);
+    if (!stage_ms || !launches) return fail(HEFX_ERR_INVALID, "null out pointer");
+    HIPCHK(hipDeviceSynchronize());
+    for (int k = 0; k < KS_STAGES; ++k) stage_ms[k] = 0.0;
+    *launches = c->prof_used / 6;
+    for (size_t base = 0; base + 6 <= c->prof_used; base += 6)
+        for (int k = 0; k < KS_STAGES; ++k) {
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, c->prof_events[base + k], c->prof_events[base + k + 1]));
+            stage_ms[k] += ms;
+        }
+    c->profiling = false;
+    c->prof_used = 0;
+    return HEFX_OK;
+}
+extern "C" const char *hefx_profile_stage_name(int k)
+{
+    static const char *names[KS_STAGES] = {"ks_intt_digits_kernel", "ks_ntt_digits_kernel", "ks_mac_kernel",
+                                           "ks_moddown_intt_kernel", "ks_moddown_finish_kernel"};
+    return (k >= 0 && k < KS_STAGES) ? names[k] : "";
 }

@@ -23,12 +23,12 @@ struct DevTables {
 struct KsItem {
     const u64 *c_in;   // source ciphertext, [2][L][N] (rotation) or [3][L][N] (relinearisation)
     const u64 *key;    // [k-1][2][k][N]
-    const uint32_t *perm;  // Galois gather table (N entries) or nullptr for relinearisation
+    const uint32_t *perm;  // scatter table of the Galois element (= gather table of g^-1), or nullptr for relin
     const u64 *pt;     // optional plaintext [L][N] multiplied into the result (fused multiply_plain)
     u64 *c_out;        // [2][L][N]
 };
 
-constexpr int KS_MAX_CHUNK = 32;
+constexpr int KS_MAX_CHUNK = 64;
 struct KsBatch {
     KsItem it[KS_MAX_CHUNK];
 };
@@ -39,6 +39,7 @@ struct KsScratch {
     u64 *x;    // [chunk][L][L+1][N]   digit i transformed to modulus slot jj (jj==L: special prime)
     u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
     u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
+    u64 *p0;   // [chunk][L][N]        perm_g(c0) of a rotation (added in by the mod-down epilogue)
 };
 
 constexpr int ADD_MANY_GROUP = 48;
@@ -57,8 +58,10 @@ hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int 
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
+// ev: nullptr, or 6 events recorded around the five launches (profiling)
+constexpr int KS_STAGES = 5;
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
-                                  const KsScratch &scr, hipStream_t s);
+                                  const KsScratch &scr, hipStream_t s, hipEvent_t *ev);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

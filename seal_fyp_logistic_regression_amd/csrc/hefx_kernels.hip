@@ -237,25 +237,51 @@ hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b
 // K5/K6/K7: key switch, five launches per chunk of items.
 // ------------------------------------------------------------------------------------------------
 
-// (1) digit i of item b: gather (Galois) -> keep NTT copy in x[b][i][i] -> INTT mod q_i -> d[b][i]
+// (1) digit i of item b: Galois permutation -> keep NTT copy in x[b][i][i] -> INTT mod q_i -> d[b][i].
+// The permutation is done through LDS (coalesced global read, LDS scatter by the table of g^-1, conflict-
+// free LDS read) instead of an 8-byte global gather that touches one cache line per lane.  For rotations the
+// extra blocks bx >= L write perm(c0[j]) into scratch p0[b][j]; the mod-down epilogue adds it in, so a rotation
+// may run in place (c_out == c_in): c_in is fully consumed by this kernel.
 template <int LOGN>
 __global__ __launch_bounds__(NttCfg<LOGN>::T, 4) void ks_intt_digits_kernel(DevTables T, KsBatch B, int L, int relin,
                                                                          KsScratch S)
 {
     using C = NttCfg<LOGN>;
     extern __shared__ __align__(16) u64 lds[];
-    const int t = threadIdx.x, i = blockIdx.x, b = blockIdx.y;
+    const int t = threadIdx.x, bx = blockIdx.x, b = blockIdx.y;
     const KsItem it = B.it[b];
-    const u64 *src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * C::N;
-    u64 *xd = S.x + (((size_t)b * L + i) * (L + 1) + i) * C::N;
     u64 v[16];
+    if (bx >= L) {  // rotation only: p0[b][j] = perm_g(c_in[0][j])
+        const int j = bx - L;
+        const u64 *src = it.c_in + (size_t)j * C::N;
+        u64 *dst = S.p0 + ((size_t)b * L + j) * C::N;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int idx = C::idx_out(t, r);
-        const int sidx = it.perm ? (int)it.perm[idx] : idx;
-        v[r] = src[sidx];
-        xd[idx] = v[r];
+        for (int r = 0; r < 16; ++r) v[r] = src[C::idx_nat(t, r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[C::phys((int)it.perm[C::idx_nat(t, r)])] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dst[C::idx_nat(t, r)] = lds[C::phys(C::idx_nat(t, r))];
+        return;
     }
+    const int i = bx;
+    const u64 *src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * C::N;
+    if (it.perm) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = src[C::idx_nat(t, r)];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lds[C::phys((int)it.perm[C::idx_nat(t, r)])] = v[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = lds[C::phys(C::idx_out(t, r))];
+        // no barrier needed: the INTT core's first LDS writes go to exactly the words this thread just read
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = src[C::idx_out(t, r)];
+    }
+    u64 *xd = S.x + (((size_t)b * L + i) * (L + 1) + i) * C::N;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
     ntt_inv_core<LOGN>(v, lds, T.itw + (size_t)i * C::N, T.mods[i], t);
     u64 *dd = S.d + ((size_t)b * L + i) * C::N;
 #pragma unroll
@@ -359,34 +385,44 @@ __global__ __launch_bounds__(NttCfg<LOGN>::T, 4) void ks_moddown_finish_kernel(D
     const u64 *ud = S.u + ((size_t)b * 2 + c) * C::N;
     u64 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        u64 x = ud[C::idx_nat(t, r)];
-        if (P > q) x = barrett64(x, q, mc.r1);
-        v[r] = submod(x, half_j, q);
-    }
-    ntt_fwd_core<LOGN>(v, lds, T.tw + (size_t)j * C::N, q, t);
-    const u64 *acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * C::N;
-    const u64 *addsrc = it.c_in + ((size_t)c * L + j) * C::N;
-    const bool has_add = relin || c == 0;
-    const u64 *pt = it.pt ? it.pt + (size_t)j * C::N : nullptr;
-    u64 *dst = it.c_out + ((size_t)c * L + j) * C::N;
+    for (int r = 0; r < 16; ++r) v[r] = ud[C::idx_nat(t, r)];  // all 16 loads in flight before any use
+    (void)P;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int idx = C::idx_out(t, r);
-        u64 x = submod(acc[idx], v[r], q);
-        x = csub(shoup_lazy(x, pinv.x, pinv.y, q), q);
-        if (has_add) {
-            const int sidx = it.perm ? (int)it.perm[idx] : idx;
-            x = addmod(x, addsrc[sidx], q);
+    for (int r = 0; r < 16; ++r) v[r] = submod(barrett64(v[r], q, mc.r1), half_j, q);  // exact for P <= q too
+    ntt_fwd_core<LOGN>(v, lds, T.tw + (size_t)j * C::N, q, t);
+    // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (1) left in S.p0.
+    // All operand loads of a half (8 coefficients) are issued before any store so their latency overlaps.
+    const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * C::N;
+    const u64 *__restrict__ addsrc =
+        relin ? it.c_in + ((size_t)c * L + j) * C::N : S.p0 + ((size_t)b * L + j) * C::N;
+    const bool has_add = relin || c == 0;
+    const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * C::N : nullptr;
+    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * C::N;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u64 a[8], sadd[8], pp[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = C::idx_out(t, 8 * h + r);
+            a[r] = acc[idx];
+            sadd[r] = has_add ? addsrc[idx] : 0;
+            pp[r] = pt ? pt[idx] : 0;
         }
-        if (pt) x = mulmod(x, pt[idx], mc);
-        dst[idx] = x;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int idx = C::idx_out(t, 8 * h + r);
+            u64 x = submod(a[r], v[8 * h + r], q);
+            x = csub(shoup_lazy(x, pinv.x, pinv.y, q), q);
+            x = addmod(x, sadd[r], q);
+            if (pt) x = mulmod(x, pp[r], mc);
+            dst[idx] = x;
+        }
     }
 }
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
-                                           const KsScratch &scr, hipStream_t s)
+                                           const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
 {
     using C = NttCfg<LOGN>;
     const size_t lds = sizeof(u64) * C::LDS_WORDS;
@@ -403,18 +439,28 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         attr_done = true;
     }
     const int rl = relin ? 1 : 0;
-    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(L, n), dim3(C::T), lds, s, T, batch, L, rl, scr);
+    // optional profiling: ev[0..5] bracket the five launches (hefx_profile_*), recorded on the same stream
+#define HEFX_EV(i) \
+    if (ev) (void)hipEventRecord(ev[i], s)
+    HEFX_EV(0);
+    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(relin ? L : 2 * L, n), dim3(C::T), lds, s, T, batch, L, rl, scr);
+    HEFX_EV(1);
     hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(L * L, n), dim3(C::T), lds, s, T, L, scr);
+    HEFX_EV(2);
     hipLaunchKernelGGL(ks_mac_kernel, dim3(C::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
+    HEFX_EV(3);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(2, n), dim3(C::T), lds, s, T, L, scr);
+    HEFX_EV(4);
     hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(2 * L, n), dim3(C::T), lds, s, T, batch, L, rl, scr);
+    HEFX_EV(5);
+#undef HEFX_EV
     return hipGetLastError();
 }
 
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
-                                  const KsScratch &scr, hipStream_t s)
+                                  const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
 {
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, s)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, s, ev)
     HEFX_DISPATCH_LOGN(T.logn, CALL)
 #undef CALL
 }
@@ -453,10 +499,10 @@ __global__ __launch_bounds__(NttCfg<LOGN>::T, 4) void rs_finish_kernel(DevTables
     const u64 *dd = d + poly * C::N;
     u64 v[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        u64 x = dd[C::idx_nat(t, r)];
-        if (ql > q) x = barrett64(x, q, mc.r1);
-        v[r] = x;
+    for (int r = 0; r < 16; ++r) v[r] = dd[C::idx_nat(t, r)];
+    if (ql > q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = barrett64(v[r], q, mc.r1);
     }
     ntt_fwd_core<LOGN>(v, lds, T.tw + (size_t)j * C::N, q, t);
     const u64 *src = in + (poly * L + j) * C::N;

@@ -224,3 +224,31 @@ class Engine:
     def reduce_canonical(self, L, size, buf, addends=8, stream=None):
         capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
         return buf
+
+    # ---- measurement
+    def event(self):
+        ev = C.c_void_p()
+        capi.check(capi.lib().hefx_event_create(self._h, C.byref(ev)))
+        return ev
+
+    def event_record(self, ev, stream=None):
+        capi.check(capi.lib().hefx_event_record(self._h, ev, stream))
+
+    def event_elapsed_ms(self, ev0, ev1) -> float:
+        ms = C.c_float()
+        capi.check(capi.lib().hefx_event_elapsed_ms(self._h, ev0, ev1, C.byref(ms)))
+        return float(ms.value)
+
+    def event_destroy(self, ev):
+        capi.check(capi.lib().hefx_event_destroy(self._h, ev))
+
+    def profile_begin(self):
+        capi.check(capi.lib().hefx_profile_begin(self._h))
+
+    def profile_end(self):
+        """-> ({launch kind: summed ms}, number of chunks)"""
+        ms = (C.c_double * 5)()
+        n = C.c_uint64()
+        capi.check(capi.lib().hefx_profile_end(self._h, ms, C.byref(n)))
+        names = [capi.lib().hefx_profile_stage_name(k).decode() for k in range(5)]
+        return {names[k]: float(ms[k]) for k in range(5)}, int(n.value)

@@ -134,6 +134,11 @@ def test_apply_galois_bit_exact(setname):
             want = o.apply_galois(ct, elt, key)
             got = e.apply_galois(L, e.to_device(ct), elt, dkey).download()
             assert (got == want).all(), (setname, L, step)
+    # in place (rotate_vector_inplace, helper.h:474)
+    ct = o.uniform(Ltop, 2, 98)
+    d = e.to_device(ct)
+    e.apply_galois(Ltop, d, O.galois_elt_from_step(o.N, 1), dkey, out=d)
+    assert (d.download() == o.apply_galois(ct, O.galois_elt_from_step(o.N, 1), key)).all()
     # conjugation element 2N-1
     ct = o.uniform(Ltop, 2, 99)
     want = o.apply_galois(ct, 2 * o.N - 1, key)
@@ -208,7 +213,5 @@ def test_invalid_arguments_raise(c2):
         e.apply_galois(3, a, 4, key)  # even Galois element
     with pytest.raises(ValueError):
         e.apply_galois(4, a, 3, key)  # level above top data level
-    with pytest.raises(ValueError):
-        e.apply_galois(3, a, 3, key, out=a)  # aliasing
     with pytest.raises(ValueError):
         e.rescale_to_next(1, 2, a)

@@ -20,9 +20,18 @@ def rnd(*shape):
         out[idx] = rng.integers(0, primes[idx[-1]], N, dtype=np.uint64)
     return out
 key = e.to_device(rnd(L, 2, k))
-cts = [e.to_device(rnd(2, L)) for _ in range(B)]
-pts = [e.to_device(rnd(L)) for _ in range(B)]
-outs = [e.empty(2, L, N) for _ in range(B)]
+SLAB = os.environ.get("SLAB", "1") != "0"
+if SLAB:  # one allocation per tensor class, items are views (what a pooling allocator gives)
+    big_ct = e.to_device(np.stack([rnd(2, L) for _ in range(B)]))
+    big_pt = e.to_device(np.stack([rnd(L) for _ in range(B)]))
+    big_out = e.empty(B, 2, L, N)
+    cts = [big_ct.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
+    pts = [big_pt.view(i * L * N, (L, N)) for i in range(B)]
+    outs = [big_out.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
+else:
+    cts = [e.to_device(rnd(2, L)) for _ in range(B)]
+    pts = [e.to_device(rnd(L)) for _ in range(B)]
+    outs = [e.empty(2, L, N) for _ in range(B)]
 elts = [3] * B
 for _ in range(2):
     e.rotate_multiply_plain_batch(L, cts, elts, [key] * B, pts, outs)
