@@ -142,10 +142,10 @@ int hefx_event_destroy(hefx_context *ctx, void *event);
 int hefx_event_record(hefx_context *ctx, void *event, void *stream);
 int hefx_event_elapsed_ms(hefx_context *ctx, void *event_start, void *event_stop, float *ms); /* blocks */
 /* Between begin and end every key-switch chunk runs serially on the caller's stream with an event between
- * its five launches; end returns the summed duration per launch kind (see hefx_profile_stage_name) and the
+ * its launches; end returns the summed duration per launch kind (see hefx_profile_stage_name) and the
  * number of chunks, so average launch duration = stage_ms[k] / launches. */
 int hefx_profile_begin(hefx_context *ctx);
-int hefx_profile_end(hefx_context *ctx, double *stage_ms /* [5] */, uint64_t *launches);
+int hefx_profile_end(hefx_context *ctx, double *stage_ms /* [6] */, uint64_t *launches);
 const char *hefx_profile_stage_name(int k);
 
 #ifdef __cplusplus

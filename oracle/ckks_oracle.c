@@ -498,7 +498,18 @@ void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *targe
     const uint64_t n = c->N;
     const int k = c->k, sp = k - 1; /* special-prime index at key level */
     const int nm = L + 1;           /* moduli touched: q_0..q_{L-1}, P */
-    u128 *acc = (u128 *)calloc((size_t)2 * nm * n, sizeof(u128));
+    /* per-thread scratch kept across calls (as SEAL's MemoryPool does): a fresh multi-MB calloc per call
+     * serialises all-core baseline runs on the kernel's mmap lock */
+    static __thread u128 *tl_acc = NULL;
+    static __thread size_t tl_acc_words = 0;
+    const size_t acc_words = (size_t)2 * nm * n;
+    if (tl_acc_words < acc_words) {
+        free(tl_acc);
+        tl_acc = (u128 *)malloc(acc_words * sizeof(u128));
+        tl_acc_words = acc_words;
+    }
+    u128 *acc = tl_acc;
+    memset(acc, 0, acc_words * sizeof(u128));
     uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * n);
     uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * n);
 
@@ -550,7 +561,6 @@ void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *targe
             }
         }
     }
-    free(acc);
     free(d);
     free(x);
 }

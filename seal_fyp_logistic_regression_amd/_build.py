@@ -7,7 +7,7 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libhefx.so")
-SOURCES = ["hefx_kernels.hip", "hefx_capi.cpp"]
+SOURCES = ["hefx_kernels.hip", "hefx_keyswitch.hip", "hefx_capi.cpp"]
 DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "../../include/hefx.h"]
 
 
@@ -31,7 +31,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c",
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip", "-c",
                os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))

@@ -79,7 +79,8 @@ EXPORTED_SYMBOLS = sorted(_SIGS)
 
 
 def library_path() -> str:
-    return _build.SO
+    # HEFX_LIB: development override to A/B alternative builds of the same ABI
+    return os.environ.get("HEFX_LIB") or _build.SO
 
 
 def lib():

@@ -158,8 +158,8 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     int logn = 0;
     while ((1u << logn) < poly_degree) ++logn;
     if ((1u << logn) != poly_degree) return fail(HEFX_ERR_INVALID, "poly_degree must be a power of two");
-    if (logn < 10 || logn > 14)
-        return fail(HEFX_ERR_UNSUPPORTED, "poly_degree must be in [1024, 16384] in this build");
+    if (logn < 10 || logn > 15)
+        return fail(HEFX_ERR_UNSUPPORTED, "poly_degree must be in [1024, 32768] in this build");
     if (k < 1 || k > 62) return fail(HEFX_ERR_INVALID, "prime count out of range");
     const u64 two_n = 2ull * poly_degree;
     for (int j = 0; j < k; ++j) {
@@ -193,13 +193,18 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     const size_t mods_bytes = sizeof(ModConst) * k;
     const size_t inv_bytes = sizeof(ulonglong2) * k * k;
     const size_t half_bytes = sizeof(u64) * k * k;
-    const size_t total = 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes;
+    const size_t modsf_bytes = sizeof(ModConstF) * k;
+    const size_t total = 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes;
     std::vector<unsigned char> host(total);
     ulonglong2 *tw = reinterpret_cast<ulonglong2 *>(host.data());
     ulonglong2 *itw = tw + n * k;
     ModConst *mods = reinterpret_cast<ModConst *>(itw + n * k);
     ulonglong2 *invmod = reinterpret_cast<ulonglong2 *>(mods + k);
     u64 *halfmod = reinterpret_cast<u64 *>(invmod + (size_t)k * k);
+    double2 *twf = reinterpret_cast<double2 *>(halfmod + (size_t)k * k);
+    double2 *itwf = twf + n * k;
+    ModConstF *modsf = reinterpret_cast<ModConstF *>(itwf + n * k);
+    static_assert(sizeof(double2) == sizeof(ulonglong2), "twiddle record size");
 
     for (int j = 0; j < k; ++j) {
         const u64 q = primes[j];
@@ -228,6 +233,23 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         m.ilw = h_mulmod(itw[(size_t)j * n + 1].x, m.ninv, q);
         m.ilw_s = h_shoup(m.ilw, q);
         m.pad = 0;
+        // FP64 policy (exact FMA modmul) for primes below 2^41; HEFX_NO_FP64=1 forces the integer policy
+        ModConstF &f = modsf[j];
+        memset(&f, 0, sizeof f);
+        if ((q >> 41) == 0 && !getenv("HEFX_NO_FP64")) {
+            const double qd = (double)q;
+            f.q = qd;
+            f.qinv = 1.0 / qd;
+            f.ninv = (double)m.ninv;
+            f.ninv_r = (double)m.ninv / qd;
+            f.ilw = (double)m.ilw;
+            f.ilw_r = (double)m.ilw / qd;
+            for (size_t i = 0; i < n; ++i) {
+                const double w = (double)tw[(size_t)j * n + i].x, iw = (double)itw[(size_t)j * n + i].x;
+                twf[(size_t)j * n + i] = make_double2(w, w / qd);
+                itwf[(size_t)j * n + i] = make_double2(iw, iw / qd);
+            }
+        }
     }
     for (int l = 0; l < k; ++l)
         for (int j = 0; j < k; ++j) {
@@ -263,6 +285,9 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     c->T.mods = reinterpret_cast<const ModConst *>(base + 2 * tw_bytes);
     c->T.invmod = reinterpret_cast<const ulonglong2 *>(base + 2 * tw_bytes + mods_bytes);
     c->T.halfmod = reinterpret_cast<const u64 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes);
+    c->T.twf = reinterpret_cast<const double2 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
+    c->T.itwf = c->T.twf + n * k;
+    c->T.modsf = reinterpret_cast<const ModConstF *>(base + 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
     c->T.k = k;
     c->T.logn = logn;
     *out = c;
@@ -358,6 +383,7 @@ static int check_level(const hefx_context *c, int L)
 }
 static int check_ks_level(const hefx_context *c, int L)
 {
+    if (c->logn < 11) return fail(HEFX_ERR_UNSUPPORTED, "key switching / rescale need poly_degree >= 2048");
     if (c->k < 2) return fail(HEFX_ERR_INVALID, "key switching needs a special prime (k >= 2)");
     if (L < 1 || L > c->k - 1) return fail(HEFX_ERR_INVALID, "key-switch level L must be in [1, k-1]");
     return HEFX_OK;
@@ -371,6 +397,13 @@ static int ntt_common(hefx_context *c, bool inv, uint64_t *d, int npoly, int nro
     CTXCHK(c);
     if (!d || npoly < 1 || nrows < 1 || mod_first < 0 || mod_first + nrows > c->k)
         return fail(HEFX_ERR_INVALID, "bad NTT arguments");
+    if (c->logn == 15) {  // split kernels are out of place: transform into scratch, copy back
+        const size_t words = (size_t)c->n * npoly * nrows;
+        if (int rc = ensure_scratch(c, words)) return rc;
+        HIPCHK(launch_ntt_split15(c->T, inv, (const u64 *)d, c->scratch, npoly, nrows, mod_first, (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(d, c->scratch, words * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return HEFX_OK;
+    }
     HIPCHK(launch_ntt(c->T, inv, (u64 *)d, npoly, nrows, mod_first, (hipStream_t)stream));
     return HEFX_OK;
 }
@@ -570,13 +603,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             } else {
                 it.key = (const u64 *)keys[base + i];
                 if (!it.key) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
-                // kernels scatter through LDS: dest = table_{g^-1}[src]  (perm_g's inverse permutation)
-                const uint32_t g = elts[base + i];
-                if (!(g & 1) || g >= 2 * c->n) return fail(HEFX_ERR_INVALID, "Galois element must be odd and < 2N");
-                uint32_t ginv = g;  // Newton iteration for the inverse modulo 2^32, then reduce mod 2N
-                for (int it2 = 0; it2 < 5; ++it2) ginv *= 2u - g * ginv;
-                ginv &= 2 * c->n - 1;
-                if (int rc = get_perm(c, ginv, &it.perm)) return rc;
+                if (int rc = get_perm(c, elts[base + i], &it.perm)) return rc;
             }
         }
         KsScratch S;
@@ -587,13 +614,13 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         S.p0 = S.u + (size_t)cnt * 2 * N;
         hipEvent_t *ev = nullptr;
         if (c->profiling) {
-            while (c->prof_events.size() < c->prof_used + 6) {
+            while (c->prof_events.size() < c->prof_used + (KS_STAGES + 1)) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));
                 c->prof_events.push_back(e);
             }
             ev = &c->prof_events[c->prof_used];
-            c->prof_used += 6;
+            c->prof_used += KS_STAGES + 1;
         }
         HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, B, relin, S, two ? c->streams[ci & 1] : user, ev));
     }
@@ -648,6 +675,7 @@ extern "C" int hefx_rescale_to_next(hefx_context *c, int L, int size, int count,
     if (L < 2) return fail(HEFX_ERR_INVALID, "cannot rescale at the last level");
     if (size < 1 || count < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad rescale arguments");
     if (in == out) return fail(HEFX_ERR_INVALID, "rescale input and output must not alias");
+    if (c->logn < 11) return fail(HEFX_ERR_UNSUPPORTED, "key switching / rescale need poly_degree >= 2048");
     if (int rc = ensure_scratch(c, (size_t)c->n * size * count)) return rc;
     HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, c->scratch, (hipStream_t)stream));
     return HEFX_OK;
@@ -712,8 +740,8 @@ extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *lau
     if (!stage_ms || !launches) return fail(HEFX_ERR_INVALID, "null out pointer");
     HIPCHK(hipDeviceSynchronize());
     for (int k = 0; k < KS_STAGES; ++k) stage_ms[k] = 0.0;
-    *launches = c->prof_used / 6;
-    for (size_t base = 0; base + 6 <= c->prof_used; base += 6)
+    *launches = c->prof_used / (KS_STAGES + 1);
+    for (size_t base = 0; base + KS_STAGES + 1 <= c->prof_used; base += KS_STAGES + 1)
         for (int k = 0; k < KS_STAGES; ++k) {
             float ms = 0.f;
             HIPCHK(hipEventElapsedTime(&ms, c->prof_events[base + k], c->prof_events[base + k + 1]));
@@ -725,7 +753,8 @@ extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *lau
 }
 extern "C" const char *hefx_profile_stage_name(int k)
 {
-    static const char *names[KS_STAGES] = {"ks_intt_digits_kernel", "ks_ntt_digits_kernel", "ks_mac_kernel",
+    static const char *names[KS_STAGES] = {"ks_prepare_kernel",      "ks_intt_digits_kernel",
+                                           "ks_ntt_digits_kernel",   "ks_mac_kernel",
                                            "ks_moddown_intt_kernel", "ks_moddown_finish_kernel"};
     return (k >= 0 && k < KS_STAGES) ? names[k] : "";
 }

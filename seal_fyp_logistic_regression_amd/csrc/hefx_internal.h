@@ -12,18 +12,32 @@ namespace hefx {
 struct DevTables {
     const ulonglong2 *tw;      // [k][N]  forward twiddles {w, floor(w*2^64/q)}, w[bitrev(i)] = psi^i
     const ulonglong2 *itw;     // [k][N]  inverse twiddles, itw[idx] = tw[idx]^-1
+    const double2 *twf;        // [k][N]  FP64-policy forward twiddles {w, RN(w/q)} (primes < 2^41 only)
+    const double2 *itwf;       // [k][N]  FP64-policy inverse twiddles
     const ModConst *mods;      // [k]
+    const ModConstF *modsf;    // [k]     q == 0 marks a prime too wide for the FP64 policy
     const ulonglong2 *invmod;  // [k][k]  invmod[l*k+j] = {q_l^-1 mod q_j, Shoup companion} (l != j)
     const u64 *halfmod;        // [k][k]  (q_l >> 1) mod q_j
     int k;
     int logn;
 };
 
+__device__ __forceinline__ NttTables ntt_tables(const DevTables &T, int m)
+{
+    const size_t o = (size_t)m << T.logn;
+    NttTables nt;
+    nt.tw = T.tw + o;
+    nt.itw = T.itw + o;
+    nt.twf = T.twf + o;
+    nt.itwf = T.itwf + o;
+    return nt;
+}
+
 // One key-switch work item (a rotation term or a relinearisation).
 struct KsItem {
     const u64 *c_in;   // source ciphertext, [2][L][N] (rotation) or [3][L][N] (relinearisation)
     const u64 *key;    // [k-1][2][k][N]
-    const uint32_t *perm;  // scatter table of the Galois element (= gather table of g^-1), or nullptr for relin
+    const uint32_t *perm;  // gather table of the Galois element (out[i] = in[perm[i]]), or nullptr for relin
     const u64 *pt;     // optional plaintext [L][N] multiplied into the result (fused multiply_plain)
     u64 *c_out;        // [2][L][N]
 };
@@ -58,10 +72,13 @@ hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int 
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
-// ev: nullptr, or 6 events recorded around the five launches (profiling)
-constexpr int KS_STAGES = 5;
+// ev: nullptr, or KS_STAGES+1 events recorded around the launches of one chunk (profiling)
+constexpr int KS_STAGES = 6;
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
                                   const KsScratch &scr, hipStream_t s, hipEvent_t *ev);
+// out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
+hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
+                              int mod_first, hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

@@ -1,0 +1,479 @@
+// hefx_keyswitch.hip -- key switching (K5/K6/K7), rescale (K8) and the large-N stand-alone NTT, built on
+// "split-2" NTT workgroups.
+//
+// Why split: a 2^14-point row needs 136 KiB of LDS, i.e. ONE 1024-thread workgroup per CU whose load / compute
+// / exchange / store phases run back to back; measured, such a workgroup spends about as long waiting on its
+// ~24 GB/s-per-CU memory phases as on its integer butterflies.  Every transform here is therefore run by TWO
+// workgroups of N/32 threads that each own a 2^(LOGN-1)-point sub-transform (68 KiB LDS at N=16384), so two
+// (or more) independent workgroups share a CU and one's memory phase overlaps the other's butterflies:
+//   forward (Cooley-Tukey):   the first stage (gap N/2, one twiddle) is applied while loading -- both halves
+//       load x[j], x[j+N/2] and keep X (half 0) or Y (half 1); the remaining stages are an independent
+//       N/2-point transform of that half with twiddle prefix 2+h.  ~7 % redundant multiplies, no exchange.
+//   inverse (Gentleman-Sande): the first stage (gap 1) pairs (2j, 2j+1); half 0 keeps the sums, half 1 the
+//       twiddled differences, and from then on even and odd positions never meet again: each half is a
+//       standard N/2-point inverse transform (same table, N^-1 folded as usual) whose result is the even /
+//       odd coefficients.  Inverse outputs are stored DE-INTERLEAVED ([evens | odds], "EO"), which the
+//       forward loaders read with full coalescing (x[j] and x[j+N/2] have the parity of the thread id).
+// The two halves of a row get block ids that differ by 8, i.e. land on the same XCD (same L2) under the
+// round-robin dispatch, so the second read of the row is an L2 hit.  Placement only affects speed.
+#include <cstdio>
+#include <cstdlib>
+#include "hefx_internal.h"
+#include "hefx_ntt.cuh"
+
+// minimum waves per SIMD the NTT workgroups are register-allocated for (second __launch_bounds__ argument)
+#ifndef HEFX_WAVES
+#define HEFX_WAVES 4
+#endif
+
+namespace hefx {
+
+template <int LOGN>
+struct SplitCfg {
+    using C = NttCfg<LOGN - 1>;  // the per-workgroup sub-transform
+    static constexpr int N = 1 << LOGN;
+    static constexpr int H = N / 2;
+    static constexpr int T = C::T;  // threads per workgroup = N/32
+    static constexpr size_t LDS_BYTES = sizeof(u64) * C::LDS_WORDS;
+};
+
+// rows -> grid: halves of row p sit at block ids that differ by 8
+__host__ __device__ static inline int split_grid(int rows) { return ((rows + 7) / 8) * 16; }
+__device__ static __forceinline__ void split_decode(int bid, int &p, int &h)
+{
+    h = (bid >> 3) & 1;
+    p = ((bid >> 4) << 3) | (bid & 7);
+}
+// index of coefficient j in a row stored de-interleaved
+__device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j >> 1); }
+
+// ------------------------------------------------------------------------------------------------
+// (0) preparation: x[b][i][i] = perm_g(c1[i]) (or c2[i] for relinearisation), p0[b][j] = perm_g(c0[j]).
+// Plain gather at full occupancy; two outputs (16 B store) per lane.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, KsBatch B, int L, int relin, KsScratch S)
+{
+    const int logn = T.logn;
+    const size_t n = (size_t)1 << logn;
+    const int row = blockIdx.y, b = blockIdx.z;
+    const KsItem it = B.it[b];
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const u64 *__restrict__ src;
+    u64 *__restrict__ dst;
+    if (row < L) {
+        src = it.c_in + ((size_t)(relin ? 2 * L : L) + row) * n;
+        dst = S.x + (((size_t)b * L + row) * (L + 1) + row) * n;
+    } else {
+        src = it.c_in + (size_t)(row - L) * n;
+        dst = S.p0 + ((size_t)b * L + (row - L)) * n;
+    }
+    ulonglong2 o;
+    if (it.perm) {
+        const uint2 pi = *reinterpret_cast<const uint2 *>(it.perm + w);
+        o.x = src[pi.x];
+        o.y = src[pi.y];
+    } else {
+        o = *reinterpret_cast<const ulonglong2 *>(src + w);
+    }
+    *reinterpret_cast<ulonglong2 *>(dst + w) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (1) digit i of item b: d[b][i] (EO) = INTT_{q_i}(x[b][i][i])
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_intt_digits_kernel(DevTables T, int L, int rows,
+                                                                              KsScratch S)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int b = p / L, i = p % L;
+    const ulonglong2 *__restrict__ src =
+        reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)b * L + i) * (L + 1) + i) * SC::N);
+    u64 v[16];
+    split_inv<LOGN>(v, src, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
+    u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
+                                                                             KsScratch S)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int b = p / (L * L), rem = p % (L * L);
+    const int i = rem / L;
+    int jj = rem % L;
+    if (jj >= i) ++jj;  // skip the diagonal; jj == L is the special prime
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const u64 qi = T.mods[i].q;
+    const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N;
+    u64 v[16];
+    const bool reduce = qi > mc.q;
+    auto ld = [&](int r, u64 &x, u64 &y) {
+        const int e = eo(C::idx_nat(t, r), SC::H);
+        x = dd[e];
+        y = dd[e + SC::H / 2];
+        if (reduce) {
+            x = barrett64(x, mc.q, mc.r1);
+            y = barrett64(y, mc.q, mc.r1);
+        }
+    };
+    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+    u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3) acc[b][c][jj] = sum_i x[b][i][jj] * key[i][c][m]  (128-bit lazy accumulation, one Barrett at the end)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, KsBatch B, int L, KsScratch S)
+{
+    const int logn = T.logn;
+    const size_t n = (size_t)1 << logn;
+    const int jj = blockIdx.y, b = blockIdx.z;
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
+    const KsItem it = B.it[b];
+    u64 a0xl = 0, a0xh = 0, a0yl = 0, a0yh = 0, a1xl = 0, a1xh = 0, a1yl = 0, a1yh = 0;
+    for (int i = 0; i < L; ++i) {
+        const ulonglong2 x =
+            reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)b * L + i) * (L + 1) + jj) * n)[w];
+        const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
+        const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
+        const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
+        mac128(a0xl, a0xh, x.x, k0.x);
+        mac128(a0yl, a0yh, x.y, k0.y);
+        mac128(a1xl, a1xh, x.x, k1.x);
+        mac128(a1yl, a1yh, x.y, k1.y);
+    }
+    ulonglong2 r0, r1;
+    r0.x = barrett128(a0xl, a0xh, mc);
+    r0.y = barrett128(a0yl, a0yh, mc);
+    r1.x = barrett128(a1xl, a1xh, mc);
+    r1.y = barrett128(a1yl, a1yh, mc);
+    reinterpret_cast<ulonglong2 *>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n)[w] = r0;
+    reinterpret_cast<ulonglong2 *>(S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n)[w] = r1;
+}
+
+// ------------------------------------------------------------------------------------------------
+// (4) u[b][c] (EO) = (INTT_P(acc[b][c][P]) + floor(P/2)) mod P
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_intt_kernel(DevTables T, int L, int rows,
+                                                                               KsScratch S)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int sp = T.k - 1;
+    const ModConst mc = T.mods[sp];
+    const ulonglong2 *__restrict__ src =
+        reinterpret_cast<const ulonglong2 *>(S.acc + ((size_t)p * (L + 1) + L) * SC::N);  // p = b*2 + c
+    u64 v[16];
+    split_inv<LOGN>(v, src, lds, ntt_tables(T, sp), mc, T.modsf[sp], t, h);
+    const u64 half = mc.q >> 1;
+    u64 *__restrict__ ud = S.u + (size_t)p * SC::N + (size_t)h * SC::H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) ud[C::idx_nat(t, r)] = csub(v[r] + half, mc.q);
+}
+
+// ------------------------------------------------------------------------------------------------
+// (5) out[b][c][j] = (acc[b][c][j] - NTT_j((u mod q_j) - (P/2 mod q_j))) * P^-1 + add-in, optionally * pt
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_finish_kernel(DevTables T, KsBatch B, int L,
+                                                                                 int relin, int rows, KsScratch S)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int b = p / (2 * L), c = (p / L) & 1, j = p % L;
+    const int sp = T.k - 1;
+    const ModConst mc = T.mods[j];
+    const u64 q = mc.q;
+    const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
+    const ulonglong2 pinv = T.invmod[(size_t)sp * T.k + j];
+    const KsItem it = B.it[b];
+    const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
+    u64 v[16];
+    auto ld = [&](int r, u64 &x, u64 &y) {  // barrett64 is exact for any 64-bit input, also when P <= q
+        const int e = eo(C::idx_nat(t, r), SC::H);
+        x = submod(barrett64(ud[e], q, mc.r1), half_j, q);
+        y = submod(barrett64(ud[e + SC::H / 2], q, mc.r1), half_j, q);
+    };
+    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (0) left in S.p0.
+    // The operand loads of a group of 4 coefficients are issued before any of its stores.
+    const size_t off = (size_t)h * SC::H;
+    const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * SC::N + off;
+    const u64 *__restrict__ addsrc =
+        (relin ? it.c_in + ((size_t)c * L + j) * SC::N : S.p0 + ((size_t)b * L + j) * SC::N) + off;
+    const bool has_add = relin || c == 0;
+    const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
+    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
+#pragma unroll
+    for (int hh = 0; hh < 4; ++hh) {
+        u64 a[4], sadd[4], pp[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = C::idx_out(t, 4 * hh + r);
+            a[r] = acc[idx];
+            sadd[r] = has_add ? addsrc[idx] : 0;
+            pp[r] = pt ? pt[idx] : 0;
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int idx = C::idx_out(t, 4 * hh + r);
+            u64 z = submod(a[r], v[4 * hh + r], q);
+            z = csub(shoup_lazy(z, pinv.x, pinv.y, q), q);
+            z = addmod(z, sadd[r], q);
+            if (pt) z = mulmod(z, pp[r], mc);
+            dst[idx] = z;
+        }
+    }
+}
+
+template <typename K>
+static void set_lds(K kernel, size_t bytes)
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)bytes);
+}
+
+template <int LOGN>
+static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+                                           const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
+{
+    using SC = SplitCfg<LOGN>;
+    const size_t lds = SC::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_lds(ks_intt_digits_kernel<LOGN>, lds);
+        set_lds(ks_ntt_digits_kernel<LOGN>, lds);
+        set_lds(ks_moddown_intt_kernel<LOGN>, lds);
+        set_lds(ks_moddown_finish_kernel<LOGN>, lds);
+        if (getenv("HEFX_DEBUG")) {
+            int nb = -1;
+            (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ks_ntt_digits_kernel<LOGN>, SC::T, lds);
+            fprintf(stderr, "[hefx] ks_ntt_digits_kernel<%d>: %d threads, %zu B LDS -> %d workgroups/CU\n", LOGN, SC::T,
+                    lds, nb);
+        }
+        attr_done = true;
+    }
+    const int rl = relin ? 1 : 0;
+    // optional profiling: ev[0..6] bracket the six launches (hefx_profile_*), recorded on the same stream
+#define HEFX_EV(i) \
+    if (ev) (void)hipEventRecord(ev[i], s)
+    HEFX_EV(0);
+    hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, relin ? L : 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
+                       scr);
+    HEFX_EV(1);
+    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
+    HEFX_EV(2);
+    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(split_grid(n * L * L)), dim3(SC::T), lds, s, T, L,
+                       n * L * L, scr);
+    HEFX_EV(3);
+    hipLaunchKernelGGL(ks_mac_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
+    HEFX_EV(4);
+    hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
+    HEFX_EV(5);
+    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(split_grid(n * 2 * L)), dim3(SC::T), lds, s, T, batch, L,
+                       rl, n * 2 * L, scr);
+    HEFX_EV(6);
+#undef HEFX_EV
+    return hipGetLastError();
+}
+
+#define HEFX_DISPATCH_SPLIT(logn, CALL)       \
+    switch (logn) {                           \
+        case 11: return CALL(11);             \
+        case 12: return CALL(12);             \
+        case 13: return CALL(13);             \
+        case 14: return CALL(14);             \
+        case 15: return CALL(15);             \
+        default: return hipErrorInvalidValue; \
+    }
+
+hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+                                  const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
+{
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, s, ev)
+    HEFX_DISPATCH_SPLIT(T.logn, CALL)
+#undef CALL
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8: rescale_to_next, SEAL 3.4.x floor variant (App. A.9): per poly 1 INTT + (L-1) NTT.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void rs_intt_kernel(DevTables T, int L, int rows, const u64 *in,
+                                                                       u64 *d)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;  // p runs over count*size polys
+    const int t = threadIdx.x;
+    const ulonglong2 *__restrict__ src =
+        reinterpret_cast<const ulonglong2 *>(in + ((size_t)p * L + (L - 1)) * SC::N);
+    u64 v[16];
+    split_inv<LOGN>(v, src, lds, ntt_tables(T, L - 1), T.mods[L - 1], T.modsf[L - 1], t, h);
+    u64 *__restrict__ dd = d + (size_t)p * SC::N + (size_t)h * SC::H;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void rs_finish_kernel(DevTables T, int L, int rows, const u64 *in,
+                                                                         const u64 *d, u64 *out)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;  // p = poly*(L-1) + j
+    const int t = threadIdx.x;
+    const int poly = p / (L - 1), j = p % (L - 1);
+    const ModConst mc = T.mods[j];
+    const u64 q = mc.q, ql = T.mods[L - 1].q;
+    const ulonglong2 qinv = T.invmod[(size_t)(L - 1) * T.k + j];
+    const u64 *__restrict__ dd = d + (size_t)poly * SC::N;
+    u64 v[16];
+    const bool reduce = ql > q;
+    auto ld = [&](int r, u64 &x, u64 &y) {
+        const int e = eo(C::idx_nat(t, r), SC::H);
+        x = dd[e];
+        y = dd[e + SC::H / 2];
+        if (reduce) {
+            x = barrett64(x, q, mc.r1);
+            y = barrett64(y, q, mc.r1);
+        }
+    };
+    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    const size_t off = (size_t)h * SC::H;
+    const u64 *__restrict__ src = in + ((size_t)poly * L + j) * SC::N + off;
+    u64 *__restrict__ dst = out + ((size_t)poly * (L - 1) + j) * SC::N + off;
+    u64 a[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[r] = src[C::idx_out(t, r)];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const u64 z = submod(a[r], v[r], q);
+        dst[C::idx_out(t, r)] = csub(shoup_lazy(z, qinv.x, qinv.y, q), q);
+    }
+}
+
+template <int LOGN>
+static hipError_t launch_rescale_t(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out,
+                                   u64 *scratch_d, hipStream_t s)
+{
+    using SC = SplitCfg<LOGN>;
+    const size_t lds = SC::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_lds(rs_intt_kernel<LOGN>, lds);
+        set_lds(rs_finish_kernel<LOGN>, lds);
+        attr_done = true;
+    }
+    const int polys = size * count;
+    hipLaunchKernelGGL((rs_intt_kernel<LOGN>), dim3(split_grid(polys)), dim3(SC::T), lds, s, T, L, polys, in,
+                       scratch_d);
+    hipLaunchKernelGGL((rs_finish_kernel<LOGN>), dim3(split_grid(polys * (L - 1))), dim3(SC::T), lds, s, T, L,
+                       polys * (L - 1), in, scratch_d, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
+                          hipStream_t s)
+{
+#define CALL(LN) launch_rescale_t<LN>(T, L, size, count, in, out, scratch_d, s)
+    HEFX_DISPATCH_SPLIT(T.logn, CALL)
+#undef CALL
+}
+
+// ------------------------------------------------------------------------------------------------
+// Stand-alone split NTT, out of place (src -> dst, natural layouts on both sides).  Used for N = 32768, whose
+// rows do not fit one workgroup's LDS; smaller N use the in-place single-workgroup kernels.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN, bool INV>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ntt_split_rows_kernel(DevTables T, const u64 *src, u64 *dst,
+                                                                              int rows, int nrows, int mod_first)
+{
+    using SC = SplitCfg<LOGN>;
+    using C = typename SC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int m = mod_first + p % nrows;
+    const ModConst mc = T.mods[m];
+    const u64 *__restrict__ s = src + (size_t)p * SC::N;
+    u64 *__restrict__ o = dst + (size_t)p * SC::N;
+    u64 v[16];
+    if (!INV) {
+        auto ld = [&](int r, u64 &x, u64 &y) {
+            x = s[C::idx_nat(t, r)];
+            y = s[C::idx_nat(t, r) + SC::H];
+        };
+        split_fwd<LOGN>(v, ld, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[(size_t)h * SC::H + C::idx_out(t, r)] = v[r];
+    } else {
+        split_inv<LOGN>(v, reinterpret_cast<const ulonglong2 *>(s), lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[2 * C::idx_nat(t, r) + h] = v[r];
+    }
+}
+
+hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
+                              int mod_first, hipStream_t s)
+{
+    using SC = SplitCfg<15>;
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_lds(ntt_split_rows_kernel<15, false>, SC::LDS_BYTES);
+        set_lds(ntt_split_rows_kernel<15, true>, SC::LDS_BYTES);
+        attr_done = true;
+    }
+    const int rows = npoly * nrows;
+    if (inverse)
+        hipLaunchKernelGGL((ntt_split_rows_kernel<15, true>), dim3(split_grid(rows)), dim3(SC::T), SC::LDS_BYTES, s, T,
+                           src, dst, rows, nrows, mod_first);
+    else
+        hipLaunchKernelGGL((ntt_split_rows_kernel<15, false>), dim3(split_grid(rows)), dim3(SC::T), SC::LDS_BYTES, s,
+                           T, src, dst, rows, nrows, mod_first);
+    return hipGetLastError();
+}
+
+}  // namespace hefx

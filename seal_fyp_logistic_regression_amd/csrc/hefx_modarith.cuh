@@ -20,6 +20,20 @@ struct ModConst {
     u64 pad;
 };
 
+// Per-modulus constants of the FP64 policy (valid only for q < 2^41).
+struct ModConstF {
+    double q, qinv;          // q and RN(1/q)
+    double ninv, ninv_r;     // N^-1 mod q and RN(ninv/q)
+    double ilw, ilw_r;       // (last inverse-stage twiddle * N^-1) mod q and RN(ilw/q)
+    double pad0, pad1;
+};
+
+// Twiddle tables of one modulus (integer and FP64 policies).
+struct NttTables {
+    const ulonglong2 *tw, *itw;  // [N] of this modulus
+    const double2 *twf, *itwf;   // [N] of this modulus (FP64 policy)
+};
+
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 // x*w mod q in [0,2q), ws = floor(w*2^64/q); valid for ANY 64-bit x (Harvey/Shoup).

@@ -1,4 +1,4 @@
-// hefx_ntt.cuh -- negacyclic NTT / inverse NTT cores for one RNS row held by ONE workgroup.
+// hefx_ntt.cuh -- negacyclic NTT / inverse NTT cores for one RNS row (or half row) held by ONE workgroup.
 //
 // Semantics (SEAL 3.4.5 util/smallntt): twiddle table tw[bitrev(i)] = psi^i with
 // psi the minimal primitive 2N-th root; forward = Cooley-Tukey, natural in -> bit-reversed out,
@@ -6,13 +6,28 @@
 //
 // gfx950 mapping: N/16 threads, 16 coefficients per thread in registers; four radix-2 stages per pass
 // are done in registers (radix-16), passes exchange through LDS (one barrier per exchange: a thread
-// only ever overwrites the LDS words it read itself).  N*8*(17/16) bytes of LDS: 136 KiB at N=16384
-// (one row per CU), 68 KiB at N=8192 (two rows per CU).  Twiddles of the first pass are workgroup-
-// uniform and of the second pass wave-uniform (scalar loads); later passes load {w, w_shoup} as one
-// 16-byte vector load per butterfly from L2.  Butterflies are Harvey lazy ([0,4q) forward, [0,2q)
-// inverse) with Shoup twiddles; outputs are canonical.
+// only ever overwrites the LDS words it read itself).  N*8*(17/16) bytes of LDS.  Twiddles of the first
+// pass are workgroup-uniform and of wide passes wave-uniform (scalar loads); later passes load a 16-byte
+// twiddle record per butterfly from L2.
+//
+// Two arithmetic policies, chosen per RNS prime (all results are canonical residues, so both give the same
+// bits as SEAL's CPU path):
+//   ArithU64  any prime < 2^61: Harvey lazy butterflies ([0,4q) forward, [0,2q) inverse) with Shoup twiddles
+//             {w, floor(w*2^64/q)}; 10 integer multiplies (v_mad_u64_u32 / v_mul_*_u32, ~6 cycles each per
+//             wave and SIMD) per butterfly, ~105 cycles.
+//   ArithF64  primes < 2^41 (SEAL's 30..40-bit data primes): coefficients are kept as exact integers in
+//             doubles and x*w mod q is computed EXACTLY with FMA: h = x*w, l = fma(x,w,-h) (exact product),
+//             c = rint(x * (w/q)), t = fma(-c,q,h) + l, |t| < 0.52q; 6 fp64 instructions (~32 cycles measured),
+//             no range corrections in the forward transform (growth 0.52q per stage), one re-centering per
+//             radix-16 pass in the inverse.  Exactness argument in DESIGN.md ("FP64 modmul").
 #pragma once
 #include "hefx_modarith.cuh"
+
+// Scheduling fence between radix-2 stages: keeps hipcc from hoisting every twiddle load of a pass (60 VGPRs)
+// above the first butterfly, which pushed the kernels past 128 VGPRs and into scratch spills.
+#ifndef HEFX_STAGE_FENCE
+#define HEFX_STAGE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
 
 namespace hefx {
 
@@ -37,31 +52,159 @@ struct NttCfg {
     }
 };
 
-// forward butterfly, inputs/outputs in [0,4q)
-__device__ __forceinline__ void ct_bfly(u64 &x, u64 &y, u64 w, u64 ws, u64 q, u64 two_q)
-{
-    u64 a = csub(x, two_q);
-    u64 t = shoup_lazy(y, w, ws, q);
-    x = a + t;
-    y = a + two_q - t;
-}
+// ------------------------------------------------------------------------------------------------
+// policy: 64-bit integers, Harvey/Shoup
+// ------------------------------------------------------------------------------------------------
+struct ArithU64 {
+    typedef u64 V;
+    typedef ulonglong2 TW;  // {w, floor(w*2^64/q)}
+    struct Ctx {
+        u64 q, two_q;
+        u64 ninv, ninv_s, ilw, ilw_s;
+    };
+    __device__ static __forceinline__ Ctx make(const ModConst &mc)
+    {
+        Ctx c;
+        c.q = mc.q;
+        c.two_q = mc.q << 1;
+        c.ninv = mc.ninv;
+        c.ninv_s = mc.ninv_s;
+        c.ilw = mc.ilw;
+        c.ilw_s = mc.ilw_s;
+        return c;
+    }
+    // forward butterfly, inputs/outputs in [0,4q)
+    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
+    {
+        u64 a = csub(x, c.two_q);
+        u64 t = shoup_lazy(y, w.x, w.y, c.q);
+        x = a + t;
+        y = a + c.two_q - t;
+    }
+    // first stage of a split forward transform: keep X (h=0) or Y (h=1); x,y canonical
+    __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
+    {
+        const u64 t = shoup_lazy(y, w.x, w.y, c.q);
+        return h ? x + c.two_q - t : x + t;
+    }
+    // inverse butterfly, inputs/outputs in [0,2q)
+    __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
+    {
+        u64 s = csub(x + y, c.two_q);
+        u64 d = x + c.two_q - y;
+        x = s;
+        y = shoup_lazy(d, w.x, w.y, c.q);
+    }
+    __device__ static __forceinline__ void gs_last(V &x, V &y, const Ctx &c)
+    {
+        u64 s = csub(x + y, c.two_q);
+        u64 d = x + c.two_q - y;
+        x = shoup_lazy(s, c.ninv, c.ninv_s, c.q);
+        y = shoup_lazy(d, c.ilw, c.ilw_s, c.q);
+    }
+    // first stage of a split inverse transform on a canonical pair (a0,a1): sum (h=0) or twiddled difference
+    __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
+    __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
+    {
+        return shoup_lazy(a0 + c.two_q - a1, w.x, w.y, c.q);
+    }
+    __device__ static __forceinline__ void inv_pass_begin(V (&)[16], const Ctx &) {}
+    __device__ static __forceinline__ V from_u64(u64 x) { return x; }
+    __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return csub(csub(x, c.two_q), c.q); }
+    __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return csub(x, c.q); }
+};
 
-// inverse butterfly, inputs/outputs in [0,2q)
-__device__ __forceinline__ void gs_bfly(u64 &x, u64 &y, u64 w, u64 ws, u64 q, u64 two_q)
-{
-    u64 s = csub(x + y, two_q);
-    u64 d = x + two_q - y;
-    x = s;
-    y = shoup_lazy(d, w, ws, q);
-}
+// ------------------------------------------------------------------------------------------------
+// policy: exact integers in doubles, FMA modmul (q < 2^41)
+// ------------------------------------------------------------------------------------------------
+struct ArithF64 {
+    typedef double V;
+    typedef double2 TW;  // {w, RN(w/q)}
+    struct Ctx {
+        double q, qinv;
+        double ninv, ninv_r, ilw, ilw_r;
+    };
+    __device__ static __forceinline__ Ctx make(const ModConstF &mf)
+    {
+        Ctx c;
+        c.q = mf.q;
+        c.qinv = mf.qinv;
+        c.ninv = mf.ninv;
+        c.ninv_r = mf.ninv_r;
+        c.ilw = mf.ilw;
+        c.ilw_r = mf.ilw_r;
+        return c;
+    }
+    // y*w mod q, exact, result in (-0.52q, 0.52q); y any integer with |y| < 2^49, 0 <= w < q < 2^41
+    __device__ static __forceinline__ double mm(double y, double w, double wr, double q)
+    {
+        const double h = y * w;
+        const double l = __builtin_fma(y, w, -h);
+        const double c = __builtin_rint(y * wr);
+        const double s = __builtin_fma(-c, q, h);
+        return s + l;
+    }
+    // re-centre: x - q*rint(x/q), exact, result in [-0.5q, 0.5q]
+    __device__ static __forceinline__ double red(double x, const Ctx &c)
+    {
+        return __builtin_fma(-__builtin_rint(x * c.qinv), c.q, x);
+    }
+    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
+    {
+        const double t = mm(y, w.x, w.y, c.q);
+        const double a = x;
+        x = a + t;
+        y = a - t;
+    }
+    __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
+    {
+        const double t = mm(y, w.x, w.y, c.q);
+        return h ? x - t : x + t;
+    }
+    __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
+    {
+        const double s = x + y, d = x - y;
+        x = s;
+        y = mm(d, w.x, w.y, c.q);
+    }
+    __device__ static __forceinline__ void gs_last(V &x, V &y, const Ctx &c)
+    {
+        const double s = x + y, d = x - y;
+        x = mm(s, c.ninv, c.ninv_r, c.q);
+        y = mm(d, c.ilw, c.ilw_r, c.q);
+    }
+    __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
+    __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
+    {
+        return mm(a0 - a1, w.x, w.y, c.q);
+    }
+    // sums double per inverse stage: re-centre the 16 registers once per radix-16 pass (|x| <= 16*0.52q after it)
+    __device__ static __forceinline__ void inv_pass_begin(V (&v)[16], const Ctx &c)
+    {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) v[e] = red(v[e], c);
+    }
+    __device__ static __forceinline__ V from_u64(u64 x) { return (double)x; }  // exact: x < 2^53
+    __device__ static __forceinline__ u64 canon(double x, const Ctx &c)
+    {
+        double r = red(x, c);
+        r = r < 0.0 ? r + c.q : r;
+        return (u64)r;
+    }
+    __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return canon(x, c); }
+    __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
+};
 
-// v[r] holds coefficient idx_nat(t,r) (any value < 4q) on entry and NTT value idx_out(t,r) in [0,q) on exit.
-template <int LOGN>
-__device__ __forceinline__ void ntt_fwd_core(u64 (&v)[16], u64 *lds, const ulonglong2 *__restrict__ tw, u64 q,
-                                             int t)
+// v[r] holds coefficient idx_nat(t,r) on entry (U64: any value < 4q; F64: |v| <= ~2q) and the NTT value
+// idx_out(t,r) on exit, NOT yet canonical (apply A::fwd_finish).
+// `pre` is the twiddle-index prefix: 1 for a whole transform of size 2^LOGN; 2+h when this call is half h of a
+// transform of size 2^(LOGN+1) whose first stage was applied by the caller (stage s uses tw[(pre << s) + i]).
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A::V *lds,
+                                             const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                             int pre)
 {
     using C = NttCfg<LOGN>;
-    const u64 two_q = q << 1;
 #pragma unroll
     for (int p = 0; p < C::FP; ++p) {
         const int LOGS = LOGN - 4 * (p + 1);
@@ -79,9 +222,10 @@ __device__ __forceinline__ void ntt_fwd_core(u64 (&v)[16], u64 *lds, const ulong
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (e & half) continue;
-                const ulonglong2 w = tw[(1 << (4 * p + u)) + (b << u) + (e >> (4 - u))];
-                ct_bfly(v[e], v[e | half], w.x, w.y, q, two_q);
+                const typename A::TW w = tw[(pre << (4 * p + u)) + (b << u) + (e >> (4 - u))];
+                A::ct(v[e], v[e | half], w, cx);
             }
+            HEFX_STAGE_FENCE();
         }
         if (p + 1 < C::FP || C::R > 0) {
 #pragma unroll
@@ -105,25 +249,24 @@ __device__ __forceinline__ void ntt_fwd_core(u64 (&v)[16], u64 *lds, const ulong
 #pragma unroll
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
-                    const ulonglong2 w = tw[(1 << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
-                    ct_bfly(v[c * C::G + e], v[c * C::G + (e | half)], w.x, w.y, q, two_q);
+                    const typename A::TW w = tw[(pre << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
+                    A::ct(v[c * C::G + e], v[c * C::G + (e | half)], w, cx);
                 }
             }
+            HEFX_STAGE_FENCE();
         }
     }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = csub(csub(v[e], two_q), q);
 }
 
-// v[r] holds NTT value idx_out(t,r) in [0,2q) on entry and coefficient idx_nat(t,r) in [0,q) on exit.
-// itw[idx] = tw[idx]^-1 (same indexing); mc.ilw = itw[1]*N^-1, mc.ninv = N^-1 (folded last stage).
-template <int LOGN>
-__device__ __forceinline__ void ntt_inv_core(u64 (&v)[16], u64 *lds, const ulonglong2 *__restrict__ itw,
-                                             const ModConst &mc, int t)
+// v[r] holds NTT value idx_out(t,r) on entry (U64: [0,2q); F64: |v| < 2^45) and coefficient idx_nat(t,r) on exit,
+// NOT yet canonical (apply A::inv_finish).  itw[idx] = tw[idx]^-1 (same indexing); N^-1 folded in the last stage.
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A::V *lds,
+                                             const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
 {
     using C = NttCfg<LOGN>;
-    const u64 q = mc.q, two_q = q << 1;
     if (C::R > 0) {
+        A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = C::R - 1; u >= 0; --u) {
             const int half = C::G >> (u + 1);
@@ -133,10 +276,11 @@ __device__ __forceinline__ void ntt_inv_core(u64 (&v)[16], u64 *lds, const ulong
 #pragma unroll
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
-                    const ulonglong2 w = itw[(1 << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
-                    gs_bfly(v[c * C::G + e], v[c * C::G + (e | half)], w.x, w.y, q, two_q);
+                    const typename A::TW w = itw[(1 << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
+                    A::gs(v[c * C::G + e], v[c * C::G + (e | half)], w, cx);
                 }
             }
+            HEFX_STAGE_FENCE();
         }
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
@@ -156,26 +300,23 @@ __device__ __forceinline__ void ntt_inv_core(u64 (&v)[16], u64 *lds, const ulong
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
         }
+        A::inv_pass_begin(v, cx);
         if (LOGS >= 6) b = __builtin_amdgcn_readfirstlane(b);
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
             const int half = 8 >> u;
             if (p == 0 && u == 0) {  // last stage: fold N^-1
 #pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    u64 s = csub(v[e] + v[e | 8], two_q);
-                    u64 d = v[e] + two_q - v[e | 8];
-                    v[e] = shoup_lazy(s, mc.ninv, mc.ninv_s, q);
-                    v[e | 8] = shoup_lazy(d, mc.ilw, mc.ilw_s, q);
-                }
+                for (int e = 0; e < 8; ++e) A::gs_last(v[e], v[e | 8], cx);
             } else {
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (e & half) continue;
-                    const ulonglong2 w = itw[(1 << (4 * p + u)) + (b << u) + (e >> (4 - u))];
-                    gs_bfly(v[e], v[e | half], w.x, w.y, q, two_q);
+                    const typename A::TW w = itw[(1 << (4 * p + u)) + (b << u) + (e >> (4 - u))];
+                    A::gs(v[e], v[e | half], w, cx);
                 }
             }
+            HEFX_STAGE_FENCE();
         }
         if (p > 0) {
 #pragma unroll
@@ -183,8 +324,130 @@ __device__ __forceinline__ void ntt_inv_core(u64 (&v)[16], u64 *lds, const ulong
             __syncthreads();
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// u64-in / u64-out wrappers that pick the policy for the row's prime (uniform per workgroup).
+// T.modsf[m].q == 0 marks a prime that is too wide for the FP64 policy.
+// ------------------------------------------------------------------------------------------------
+// whole transform of size 2^LOGN; v: canonical in (idx_nat) -> canonical out (idx_out)
+template <int LOGN>
+__device__ __forceinline__ void ntt_fwd_row(u64 (&v)[16], u64 *lds, const NttTables &nt, const ModConst &mc,
+                                            const ModConstF &mf, int t)
+{
+    if (mf.q != 0.0) {
+        const ArithF64::Ctx cx = ArithF64::make(mf);
+        double f[16];
 #pragma unroll
-    for (int e = 0; e < 16; ++e) v[e] = csub(v[e], q);
+        for (int r = 0; r < 16; ++r) f[r] = ArithF64::from_u64(v[r]);
+        ntt_fwd_core<LOGN, ArithF64>(f, reinterpret_cast<double *>(lds), nt.twf, cx, t, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ArithF64::fwd_finish(f[r], cx);
+    } else {
+        const ArithU64::Ctx cx = ArithU64::make(mc);
+        ntt_fwd_core<LOGN, ArithU64>(v, lds, nt.tw, cx, t, 1);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ArithU64::fwd_finish(v[r], cx);
+    }
+}
+
+template <int LOGN>
+__device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTables &nt, const ModConst &mc,
+                                            const ModConstF &mf, int t)
+{
+    if (mf.q != 0.0) {
+        const ArithF64::Ctx cx = ArithF64::make(mf);
+        double f[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = ArithF64::from_u64(v[r]);
+        ntt_inv_core<LOGN, ArithF64>(f, reinterpret_cast<double *>(lds), nt.itwf, cx, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ArithF64::inv_finish(f[r], cx);
+    } else {
+        const ArithU64::Ctx cx = ArithU64::make(mc);
+        ntt_inv_core<LOGN, ArithU64>(v, lds, nt.itw, cx, t);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = ArithU64::inv_finish(v[r], cx);
+    }
+}
+
+// Forward split (transform size 2^LOGN, this workgroup = half h, sub-transform 2^(LOGN-1)):
+// ld(r, x, y) must deliver the canonical coefficients idx_nat(t,r) and idx_nat(t,r)+N/2; on return
+// v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
+template <int LOGN, class A, class LD>
+__device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, u64 *lds,
+                                            const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                            int h)
+{
+    typename A::V f[16];
+    const typename A::TW w1 = tw[1];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        u64 x[8], y[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[8 * g + r] = A::ct_half(A::from_u64(x[r]), A::from_u64(y[r]), w1, cx, h);
+        HEFX_STAGE_FENCE();
+    }
+    ntt_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = A::fwd_finish(f[r], cx);
+}
+
+template <int LOGN, class LD>
+__device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, u64 *lds, const NttTables &nt,
+                                          const ModConst &mc, const ModConstF &mf, int t, int h)
+{
+    if (mf.q != 0.0)
+        split_fwd_a<LOGN, ArithF64>(v, ld, lds, nt.twf, ArithF64::make(mf), t, h);
+    else
+        split_fwd_a<LOGN, ArithU64>(v, ld, lds, nt.tw, ArithU64::make(mc), t, h);
+}
+
+// Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the
+// sub-transform; on return v[r] = coefficient 2*idx_nat(t,r) + h, canonical.
+// `pairs` points at the row viewed as (value[2j], value[2j+1]) records.  The first stage is done in two batches
+// of eight pairs (+ eight twiddles for the odd half) with a scheduling fence between them: issuing all 16 pair
+// loads and 16 twiddle loads at once needs ~250 VGPRs in the FP64 policy and spilled heavily at the 128 cap.
+template <int LOGN, class A>
+__device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
+                                            const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t,
+                                            int h)
+{
+    using C = NttCfg<LOGN - 1>;
+    typename A::V f[16];
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        ulonglong2 pr[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) pr[r] = pairs[C::idx_out(t, 8 * g + r)];
+        if (h == 0) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) f[8 * g + r] = A::gs_half_sum(A::from_u64(pr[r].x), A::from_u64(pr[r].y), cx);
+        } else {
+            typename A::TW w[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) w[r] = itw[C::N + C::idx_out(t, 8 * g + r)];  // itw[N/2 + j]
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                f[8 * g + r] = A::gs_half_diff(A::from_u64(pr[r].x), A::from_u64(pr[r].y), w[r], cx);
+        }
+        HEFX_STAGE_FENCE();
+    }
+    ntt_inv_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) v[r] = A::inv_finish(f[r], cx);
+}
+
+template <int LOGN>
+__device__ __forceinline__ void split_inv(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
+                                          const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
+{
+    if (mf.q != 0.0)
+        split_inv_a<LOGN, ArithF64>(v, pairs, lds, nt.itwf, ArithF64::make(mf), t, h);
+    else
+        split_inv_a<LOGN, ArithU64>(v, pairs, lds, nt.itw, ArithU64::make(mc), t, h);
 }
 
 }  // namespace hefx

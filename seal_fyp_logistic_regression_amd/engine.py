@@ -247,8 +247,13 @@ class Engine:
 
     def profile_end(self):
         """-> ({launch kind: summed ms}, number of chunks)"""
-        ms = (C.c_double * 5)()
+        ms = (C.c_double * 8)()
         n = C.c_uint64()
         capi.check(capi.lib().hefx_profile_end(self._h, ms, C.byref(n)))
-        names = [capi.lib().hefx_profile_stage_name(k).decode() for k in range(5)]
-        return {names[k]: float(ms[k]) for k in range(5)}, int(n.value)
+        names = []
+        for k in range(8):
+            nm = capi.lib().hefx_profile_stage_name(k).decode()
+            if not nm:
+                break
+            names.append(nm)
+        return {nm: float(ms[k]) for k, nm in enumerate(names)}, int(n.value)

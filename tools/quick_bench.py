@@ -9,6 +9,10 @@ SETS = {
     "C3": (16384, [0xffffffffffd8001, 0xffffb20001, 0xffffc40001, 0xffffca8001, 0xffffe80001, 0xffffffffffe8001]),
 }
 name = sys.argv[1] if len(sys.argv) > 1 else "C3"
+if name in ("F40", "I60", "F40s", "I60s"):  # uniform-width prime sets to isolate the two arithmetic policies
+    from oracle import oracle as O
+    n_ = 8192 if name.endswith("s") else 16384
+    SETS[name] = (n_, O.coeff_modulus_create(n_, [40 if name[0] == "F" else 60] * 6))
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 64
 N, primes = SETS[name]
 e = Engine(N, primes)
