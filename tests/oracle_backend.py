@@ -1,0 +1,89 @@
+"""Oracle-backed twin of seal.GpuBackend (TEST INFRASTRUCTURE): same methods, numpy arrays as handles, every
+operation computed by oracle/ckks_oracle.c.  Running seal.Evaluator / algorithms.* on this backend yields the
+reference-semantics result that the HIP engine must reproduce bit for bit."""
+import numpy as np
+
+from oracle import oracle as O
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, N, primes):
+        self.o = O.Oracle(N, primes)
+        self.N, self.primes, self.k = N, list(primes), len(primes)
+
+    def from_host(self, a):
+        return np.ascontiguousarray(a, dtype=np.uint64).copy()
+
+    def to_host(self, h):
+        return h
+
+    def _ct(self, h, size, L):
+        return np.ascontiguousarray(h).reshape(size, L, self.N)
+
+    def ntt_forward(self, h, npoly, nrows, mod_first=0):
+        v = h.reshape(npoly, nrows, self.N)
+        for p in range(npoly):
+            for r in range(nrows):
+                v[p, r] = self.o.ntt_fwd(mod_first + r, v[p, r])
+        return h
+
+    def ntt_inverse(self, h, npoly, nrows, mod_first=0):
+        v = h.reshape(npoly, nrows, self.N)
+        for p in range(npoly):
+            for r in range(nrows):
+                v[p, r] = self.o.ntt_inv(mod_first + r, v[p, r])
+        return h
+
+    def add(self, L, size, a, b):
+        return self.o.add(self._ct(a, size, L), self._ct(b, size, L))
+
+    def sub(self, L, size, a, b):
+        return self.o.sub(self._ct(a, size, L), self._ct(b, size, L))
+
+    def negate(self, L, size, a):
+        return self.o.negate(self._ct(a, size, L))
+
+    def add_plain(self, L, size, ct, pt):
+        return self.o.add_plain(self._ct(ct, size, L), np.ascontiguousarray(pt).reshape(L, self.N))
+
+    def add_many(self, L, size, cts):
+        acc = self._ct(cts[0], size, L).copy()
+        for c in cts[1:]:
+            acc = self.o.add(acc, self._ct(c, size, L))
+        return acc
+
+    def multiply_plain(self, L, size, ct, pt):
+        return self.o.multiply_plain(self._ct(ct, size, L), np.ascontiguousarray(pt).reshape(L, self.N))
+
+    def multiply(self, L, a, b):
+        return self.o.multiply(self._ct(a, 2, L), self._ct(b, 2, L))
+
+    def square(self, L, a):
+        return self.o.multiply(self._ct(a, 2, L), self._ct(a, 2, L))
+
+    def apply_galois(self, L, ct, elt, key):
+        return self.o.apply_galois(self._ct(ct, 2, L), elt, key)
+
+    def apply_galois_batch(self, L, cts, elts, keys):
+        return [self.apply_galois(L, c, e, k) for c, e, k in zip(cts, elts, keys)]
+
+    def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts):
+        return [self.o.rotate_mulplain(self._ct(c, 2, L), e, k, np.ascontiguousarray(p).reshape(L, self.N))
+                for c, e, k, p in zip(cts, elts, keys, pts)]
+
+    def relinearize(self, L, ct3, key):
+        return self.o.relinearize(self._ct(ct3, 3, L), key)
+
+    def rescale(self, L, size, ct):
+        return self.o.rescale(self._ct(ct, size, L))
+
+    def mod_drop(self, L_in, L_out, npoly, x):
+        return np.ascontiguousarray(np.ascontiguousarray(x).reshape(npoly, L_in, self.N)[:, :L_out, :])
+
+    def reduce_canonical(self, L, size, h, addends):
+        v = self._ct(h, size, L)
+        for j in range(L):
+            v[:, j, :] %= np.uint64(self.primes[j])
+        return v

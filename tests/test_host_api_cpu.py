@@ -1,0 +1,155 @@
+"""Host logic of the SEAL API mirror (seal.py) and the L3 algorithms (algorithms.py), exercised on the
+oracle-backed backend so it runs without a GPU: CKKS semantics (decrypt(f(enc x)) == f(x)), the reference's known
+answers, SEAL's error behaviour, NAF plans."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from seal_fyp_logistic_regression_amd import algorithms as alg
+from seal_fyp_logistic_regression_amd import seal as S
+from tests.oracle_backend import OracleBackend
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "appendix_b.json")))
+
+
+def make(N, bits, seed=1):
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
+    ctx = S.SEALContext.Create(parms, backend=OracleBackend(N, parms.coeff_modulus()))
+    kg = S.KeyGenerator(ctx, seed)
+    return dict(ctx=ctx, kg=kg, enc=S.Encryptor(ctx, kg.public_key()), dec=S.Decryptor(ctx, kg.secret_key()),
+                encoder=S.CKKSEncoder(ctx), ev=S.Evaluator(ctx), rk=kg.relin_keys(), gk=kg.galois_keys())
+
+
+@pytest.fixture(scope="module")
+def env():
+    return make(2048, [50, 30, 30, 30, 50])
+
+
+def dec(e, ct, n=None):
+    v = e["encoder"].decode(e["dec"].decrypt(ct))
+    return v[:n] if n else v
+
+
+def test_coeff_modulus_create_matches_golden():
+    for s in GOLD["sets"]:
+        assert S.CoeffModulus.Create(s["N"], s["bits"]) == [int(p, 16) for p in s["primes"]]
+    for step, want in GOLD["naf_examples"].items():
+        assert S.naf(int(step)) == want
+
+
+def test_rotation_plan_counts(env):
+    ev, gk = env["ev"], env["gk"]
+    # Linear_Transform_Plain key-switch counts: rotate(-d) + rotate(1..d-1)
+    for d, want in (("4", 5), ("10", 16), ("16", 29)):
+        d = int(d)
+        assert sum(len(ev.rotation_plan(s, gk)) for s in [-d] + list(range(1, d))) == want
+    with pytest.raises(ValueError, match="Galois key not present"):
+        ev.rotation_plan(4, S.KSwitchKeys())
+
+
+def test_encode_encrypt_roundtrip_and_scalar(env):
+    e, scale = env, 2.0 ** 30
+    v = np.random.default_rng(0).standard_normal(1024) + 0.5j
+    pt = e["encoder"].encode(v, scale)
+    assert np.abs(e["encoder"].decode(pt) - v).max() < 1e-5
+    ct = e["enc"].encrypt(pt)
+    assert ct.size() == 2 and ct.parms_id() == e["ctx"].first_parms_id()
+    assert np.abs(dec(e, ct) - v).max() < 1e-4
+    pts = e["encoder"].encode(3.25, scale)
+    assert np.abs(e["encoder"].decode(pts) - 3.25).max() < 1e-6
+
+
+def test_evaluator_semantics(env):
+    e, ev, scale = env, env["ev"], 2.0 ** 30
+    rng = np.random.default_rng(1)
+    a, b = rng.standard_normal(1024), rng.standard_normal(1024)
+    ca, cb = e["enc"].encrypt(e["encoder"].encode(a, scale)), e["enc"].encrypt(e["encoder"].encode(b, scale))
+    assert np.abs(dec(e, ev.add(ca, cb)) - (a + b)).max() < 1e-4
+    assert np.abs(dec(e, ev.sub(ca, cb)) - (a - b)).max() < 1e-4
+    assert np.abs(dec(e, ev.negate(ca)) + a).max() < 1e-4
+    m = ev.multiply(ca, cb)
+    assert m.size() == 3 and m.scale == scale * scale
+    assert np.abs(dec(e, m) - a * b).max() < 1e-3
+    ev.relinearize_inplace(m, e["rk"])
+    assert m.size() == 2
+    ev.rescale_to_next_inplace(m)
+    assert m.parms_id() == e["ctx"].first_parms_id() - 1
+    assert np.abs(dec(e, m) - a * b).max() < 1e-3
+    for step in (1, -3, 7):
+        assert np.abs(dec(e, ev.rotate_vector(ca, step, e["gk"])) - np.roll(a, -step)).max() < 1e-3
+    mp = ev.multiply_plain(ca, e["encoder"].encode(b, scale))
+    assert np.abs(dec(e, mp) - a * b).max() < 1e-3
+    # size-3 + size-2 addition pads (SEAL: result size = max)
+    s32 = ev.add(ev.multiply(ca, cb), ev.multiply_plain(ca, e["encoder"].encode(np.ones(1024), scale)))
+    assert s32.size() == 3
+    assert np.abs(dec(e, s32) - (a * b + a)).max() < 1e-3
+
+
+def test_error_behaviour(env):
+    e, ev, scale = env, env["ev"], 2.0 ** 30
+    a = e["enc"].encrypt(e["encoder"].encode([1.0, 2.0], scale))
+    b = e["enc"].encrypt(e["encoder"].encode([1.0, 2.0], scale * 2))
+    with pytest.raises(ValueError, match="scale mismatch"):
+        ev.add(a, b)
+    low = a.copy()
+    ev.mod_switch_to_next_inplace(low)
+    with pytest.raises(ValueError, match="parameter mismatch"):
+        ev.add(a, low)
+    with pytest.raises(RuntimeError, match="transparent"):
+        ev.multiply_plain(a, e["encoder"].encode(np.zeros(4), scale))
+    with pytest.raises(ValueError, match="scale out of bounds"):
+        big = a.copy()
+        for _ in range(6):
+            big = ev.multiply_plain(big, e["encoder"].encode([1.0], scale))
+    with pytest.raises(ValueError, match="encrypted size must be 2"):
+        ev.rotate_vector(ev.multiply(a, a), 1, e["gk"])
+    with pytest.raises(ValueError, match="higher level"):
+        ev.mod_switch_to_inplace(low, e["ctx"].first_parms_id())
+    c = a.copy()
+    while c.parms_id() > 1:
+        ev.mod_switch_to_next_inplace(c)
+    with pytest.raises(ValueError, match="end of modulus switching chain"):
+        ev.rescale_to_next_inplace(c)
+
+
+def test_linear_transform_known_answer(env):
+    """M = 1..16 (4x4): M @ [1,5,9,13] = [90,202,314,426] (reference imgs/lin_transf.jpg / matmul first column)."""
+    e, ev, scale, d = env, env["ev"], 2.0 ** 30, 4
+    M = np.arange(1, 17, dtype=float).reshape(4, 4)
+    v = np.array([1.0, 5.0, 9.0, 13.0])
+    diags = [e["encoder"].encode(dg, scale) for dg in alg.get_all_diagonals(M)]
+    ct = e["enc"].encrypt(e["encoder"].encode(v, scale))
+    out = alg.linear_transform_plain(ev, ct, diags, e["gk"])
+    got = dec(e, out, d).real
+    assert np.allclose(got, [90, 202, 314, 426], atol=1e-2)
+    cdiags = [e["enc"].encrypt(p) for p in diags]
+    out2 = alg.linear_transform_cipher(ev, ct, cdiags, e["gk"])
+    assert out2.size() == 3
+    assert np.allclose(dec(e, out2, d).real, [90, 202, 314, 426], atol=1e-2)
+
+
+def test_cipher_dot_product_and_powers(env):
+    e, ev, scale = env, env["ev"], 2.0 ** 30
+    a, b = np.array([1.0, 2.0, 3.0, 4.0]), np.array([0.5, -1.0, 2.0, 0.25])
+    ca, cb = e["enc"].encrypt(e["encoder"].encode(a, scale)), e["enc"].encrypt(e["encoder"].encode(b, scale))
+    dp = alg.cipher_dot_product(ev, ca, cb, 4, e["rk"], e["gk"])
+    assert abs(dec(e, dp, 1)[0].real - float(a @ b)) < 0.05  # scale was forced to a power of two (helper.h:489)
+    x = e["enc"].encrypt(e["encoder"].encode([0.8, -0.5], scale))
+    pw = alg.compute_all_powers(ev, x, 3, e["rk"])
+    for i in (2, 3):
+        assert np.allclose(dec(e, pw[i], 2).real, np.array([0.8, -0.5]) ** i, atol=1e-2)
+
+
+def test_matrix_encode_decode(env):
+    e, ev, scale, n = env, env["ev"], 2.0 ** 30, 3
+    rows = [np.arange(n) + 10.0 * i for i in range(n)]
+    cts = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in rows]
+    packed = alg.c_matrix_encode(ev, cts, e["gk"])
+    assert np.allclose(dec(e, packed, n * n).real, np.concatenate(rows), atol=1e-3)
+    back = alg.c_matrix_decode(ev, e["encoder"], packed, n, scale, e["gk"])
+    for i in range(n):
+        assert np.allclose(dec(e, back[i], n).real, rows[i], atol=1e-2)
