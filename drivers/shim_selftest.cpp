@@ -1,0 +1,169 @@
+// shim_selftest.cpp -- exercises include/seal/seal.h the way the reference's drivers do (both API spellings) and
+// checks decrypted values and SEAL's error behaviour.  Exit code 0 = all checks passed.  Needs a HIP device.
+#include <cmath>
+#include <iostream>
+
+#include "seal/seal.h"
+
+using namespace std;
+using namespace seal;
+
+static int failures = 0;
+#define CHECK(cond, what)                                  \
+    do {                                                   \
+        if (!(cond)) {                                     \
+            cout << "FAIL: " << what << endl;              \
+            ++failures;                                    \
+        } else                                             \
+            cout << "ok:   " << what << endl;              \
+    } while (0)
+
+template <class F>
+static bool throws_invalid(F f, const string &needle)
+{
+    try {
+        f();
+    } catch (const invalid_argument &e) {
+        return string(e.what()).find(needle) != string::npos;
+    } catch (...) {
+    }
+    return false;
+}
+
+// helper.h:237-262 restated against the 3.6 spelling (context rebuilt per call, keys by value)
+static Ciphertext lt_plain(Ciphertext ct, vector<Plaintext> diags, GaloisKeys gk, EncryptionParameters params)
+{
+    SEALContext context(params);
+    Evaluator evaluator(context);
+    Ciphertext ct_rot, ct_new, out;
+    evaluator.rotate_vector(ct, -(int)diags.size(), gk, ct_rot);
+    evaluator.add(ct, ct_rot, ct_new);
+    vector<Ciphertext> res(diags.size());
+    evaluator.multiply_plain(ct_new, diags[0], res[0]);
+    for (size_t l = 1; l < diags.size(); l++) {
+        Ciphertext tmp;
+        evaluator.rotate_vector(ct_new, (int)l, gk, tmp);
+        evaluator.multiply_plain(tmp, diags[l], res[l]);
+    }
+    evaluator.add_many(res, out);
+    return out;
+}
+
+int main()
+{
+    EncryptionParameters params(scheme_type::CKKS);
+    params.set_poly_modulus_degree(8192);
+    params.set_coeff_modulus(CoeffModulus::Create(8192, {60, 40, 40, 60}));
+    auto context = SEALContext::Create(params);  // 3.4.5 spelling
+    CHECK(context->first_context_data()->chain_index() == 2, "chain_index of first data level");
+    CHECK(context->key_context_data()->total_coeff_modulus_bit_count() == 200, "total_coeff_modulus_bit_count");
+    CHECK(params.coeff_modulus()[0].value() == 0xffffffffffe8001ull && params.coeff_modulus()[3].value() == 0xfffffffffffc001ull,
+          "CoeffModulus::Create primes (SURVEY App. B, C2)");
+
+    KeyGenerator keygen(context);
+    PublicKey pk = keygen.public_key();
+    SecretKey sk = keygen.secret_key();
+    RelinKeys rk = keygen.relin_keys();
+    GaloisKeys gk;
+    keygen.create_galois_keys(gk);  // 3.6 spelling
+    CHECK(gk.size() == 24, "default Galois keys: 24 distinct elements at N=8192");
+    Encryptor encryptor(context, pk);
+    Evaluator evaluator(context);
+    Decryptor decryptor(context, sk);
+    CKKSEncoder encoder(context);
+    const double scale = pow(2.0, 40);
+
+    auto dec = [&](const Ciphertext &c) {
+        Plaintext p;
+        vector<double> v;
+        decryptor.decrypt(c, p);
+        encoder.decode(p, v);
+        return v;
+    };
+
+    vector<double> a{1.0, 2.0, 3.0, 4.0}, b{0.5, -1.0, 2.0, 0.25};
+    Plaintext pa, pb;
+    encoder.encode(a, scale, pa);
+    encoder.encode(b, scale, pb);
+    Ciphertext ca, cb;
+    encryptor.encrypt(pa, ca);
+    encryptor.encrypt(pb, cb);
+    auto va = dec(ca);
+    CHECK(fabs(va[0] - 1) < 1e-6 && fabs(va[3] - 4) < 1e-6 && fabs(va[4]) < 1e-6, "encode/encrypt/decrypt/decode");
+
+    Ciphertext sum, prod, rot;
+    evaluator.add(ca, cb, sum);
+    CHECK(fabs(dec(sum)[1] - 1.0) < 1e-6, "add");
+    evaluator.multiply(ca, cb, prod);
+    CHECK(prod.size() == 3, "multiply gives size 3");
+    CHECK(fabs(dec(prod)[2] - 6.0) < 1e-5, "decrypt of a size-3 ciphertext");
+    evaluator.relinearize_inplace(prod, rk);
+    evaluator.rescale_to_next_inplace(prod);
+    CHECK(prod.size() == 2 && context->get_context_data(prod.parms_id())->chain_index() == 1, "relinearize + rescale level");
+    CHECK(fabs(dec(prod)[2] - 6.0) < 1e-5 && fabs(dec(prod)[1] + 2.0) < 1e-5, "relinearize + rescale values");
+    evaluator.rotate_vector(ca, 1, gk, rot);
+    CHECK(fabs(dec(rot)[0] - 2.0) < 1e-5 && fabs(dec(rot)[2] - 4.0) < 1e-5, "rotate_vector by 1");
+    evaluator.rotate_vector(ca, 3, gk, rot);  // NAF chain: -1 then 4
+    CHECK(fabs(dec(rot)[0] - 4.0) < 1e-5, "rotate_vector by 3 (NAF chain)");
+    evaluator.rotate_vector_inplace(rot, -3, gk);
+    CHECK(fabs(dec(rot)[0] - 1.0) < 1e-5 && fabs(dec(rot)[3] - 4.0) < 1e-5, "rotate_vector_inplace back");
+    Plaintext p3;
+    encoder.encode(3.0, scale, p3);
+    Ciphertext sc;
+    evaluator.multiply_plain(ca, p3, sc);
+    CHECK(fabs(dec(sc)[3] - 12.0) < 1e-5 && sc.scale() == scale * scale, "multiply_plain with scalar plaintext");
+
+    // Linear_Transform_Plain known answer: M = 1..16, v = first column -> [90, 202, 314, 426]
+    {
+        vector<vector<double>> M(4, vector<double>(4));
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) M[i][j] = 4 * i + j + 1;
+        vector<Plaintext> diags(4);
+        for (int l = 0; l < 4; l++) {
+            vector<double> d(4);
+            for (int i = 0; i < 4; i++) d[i] = M[i][(i + l) % 4];
+            encoder.encode(d, scale, diags[l]);
+        }
+        Plaintext pv;
+        encoder.encode(vector<double>{1, 5, 9, 13}, scale, pv);
+        Ciphertext cv;
+        encryptor.encrypt(pv, cv);
+        auto r = dec(lt_plain(cv, diags, gk, params));
+        CHECK(fabs(r[0] - 90) < 1e-3 && fabs(r[1] - 202) < 1e-3 && fabs(r[2] - 314) < 1e-3 && fabs(r[3] - 426) < 1e-3,
+              "Linear_Transform_Plain 4x4 known answer [90,202,314,426]");
+    }
+
+    // SEAL's error behaviour at the boundary
+    Ciphertext low = ca;
+    evaluator.mod_switch_to_next_inplace(low);
+    CHECK(throws_invalid([&] { Ciphertext t; evaluator.add(ca, low, t); }, "parameter mismatch"), "add: parms_id mismatch throws");
+    Ciphertext big = ca;
+    big.scale() = scale * 2;
+    CHECK(throws_invalid([&] { Ciphertext t; evaluator.add(ca, big, t); }, "scale mismatch"), "add: scale mismatch throws");
+    CHECK(throws_invalid([&] { Ciphertext t; evaluator.rotate_vector(ca, 4096, gk, t); }, "step count too large"), "rotate: step too large");
+    CHECK(throws_invalid([&] { GaloisKeys none; Ciphertext t; evaluator.rotate_vector(ca, 4, none, t); }, "Galois key not present"),
+          "rotate: missing key throws");
+    bool transparent = false;
+    try {
+        Plaintext zero;
+        encoder.encode(vector<double>{0.0, 0.0}, scale, zero);
+        Ciphertext t;
+        evaluator.multiply_plain(ca, zero, t);
+    } catch (const logic_error &e) {
+        transparent = string(e.what()).find("transparent") != string::npos;
+    }
+    CHECK(transparent, "multiply_plain by zero plaintext: logic_error(transparent)");
+    CHECK(throws_invalid([&] {
+              Ciphertext t = sc;  // scale 2^80
+              Plaintext p;
+              encoder.encode(1.0, scale, p);
+              evaluator.multiply_plain(t, p, t);
+              evaluator.multiply_plain(t, p, t);  // 2^160 fits 200 bits; one more exceeds it
+              evaluator.multiply_plain(t, p, t);
+              evaluator.multiply_plain(t, p, t);
+          }, "scale out of bounds"),
+          "scale out of bounds throws");
+
+    cout << (failures ? "SELFTEST FAILED" : "SELFTEST PASSED") << " (" << failures << " failures)" << endl;
+    return failures ? 1 : 0;
+}

@@ -1,0 +1,1247 @@
+// seal/seal.h -- header-only shim that offers the part of Microsoft SEAL's C++ API used by
+// MarwanNour/SEAL-FYP-Logistic-Regression (the union of every seal:: call in the
+// reference, in BOTH its SEAL 3.4.5 spelling -- SEALContext::Create, scheme_type::CKKS, keygen.galois_keys() --
+// and its 3.6 spelling -- SEALContext context(parms), scheme_type::ckks, keygen.create_galois_keys(gk)) on top
+// of the hefx C-ABI (include/hefx.h, gfx950 HIP kernels).  The reference's drivers compile against this header
+// unchanged and link with -lhefx; see INTEGRATION.md.
+//
+// What runs where: every homomorphic operation (Evaluator::*) and every NTT dispatches HIP kernels through
+// hefx_*; ciphertext / plaintext / key payloads live in device memory (immutable buffers shared by value-
+// semantic handles, so SEAL's copy-heavy call style -- helper.h:237 passes GaloisKeys BY VALUE -- costs
+// nothing).  Host-side: parameter bookkeeping (parms_id chain, scale), SEAL's validity checks and exception
+// types/messages, NAF decomposition of rotation steps (App. A.7), random sampling and the complex FFT of
+// CKKSEncoder.  BFV-only classes exist so that the drivers compile; they throw std::logic_error when used.
+#pragma once
+
+#include <algorithm>
+#include <array>
+#include <cmath>
+#include <complex>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <random>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../hefx.h"
+
+namespace seal {
+
+// ------------------------------------------------------------------------------------------------
+// basic types
+// ------------------------------------------------------------------------------------------------
+enum class scheme_type : std::uint8_t { none = 0, BFV = 1, bfv = 1, CKKS = 2, ckks = 2 };
+using parms_id_type = std::array<std::uint64_t, 4>;
+static const parms_id_type parms_id_zero = {0, 0, 0, 0};
+
+class SmallModulus {
+public:
+    SmallModulus(std::uint64_t v = 0) : value_(v) {}
+    std::uint64_t value() const { return value_; }
+    int bit_count() const
+    {
+        int b = 0;
+        for (std::uint64_t v = value_; v; v >>= 1) ++b;
+        return b;
+    }
+    bool is_zero() const { return value_ == 0; }
+    bool operator==(const SmallModulus &o) const { return value_ == o.value_; }
+    bool operator!=(const SmallModulus &o) const { return value_ != o.value_; }
+
+private:
+    std::uint64_t value_;
+};
+using Modulus = SmallModulus;  // SEAL >= 3.5 name
+
+namespace shim {
+
+typedef unsigned __int128 u128;
+inline std::uint64_t mulmod(std::uint64_t a, std::uint64_t b, std::uint64_t q) { return (std::uint64_t)(((u128)a * b) % q); }
+inline std::uint64_t powmod(std::uint64_t a, std::uint64_t e, std::uint64_t q)
+{
+    std::uint64_t r = 1 % q;
+    a %= q;
+    for (; e; e >>= 1) {
+        if (e & 1) r = mulmod(r, a, q);
+        a = mulmod(a, a, q);
+    }
+    return r;
+}
+inline bool is_prime(std::uint64_t n)
+{
+    if (n < 2) return false;
+    static const std::uint64_t bases[] = {2, 3, 5, 7, 11, 13, 17, 19, 23, 29, 31, 37};
+    for (auto p : bases) {
+        if (n == p) return true;
+        if (n % p == 0) return false;
+    }
+    std::uint64_t d = n - 1;
+    int r = 0;
+    while (!(d & 1)) d >>= 1, ++r;
+    for (auto a : bases) {
+        std::uint64_t x = powmod(a, d, n);
+        if (x == 1 || x == n - 1) continue;
+        bool comp = true;
+        for (int i = 1; i < r && comp; ++i) {
+            x = mulmod(x, x, n);
+            if (x == n - 1) comp = false;
+        }
+        if (comp) return false;
+    }
+    return true;
+}
+
+[[noreturn]] inline void raise(int rc)
+{
+    const std::string msg = hefx_last_error();
+    if (rc == HEFX_ERR_INVALID) throw std::invalid_argument(msg);
+    if (rc == HEFX_ERR_TRANSPARENT) throw std::logic_error(msg);
+    throw std::runtime_error("hefx: " + msg);
+}
+inline void check(int rc)
+{
+    if (rc != HEFX_OK) raise(rc);
+}
+
+// One engine context per distinct (N, primes); created on first use and kept for the life of the process, so the
+// reference's habit of rebuilding SEALContext + Evaluator inside every Linear_Transform_Plain call
+// (helper.h:239-240) costs a map lookup.  Also owns a size-bucketed device-buffer pool: hipFree synchronises the
+// device, so freed payload buffers are recycled instead (all work is ordered on the default stream).
+struct Engine {
+    hefx_context *ctx = nullptr;
+    std::uint32_t n = 0;
+    std::vector<std::uint64_t> primes;
+    std::mutex mu;
+    std::map<std::size_t, std::vector<std::uint64_t *>> pool;
+
+    std::uint64_t *alloc(std::size_t words)
+    {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            auto it = pool.find(words);
+            if (it != pool.end() && !it->second.empty()) {
+                std::uint64_t *p = it->second.back();
+                it->second.pop_back();
+                return p;
+            }
+        }
+        void *p = nullptr;
+        check(hefx_malloc(ctx, words * sizeof(std::uint64_t), &p));
+        return static_cast<std::uint64_t *>(p);
+    }
+    void release(std::uint64_t *p, std::size_t words)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        pool[words].push_back(p);
+    }
+};
+
+inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std::uint64_t> &primes)
+{
+    static std::mutex mu;
+    static auto *registry = new std::map<std::pair<std::uint32_t, std::vector<std::uint64_t>>, std::shared_ptr<Engine>>();
+    std::lock_guard<std::mutex> lk(mu);
+    auto key = std::make_pair(n, primes);
+    auto it = registry->find(key);
+    if (it != registry->end()) return it->second;
+    auto e = std::make_shared<Engine>();
+    e->n = n;
+    e->primes = primes;
+    int dev = 0;
+    if (const char *d = std::getenv("HEFX_DEVICE")) dev = std::atoi(d);
+    check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx));
+    (*registry)[key] = e;
+    return e;
+}
+
+// immutable device payload
+struct Buf {
+    std::shared_ptr<Engine> eng;
+    std::uint64_t *p = nullptr;
+    std::size_t words = 0;
+    Buf(std::shared_ptr<Engine> e, std::size_t w) : eng(std::move(e)), p(eng->alloc(w)), words(w) {}
+    ~Buf()
+    {
+        if (p) eng->release(p, words);
+    }
+    Buf(const Buf &) = delete;
+    Buf &operator=(const Buf &) = delete;
+};
+using BufPtr = std::shared_ptr<Buf>;
+inline BufPtr new_buf(const std::shared_ptr<Engine> &e, std::size_t words) { return std::make_shared<Buf>(e, words); }
+inline BufPtr upload(const std::shared_ptr<Engine> &e, const std::vector<std::uint64_t> &h)
+{
+    BufPtr b = new_buf(e, h.size());
+    check(hefx_upload(e->ctx, b->p, h.data(), h.size() * 8, nullptr));
+    return b;
+}
+inline std::vector<std::uint64_t> download(const BufPtr &b, std::size_t words = 0)
+{
+    std::vector<std::uint64_t> h(words ? words : b->words);
+    check(hefx_download(b->eng->ctx, h.data(), b->p, h.size() * 8, nullptr));
+    return h;
+}
+
+inline std::mt19937_64 &rng()
+{
+    static std::mt19937_64 g = [] {
+        if (const char *s = std::getenv("SEAL_SHIM_SEED")) return std::mt19937_64(std::strtoull(s, nullptr, 0));
+        std::random_device rd;
+        return std::mt19937_64(((std::uint64_t)rd() << 32) ^ rd());
+    }();
+    return g;
+}
+
+inline std::uint32_t galois_elt_from_step(int step, std::size_t n)
+{
+    const std::uint32_t m = (std::uint32_t)(2 * n);
+    if (step == 0) return m - 1;
+    std::size_t pos;
+    if (step < 0) {
+        if ((std::size_t)(-step) >= n / 2) throw std::invalid_argument("step count too large");
+        pos = n / 2 - (std::size_t)(-step);
+    } else {
+        if ((std::size_t)step >= n / 2) throw std::invalid_argument("step count too large");
+        pos = (std::size_t)step;
+    }
+    std::uint64_t e = 1;
+    for (std::size_t i = 0; i < pos; ++i) e = (e * 3) & (m - 1);
+    return (std::uint32_t)e;
+}
+
+inline std::vector<int> naf(int value)
+{
+    std::vector<int> res;
+    const bool sign = value < 0;
+    value = std::abs(value);
+    for (int i = 0; value; ++i) {
+        const int zi = (value & 1) ? 2 - (value & 3) : 0;
+        value = (value - zi) >> 1;
+        if (zi) res.push_back((sign ? -zi : zi) * (1 << i));
+    }
+    return res;
+}
+
+inline std::uint32_t bitrev(std::uint32_t x, int bits)
+{
+    std::uint32_t r = 0;
+    for (int i = 0; i < bits; ++i) r = (r << 1) | ((x >> i) & 1);
+    return r;
+}
+
+}  // namespace shim
+
+// ------------------------------------------------------------------------------------------------
+// parameters / context
+// ------------------------------------------------------------------------------------------------
+class CoeffModulus {
+public:
+    static int MaxBitCount(std::size_t n)
+    {
+        switch (n) {
+            case 1024: return 27;
+            case 2048: return 54;
+            case 4096: return 109;
+            case 8192: return 218;
+            case 16384: return 438;
+            case 32768: return 881;
+            default: return 0;
+        }
+    }
+    // SEAL CoeffModulus::Create
+    static std::vector<SmallModulus> Create(std::size_t n, std::vector<int> bit_sizes)
+    {
+        std::map<int, int> need;
+        for (int b : bit_sizes) {
+            if (b < 2 || b > 60) throw std::invalid_argument("bit_sizes is invalid");
+            ++need[b];
+        }
+        std::map<int, std::vector<std::uint64_t>> table;
+        for (auto &kv : need) {
+            std::uint64_t v = ((std::uint64_t)1 << kv.first) - 2 * n + 1, lower = (std::uint64_t)1 << (kv.first - 1);
+            auto &vec = table[kv.first];
+            while ((int)vec.size() < kv.second && v > lower) {
+                if (shim::is_prime(v)) vec.push_back(v);
+                v -= 2 * n;
+            }
+            if ((int)vec.size() < kv.second) throw std::logic_error("failed to find enough qualifying primes");
+        }
+        std::vector<SmallModulus> out;
+        for (int b : bit_sizes) {
+            out.emplace_back(table[b].back());
+            table[b].pop_back();
+        }
+        return out;
+    }
+    // SEAL's hard-coded 128-bit-security defaults (util/globals.cpp), the sizes the reference uses
+    static std::vector<SmallModulus> BFVDefault(std::size_t n)
+    {
+        switch (n) {
+            case 4096: return {0xffffee001ull, 0xffffc4001ull, 0x1ffffe0001ull};
+            case 8192: return {0x7fffffd8001ull, 0x7fffffc8001ull, 0xfffffffc001ull, 0xffffff6c001ull, 0xfffffebc001ull};
+            case 16384:
+                return {0xfffffffd8001ull,  0xfffffffa0001ull,  0xfffffff00001ull,  0x1fffffff68001ull, 0x1fffffff50001ull,
+                        0x1ffffffee8001ull, 0x1ffffffea0001ull, 0x1ffffffe88001ull, 0x1ffffffe48001ull};
+            default: throw std::invalid_argument("poly_modulus_degree is not supported by BFVDefault in this shim");
+        }
+    }
+};
+
+class PlainModulus {
+public:
+    static SmallModulus Batching(std::size_t n, int bit_size) { return CoeffModulus::Create(n, {bit_size})[0]; }
+};
+
+class EncryptionParameters {
+public:
+    EncryptionParameters(scheme_type s = scheme_type::ckks) : scheme_(s) {}
+    EncryptionParameters(std::uint8_t s) : scheme_((scheme_type)s) {}
+    void set_poly_modulus_degree(std::size_t n) { n_ = n; }
+    void set_coeff_modulus(const std::vector<SmallModulus> &q) { q_ = q; }
+    void set_plain_modulus(const SmallModulus &t) { t_ = t; }
+    void set_plain_modulus(std::uint64_t t) { t_ = SmallModulus(t); }
+    std::size_t poly_modulus_degree() const { return n_; }
+    const std::vector<SmallModulus> &coeff_modulus() const { return q_; }
+    const SmallModulus &plain_modulus() const { return t_; }
+    scheme_type scheme() const { return scheme_; }
+
+private:
+    scheme_type scheme_;
+    std::size_t n_ = 0;
+    std::vector<SmallModulus> q_;
+    SmallModulus t_;
+};
+
+struct EncryptionParameterQualifiers {
+    bool parameters_set = true, using_fft = true, using_ntt = true, using_batching = false, using_fast_plain_lift = false,
+         using_descending_modulus_chain = true;
+    int sec_level = 128;
+};
+
+class SEALContext {
+public:
+    class ContextData {
+    public:
+        const EncryptionParameters &parms() const { return parms_; }
+        const parms_id_type &parms_id() const { return id_; }
+        std::size_t chain_index() const { return chain_index_; }
+        int total_coeff_modulus_bit_count() const { return bits_; }
+        EncryptionParameterQualifiers qualifiers() const { return quals_; }
+        std::shared_ptr<const ContextData> next_context_data() const { return next_; }
+
+    private:
+        friend class SEALContext;
+        EncryptionParameters parms_;
+        parms_id_type id_{};
+        std::size_t chain_index_ = 0;
+        int bits_ = 0;
+        EncryptionParameterQualifiers quals_;
+        std::shared_ptr<const ContextData> next_;
+    };
+
+    // SEAL 3.6 spelling: public, copyable (helper.h:239, logistic_regression_ckks.cpp:59-60)
+    SEALContext(const EncryptionParameters &parms, bool = true, int = 128) { init(parms); }
+    // SEAL 3.4.5 spelling (linear_transformation2.cpp:235, matrix_multiplication.cpp:149)
+    static std::shared_ptr<SEALContext> Create(const EncryptionParameters &parms, bool = true, int = 128)
+    {
+        return std::make_shared<SEALContext>(parms);
+    }
+
+    std::shared_ptr<const ContextData> key_context_data() const { return levels_.back(); }
+    std::shared_ptr<const ContextData> first_context_data() const { return levels_[first_level()]; }
+    std::shared_ptr<const ContextData> last_context_data() const { return levels_[0]; }
+    std::shared_ptr<const ContextData> get_context_data(const parms_id_type &id) const
+    {
+        for (auto &l : levels_)
+            if (l->id_ == id) return l;
+        return nullptr;
+    }
+    const parms_id_type &key_parms_id() const { return levels_.back()->id_; }
+    const parms_id_type &first_parms_id() const { return levels_[first_level()]->id_; }
+    const parms_id_type &last_parms_id() const { return levels_[0]->id_; }
+    bool parameters_set() const { return true; }
+    bool using_keyswitching() const { return k_ > 1; }
+
+    // ---- shim internals
+    const std::shared_ptr<shim::Engine> &engine() const
+    {
+        if (!eng_) eng_ = shim::get_engine((std::uint32_t)n_, primes_);  // lazily: BFV drivers never reach the GPU
+        return eng_;
+    }
+    std::size_t n() const { return n_; }
+    int k() const { return k_; }
+    const std::vector<std::uint64_t> &primes() const { return primes_; }
+    bool is_ckks() const { return scheme_ == scheme_type::ckks; }
+    // number of RNS rows of a level, from its parms_id (0 if unknown)
+    int rows_of(const parms_id_type &id) const
+    {
+        for (std::size_t i = 0; i < levels_.size(); ++i)
+            if (levels_[i]->id_ == id) return (int)i + 1;
+        return 0;
+    }
+    const parms_id_type &id_of_rows(int rows) const { return levels_[rows - 1]->id_; }
+
+private:
+    std::size_t first_level() const { return k_ > 1 ? (std::size_t)k_ - 2 : 0; }
+    void init(const EncryptionParameters &parms)
+    {
+        n_ = parms.poly_modulus_degree();
+        scheme_ = parms.scheme();
+        k_ = (int)parms.coeff_modulus().size();
+        if (k_ < 1) throw std::invalid_argument("coeff_modulus is not set");
+        if (n_ < 1024 || (n_ & (n_ - 1))) throw std::invalid_argument("poly_modulus_degree is not valid");
+        for (auto &q : parms.coeff_modulus()) primes_.push_back(q.value());
+        std::uint64_t h = 1469598103934665603ull;  // FNV-1a over (N, primes): identifies the parameter set
+        auto mix = [&](std::uint64_t v) {
+            for (int i = 0; i < 8; ++i) h = (h ^ ((v >> (8 * i)) & 0xff)) * 1099511628211ull;
+        };
+        mix(n_);
+        for (auto q : primes_) mix(q);
+        levels_.resize(k_);
+        for (int rows = 1; rows <= k_; ++rows) {
+            auto cd = std::make_shared<ContextData>();
+            EncryptionParameters p(scheme_);
+            p.set_poly_modulus_degree(n_);
+            p.set_coeff_modulus(std::vector<SmallModulus>(parms.coeff_modulus().begin(), parms.coeff_modulus().begin() + rows));
+            p.set_plain_modulus(parms.plain_modulus());
+            cd->parms_ = p;
+            cd->id_ = {(std::uint64_t)rows, (std::uint64_t)n_, h, 0x5ea1c0deull};
+            // chain_index: key level = k-1 ... last data level = 0 (App. A.2)
+            cd->chain_index_ = (std::size_t)(rows - 1);
+            shim::u128 dummy = 0;
+            (void)dummy;
+            int bits = 0;
+            {  // bit count of the product of the first `rows` primes
+                long double lg = 0;
+                for (int j = 0; j < rows; ++j) lg += std::log2((long double)primes_[j]);
+                bits = (int)std::floor(lg) + 1;
+            }
+            cd->bits_ = bits;
+            cd->quals_.using_batching = scheme_ == scheme_type::bfv;
+            levels_[rows - 1] = cd;
+        }
+        for (int rows = 2; rows <= k_; ++rows) levels_[rows - 1]->next_ = levels_[rows - 2];
+    }
+
+    std::size_t n_ = 0;
+    int k_ = 0;
+    scheme_type scheme_ = scheme_type::ckks;
+    std::vector<std::uint64_t> primes_;
+    std::vector<std::shared_ptr<ContextData>> levels_;  // index = rows-1
+    mutable std::shared_ptr<shim::Engine> eng_;
+};
+
+namespace shim {
+// the two context spellings the reference passes to constructors
+inline std::shared_ptr<SEALContext> as_ptr(const std::shared_ptr<SEALContext> &c)
+{
+    if (!c) throw std::invalid_argument("invalid context");
+    return c;
+}
+inline std::shared_ptr<SEALContext> as_ptr(const SEALContext &c) { return std::make_shared<SEALContext>(c); }
+}  // namespace shim
+
+// ------------------------------------------------------------------------------------------------
+// payload carriers
+// ------------------------------------------------------------------------------------------------
+class Plaintext {
+public:
+    Plaintext() = default;
+    explicit Plaintext(const std::string &) { throw std::logic_error("BFV plaintext polynomials are not built in this shim"); }
+    double &scale() { return scale_; }
+    const double &scale() const { return scale_; }
+    parms_id_type &parms_id() { return id_; }
+    const parms_id_type &parms_id() const { return id_; }
+    bool is_ntt_form() const { return true; }
+    bool is_zero() const { return zero_; }
+    std::string to_string() const { throw std::logic_error("BFV plaintext polynomials are not built in this shim"); }
+    // shim internals
+    shim::BufPtr buf;
+    int rows = 0;
+    bool zero_ = false;
+
+private:
+    double scale_ = 1.0;
+    parms_id_type id_ = parms_id_zero;
+};
+
+class Ciphertext {
+public:
+    Ciphertext() = default;
+    double &scale() { return scale_; }
+    const double &scale() const { return scale_; }
+    parms_id_type &parms_id() { return id_; }
+    const parms_id_type &parms_id() const { return id_; }
+    std::size_t size() const { return size_; }
+    std::size_t coeff_mod_count() const { return (std::size_t)rows; }
+    bool is_ntt_form() const { return true; }
+    // shim internals
+    shim::BufPtr buf;
+    int rows = 0;
+    std::size_t size_ = 0;
+    void set(shim::BufPtr b, std::size_t size, int r, const parms_id_type &id, double scale)
+    {
+        buf = std::move(b);
+        size_ = size;
+        rows = r;
+        id_ = id;
+        scale_ = scale;
+    }
+
+private:
+    double scale_ = 1.0;
+    parms_id_type id_ = parms_id_zero;
+};
+
+class SecretKey {
+public:
+    std::vector<std::uint64_t> host;  // [k][N], NTT form
+    shim::BufPtr buf;
+};
+class PublicKey {
+public:
+    shim::BufPtr buf;  // [2][k][N]
+};
+class KSwitchKeys {
+public:
+    bool has_key(std::uint32_t elt) const { return keys.count(elt) != 0; }
+    std::map<std::uint32_t, shim::BufPtr> keys;  // Galois element -> [k-1][2][k][N]; relin key under element 0
+    std::size_t size() const { return keys.size(); }
+};
+class RelinKeys : public KSwitchKeys {};
+class GaloisKeys : public KSwitchKeys {};
+
+// ------------------------------------------------------------------------------------------------
+// KeyGenerator (App. A.11): sampling on the host, arithmetic on the GPU
+// ------------------------------------------------------------------------------------------------
+class KeyGenerator {
+public:
+    template <class Ctx>
+    explicit KeyGenerator(const Ctx &context) : ctx_(shim::as_ptr(context))
+    {
+        if (!ctx_->is_ckks()) return;  // BFV drivers only compile
+        const std::size_t n = ctx_->n();
+        const int k = ctx_->k();
+        std::vector<int> tern(n);
+        std::uniform_int_distribution<int> d(-1, 1);
+        for (auto &t : tern) t = d(shim::rng());
+        std::vector<std::uint64_t> s((std::size_t)k * n);
+        for (int j = 0; j < k; ++j)
+            for (std::size_t i = 0; i < n; ++i)
+                s[(std::size_t)j * n + i] = tern[i] < 0 ? ctx_->primes()[j] - 1 : (std::uint64_t)tern[i];
+        sk_.buf = shim::upload(ctx_->engine(), s);
+        shim::check(hefx_ntt_forward(ctx_->engine()->ctx, sk_.buf->p, 1, k, 0, nullptr));
+        sk_.host = shim::download(sk_.buf);
+    }
+
+    const SecretKey &secret_key() const { return sk_; }
+    PublicKey public_key()
+    {
+        PublicKey pk;
+        auto z = encrypt_zero(1, ctx_->k());
+        const std::size_t w = (std::size_t)ctx_->k() * ctx_->n();
+        std::vector<std::uint64_t> h(2 * w);
+        auto c0 = shim::download(z.first);
+        std::copy(c0.begin(), c0.end(), h.begin());
+        std::copy(z.second.begin(), z.second.end(), h.begin() + w);
+        pk.buf = shim::upload(ctx_->engine(), h);
+        return pk;
+    }
+    void create_public_key(PublicKey &pk) { pk = public_key(); }
+
+    RelinKeys relin_keys(std::size_t = 1)
+    {
+        RelinKeys rk;
+        const int k = ctx_->k();
+        auto &e = ctx_->engine();
+        auto s2 = shim::new_buf(e, (std::size_t)k * ctx_->n());
+        shim::check(hefx_multiply_plain(e->ctx, k, 1, 1, sk_.buf->p, sk_.buf->p, s2->p, nullptr));
+        rk.keys[0] = kswitch_key(shim::download(s2));
+        return rk;
+    }
+    void create_relin_keys(RelinKeys &rk) { rk = relin_keys(); }
+
+    // default: 3^(+-2^i) and 2N-1 (power-of-two steps only, App. A.7)
+    GaloisKeys galois_keys()
+    {
+        const std::size_t n = ctx_->n();
+        int logn = 0;
+        while (((std::size_t)1 << logn) < n) ++logn;
+        std::vector<std::uint32_t> elts{(std::uint32_t)(2 * n - 1)};
+        for (int i = 0; i < logn - 1; ++i) {
+            elts.push_back(shim::galois_elt_from_step(1 << i, n));
+            elts.push_back(shim::galois_elt_from_step(-(1 << i), n));
+        }
+        return galois_keys_for(elts);
+    }
+    GaloisKeys galois_keys(const std::vector<int> &steps)
+    {
+        std::vector<std::uint32_t> elts;
+        for (int s : steps) elts.push_back(shim::galois_elt_from_step(s, ctx_->n()));
+        return galois_keys_for(elts);
+    }
+    void create_galois_keys(GaloisKeys &gk) { gk = galois_keys(); }
+    void create_galois_keys(const std::vector<int> &steps, GaloisKeys &gk) { gk = galois_keys(steps); }
+
+private:
+    GaloisKeys galois_keys_for(const std::vector<std::uint32_t> &elts)
+    {
+        GaloisKeys gk;
+        const std::size_t n = ctx_->n();
+        const int k = ctx_->k();
+        int logn = 0;
+        while (((std::size_t)1 << logn) < n) ++logn;
+        for (std::uint32_t g : elts) {
+            if (gk.has_key(g)) continue;
+            std::vector<std::uint64_t> sp((std::size_t)k * n);
+            for (std::size_t i = 0; i < n; ++i) {
+                const std::uint32_t raw = (std::uint32_t)(((std::uint64_t)g * (2 * shim::bitrev((std::uint32_t)i, logn) + 1)) & (2 * n - 1));
+                const std::uint32_t src = shim::bitrev((raw - 1) >> 1, logn);
+                for (int j = 0; j < k; ++j) sp[(std::size_t)j * n + i] = sk_.host[(std::size_t)j * n + src];
+            }
+            gk.keys[g] = kswitch_key(sp);
+        }
+        return gk;
+    }
+
+    std::vector<std::uint64_t> noise(int npoly, int rows)
+    {
+        const std::size_t n = ctx_->n();
+        std::normal_distribution<double> nd(0.0, 3.2);
+        std::vector<std::uint64_t> out((std::size_t)npoly * rows * n);
+        for (int p = 0; p < npoly; ++p)
+            for (std::size_t i = 0; i < n; ++i) {
+                double v;
+                do v = nd(shim::rng());
+                while (std::fabs(v) > 19.2);
+                const long long e = (long long)v;
+                for (int j = 0; j < rows; ++j) {
+                    const std::uint64_t q = ctx_->primes()[j];
+                    out[((std::size_t)p * rows + j) * n + i] = e >= 0 ? (std::uint64_t)e : q - (std::uint64_t)(-e);
+                }
+            }
+        return out;
+    }
+
+    // npoly fresh symmetric encryptions of zero over the first `rows` primes: (device c0, host c1)
+    std::pair<shim::BufPtr, std::vector<std::uint64_t>> encrypt_zero(int npoly, int rows)
+    {
+        auto &e = ctx_->engine();
+        const std::size_t n = ctx_->n();
+        std::vector<std::uint64_t> a((std::size_t)npoly * rows * n);
+        for (int p = 0; p < npoly; ++p)
+            for (int j = 0; j < rows; ++j) {
+                std::uniform_int_distribution<std::uint64_t> d(0, ctx_->primes()[j] - 1);
+                for (std::size_t i = 0; i < n; ++i) a[((std::size_t)p * rows + j) * n + i] = d(shim::rng());
+            }
+        auto da = shim::upload(e, a);
+        auto de = shim::upload(e, noise(npoly, rows));
+        shim::check(hefx_ntt_forward(e->ctx, de->p, npoly, rows, 0, nullptr));
+        auto t = shim::new_buf(e, a.size());
+        shim::check(hefx_multiply_plain(e->ctx, rows, npoly, 1, da->p, sk_.buf->p, t->p, nullptr));
+        shim::check(hefx_add(e->ctx, rows, npoly, 1, t->p, de->p, t->p, nullptr));
+        shim::check(hefx_negate(e->ctx, rows, npoly, 1, t->p, t->p, nullptr));
+        return {t, a};
+    }
+
+    shim::BufPtr kswitch_key(const std::vector<std::uint64_t> &new_sk)
+    {
+        auto &e = ctx_->engine();
+        const std::size_t n = ctx_->n();
+        const int k = ctx_->k();
+        if (k < 2) throw std::logic_error("keyswitching is not supported by the context");
+        auto z = encrypt_zero(k - 1, k);
+        std::vector<std::uint64_t> c0 = shim::download(z.first);
+        const std::uint64_t P = ctx_->primes()[k - 1];
+        std::vector<std::uint64_t> key((std::size_t)(k - 1) * 2 * k * n);
+        for (int i = 0; i < k - 1; ++i) {
+            const std::uint64_t q = ctx_->primes()[i], f = P % q;
+            std::uint64_t *row = &c0[((std::size_t)i * k + i) * n];
+            const std::uint64_t *ns = &new_sk[(std::size_t)i * n];
+            for (std::size_t a = 0; a < n; ++a) {
+                const std::uint64_t s = row[a] + shim::mulmod(ns[a], f, q);
+                row[a] = s >= q ? s - q : s;
+            }
+            std::copy(c0.begin() + (std::size_t)i * k * n, c0.begin() + (std::size_t)(i + 1) * k * n,
+                      key.begin() + ((std::size_t)i * 2) * k * n);
+            std::copy(z.second.begin() + (std::size_t)i * k * n, z.second.begin() + (std::size_t)(i + 1) * k * n,
+                      key.begin() + ((std::size_t)i * 2 + 1) * k * n);
+        }
+        return shim::upload(e, key);
+    }
+
+    std::shared_ptr<SEALContext> ctx_;
+    SecretKey sk_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// Encryptor / Decryptor
+// ------------------------------------------------------------------------------------------------
+class Encryptor {
+public:
+    template <class Ctx>
+    Encryptor(const Ctx &context, const PublicKey &pk) : ctx_(shim::as_ptr(context)), pk_(pk) {}
+
+    // (pk0*u + e0 + m, pk1*u + e1) over the plaintext's level
+    void encrypt(const Plaintext &plain, Ciphertext &dest) const
+    {
+        if (!ctx_->is_ckks()) throw std::logic_error("BFV is not built in this shim");
+        if (!plain.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
+        auto &e = ctx_->engine();
+        const std::size_t n = ctx_->n();
+        const int L = plain.rows, k = ctx_->k();
+        std::vector<std::uint64_t> u((std::size_t)L * n), err((std::size_t)2 * L * n);
+        std::uniform_int_distribution<int> td(-1, 1);
+        std::normal_distribution<double> nd(0.0, 3.2);
+        for (std::size_t i = 0; i < n; ++i) {
+            const int t = td(shim::rng());
+            long long en[2];
+            for (auto &x : en) {
+                double v;
+                do v = nd(shim::rng());
+                while (std::fabs(v) > 19.2);
+                x = (long long)v;
+            }
+            for (int j = 0; j < L; ++j) {
+                const std::uint64_t q = ctx_->primes()[j];
+                u[(std::size_t)j * n + i] = t < 0 ? q - 1 : (std::uint64_t)t;
+                for (int c = 0; c < 2; ++c)
+                    err[((std::size_t)c * L + j) * n + i] = en[c] >= 0 ? (std::uint64_t)en[c] : q - (std::uint64_t)(-en[c]);
+            }
+        }
+        auto du = shim::upload(e, u), de = shim::upload(e, err);
+        shim::check(hefx_ntt_forward(e->ctx, du->p, 1, L, 0, nullptr));
+        shim::check(hefx_ntt_forward(e->ctx, de->p, 2, L, 0, nullptr));
+        auto pkl = shim::new_buf(e, (std::size_t)2 * L * n);  // first L rows of each pk poly
+        shim::check(hefx_mod_drop(e->ctx, k, L, 2, pk_.buf->p, pkl->p, nullptr));
+        auto c = shim::new_buf(e, (std::size_t)2 * L * n);
+        shim::check(hefx_multiply_plain(e->ctx, L, 2, 1, pkl->p, du->p, c->p, nullptr));
+        shim::check(hefx_add(e->ctx, L, 2, 1, c->p, de->p, c->p, nullptr));
+        shim::check(hefx_add_plain(e->ctx, L, 2, c->p, plain.buf->p, c->p, nullptr));
+        dest.set(c, 2, L, plain.parms_id(), plain.scale());
+    }
+
+private:
+    std::shared_ptr<SEALContext> ctx_;
+    PublicKey pk_;
+};
+
+class Decryptor {
+public:
+    template <class Ctx>
+    Decryptor(const Ctx &context, const SecretKey &sk) : ctx_(shim::as_ptr(context)), sk_(sk) {}
+
+    // c0 + c1 s (+ c2 s^2 ...): handles size-3 ciphertexts (matrix_multiplication.cpp:419)
+    void decrypt(const Ciphertext &ct, Plaintext &dest) const
+    {
+        if (!ct.buf) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        auto &e = ctx_->engine();
+        const std::size_t n = ctx_->n(), w = (std::size_t)ct.rows * n;
+        const int L = ct.rows;
+        auto acc = shim::new_buf(e, w);
+        shim::check(hefx_copy(e->ctx, acc->p, ct.buf->p + (ct.size() - 1) * w, w * 8, nullptr));
+        for (int p = (int)ct.size() - 2; p >= 0; --p) {
+            shim::check(hefx_multiply_plain(e->ctx, L, 1, 1, acc->p, sk_.buf->p, acc->p, nullptr));
+            shim::check(hefx_add(e->ctx, L, 1, 1, acc->p, ct.buf->p + (std::size_t)p * w, acc->p, nullptr));
+        }
+        dest.buf = acc;
+        dest.rows = L;
+        dest.parms_id() = ct.parms_id();
+        dest.scale() = ct.scale();
+        dest.zero_ = false;
+    }
+    int invariant_noise_budget(const Ciphertext &) const { throw std::logic_error("BFV is not built in this shim"); }
+
+private:
+    std::shared_ptr<SEALContext> ctx_;
+    SecretKey sk_;
+};
+
+// ------------------------------------------------------------------------------------------------
+// CKKSEncoder (App. A.12): canonical embedding, slot i <-> root zeta^(3^i); FFT on the host, NTT on the GPU
+// ------------------------------------------------------------------------------------------------
+class CKKSEncoder {
+public:
+    template <class Ctx>
+    explicit CKKSEncoder(const Ctx &context) : ctx_(shim::as_ptr(context))
+    {
+        if (!ctx_->is_ckks()) throw std::invalid_argument("unsupported scheme");
+        const std::size_t n = ctx_->n();
+        r1_.resize(n / 2);
+        r2_.resize(n / 2);
+        std::uint64_t pos = 1;
+        for (std::size_t i = 0; i < n / 2; ++i) {
+            r1_[i] = (std::size_t)((pos - 1) >> 1);
+            r2_[i] = (std::size_t)((2 * n - pos - 1) >> 1);
+            pos = (pos * 3) & (2 * n - 1);
+        }
+        zeta_.resize(n);
+        const double pi = std::acos(-1.0);
+        for (std::size_t i = 0; i < n; ++i) zeta_[i] = std::polar(1.0, pi * (double)i / (double)n);
+        tw_.resize(n / 2);
+        for (std::size_t i = 0; i < n / 2; ++i) tw_[i] = std::polar(1.0, -2.0 * pi * (double)i / (double)n);
+    }
+    std::size_t slot_count() const { return ctx_->n() / 2; }
+
+    void encode(const std::vector<double> &values, parms_id_type id, double scale, Plaintext &dest) const
+    {
+        const std::size_t n = ctx_->n();
+        if (values.size() > n / 2) throw std::invalid_argument("values has invalid size");
+        const int L = rows_checked(id, scale);
+        std::vector<std::complex<double>> A(n, 0.0);
+        for (std::size_t i = 0; i < values.size(); ++i) {
+            A[r1_[i]] = values[i];
+            A[r2_[i]] = values[i];
+        }
+        fft(A, false);  // a_k = (1/N) sum_r A_r e^{-2 pi i r k / N}
+        std::vector<std::uint64_t> rows((std::size_t)L * n);
+        bool any = false;
+        for (std::size_t i = 0; i < n; ++i) {
+            const double co = std::round((A[i] * std::conj(zeta_[i])).real() / (double)n * scale);
+            any = any || co != 0.0;
+            put(rows, i, co, L);
+        }
+        auto &e = ctx_->engine();
+        dest.buf = shim::upload(e, rows);
+        shim::check(hefx_ntt_forward(e->ctx, dest.buf->p, 1, L, 0, nullptr));
+        finish(dest, L, id, scale, !any);
+    }
+    void encode(const std::vector<double> &values, double scale, Plaintext &dest) const
+    {
+        encode(values, ctx_->first_parms_id(), scale, dest);
+    }
+    // every NTT slot = round(value*scale): no FFT
+    void encode(double value, parms_id_type id, double scale, Plaintext &dest) const
+    {
+        const std::size_t n = ctx_->n();
+        const int L = rows_checked(id, scale);
+        const double co = std::round(value * scale);
+        std::vector<std::uint64_t> one((std::size_t)L), rows((std::size_t)L * n);
+        std::vector<std::uint64_t> tmp((std::size_t)L * n, 0);
+        put(tmp, 0, co, L);  // residue of the constant per row
+        for (int j = 0; j < L; ++j) std::fill(rows.begin() + (std::size_t)j * n, rows.begin() + (std::size_t)(j + 1) * n, tmp[(std::size_t)j * n]);
+        dest.buf = shim::upload(ctx_->engine(), rows);
+        finish(dest, L, id, scale, co == 0.0);
+    }
+    void encode(double value, double scale, Plaintext &dest) const { encode(value, ctx_->first_parms_id(), scale, dest); }
+
+    void decode(const Plaintext &plain, std::vector<double> &dest) const
+    {
+        if (!plain.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
+        auto &e = ctx_->engine();
+        const std::size_t n = ctx_->n();
+        const int L = plain.rows;
+        auto tmp = shim::new_buf(e, (std::size_t)L * n);
+        shim::check(hefx_copy(e->ctx, tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
+        shim::check(hefx_ntt_inverse(e->ctx, tmp->p, 1, L, 0, nullptr));
+        const std::vector<std::uint64_t> co = shim::download(tmp);
+        // CRT compose (Garner mixed radix -> little-endian limbs), centre, scale
+        const auto &q = ctx_->primes();
+        std::vector<std::vector<std::uint64_t>> inv(L, std::vector<std::uint64_t>(L, 0));
+        for (int i = 0; i < L; ++i)
+            for (int j = 0; j < i; ++j) inv[j][i] = shim::powmod(q[j] % q[i], q[i] - 2, q[i]);
+        const int NL = L + 1;
+        std::vector<std::uint64_t> Q(NL, 0), half(NL, 0);
+        Q[0] = 1;
+        for (int j = 0; j < L; ++j) mul_add(Q, q[j], 0);
+        for (int i = 0; i < NL; ++i) half[i] = (Q[i] >> 1) | (i + 1 < NL ? Q[i + 1] << 63 : 0);
+        std::vector<std::complex<double>> A(n);
+        std::vector<std::uint64_t> dig(L), X(NL), Y(NL);
+        for (std::size_t a = 0; a < n; ++a) {
+            for (int i = 0; i < L; ++i) {
+                std::uint64_t t = co[(std::size_t)i * n + a];
+                for (int j = 0; j < i; ++j) {
+                    const std::uint64_t dj = dig[j] % q[i];
+                    t = shim::mulmod(t >= dj ? t - dj : t + q[i] - dj, inv[j][i], q[i]);
+                }
+                dig[i] = t;
+            }
+            std::fill(X.begin(), X.end(), 0);
+            X[0] = dig[L - 1];
+            for (int i = L - 2; i >= 0; --i) mul_add(X, q[i], dig[i]);
+            double v;
+            if (cmp(X, half) > 0) {
+                sub(Y, Q, X);
+                v = -to_double(Y);
+            } else
+                v = to_double(X);
+            A[a] = (v / plain.scale()) * zeta_[a];
+        }
+        fft(A, true);  // P(zeta^(2r+1)) = sum_k p_k zeta^k e^{+2 pi i r k / N}
+        dest.resize(n / 2);
+        for (std::size_t i = 0; i < n / 2; ++i) dest[i] = A[r1_[i]].real();
+    }
+
+private:
+    int rows_checked(const parms_id_type &id, double scale) const
+    {
+        const int L = ctx_->rows_of(id);
+        if (L == 0) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (scale <= 0 || (int)std::log2(scale) >= ctx_->get_context_data(id)->total_coeff_modulus_bit_count())
+            throw std::invalid_argument("scale out of bounds");
+        return L;
+    }
+    void finish(Plaintext &dest, int L, const parms_id_type &id, double scale, bool zero) const
+    {
+        dest.rows = L;
+        dest.parms_id() = id;
+        dest.scale() = scale;
+        dest.zero_ = zero;
+    }
+    void put(std::vector<std::uint64_t> &rows, std::size_t i, double co, int L) const
+    {
+        const std::size_t n = ctx_->n();
+        const bool neg = co < 0;
+        const shim::u128 mag = (shim::u128)std::fabs(co);
+        for (int j = 0; j < L; ++j) {
+            const std::uint64_t q = ctx_->primes()[j], r = (std::uint64_t)(mag % q);
+            rows[(std::size_t)j * n + i] = neg ? (r ? q - r : 0) : r;
+        }
+    }
+    // in-place radix-2 DFT of size N; inverse=false: e^{-i}, scaled by nothing (caller divides); inverse=true: e^{+i}
+    void fft(std::vector<std::complex<double>> &v, bool positive) const
+    {
+        const std::size_t n = v.size();
+        for (std::size_t i = 1, j = 0; i < n; ++i) {
+            std::size_t bit = n >> 1;
+            for (; j >= bit; bit >>= 1) j -= bit;
+            j += bit;
+            if (i < j) std::swap(v[i], v[j]);
+        }
+        for (std::size_t len = 2; len <= n; len <<= 1) {
+            const std::size_t h = len >> 1, step = n / len;
+            for (std::size_t i = 0; i < n; i += len)
+                for (std::size_t j = 0; j < h; ++j) {
+                    const std::complex<double> w = positive ? std::conj(tw_[j * step]) : tw_[j * step];
+                    const std::complex<double> a = v[i + j], b = v[i + j + h] * w;
+                    v[i + j] = a + b;
+                    v[i + j + h] = a - b;
+                }
+        }
+    }
+    static void mul_add(std::vector<std::uint64_t> &x, std::uint64_t m, std::uint64_t a)
+    {
+        shim::u128 carry = a;
+        for (auto &limb : x) {
+            const shim::u128 t = (shim::u128)limb * m + carry;
+            limb = (std::uint64_t)t;
+            carry = t >> 64;
+        }
+    }
+    static int cmp(const std::vector<std::uint64_t> &a, const std::vector<std::uint64_t> &b)
+    {
+        for (int i = (int)a.size() - 1; i >= 0; --i)
+            if (a[i] != b[i]) return a[i] > b[i] ? 1 : -1;
+        return 0;
+    }
+    static void sub(std::vector<std::uint64_t> &r, const std::vector<std::uint64_t> &a, const std::vector<std::uint64_t> &b)
+    {
+        std::uint64_t borrow = 0;
+        for (std::size_t i = 0; i < a.size(); ++i) {
+            const std::uint64_t t = a[i] - b[i], b1 = a[i] < b[i], t2 = t - borrow, b2 = t < borrow;
+            r[i] = t2;
+            borrow = b1 | b2;
+        }
+    }
+    static double to_double(const std::vector<std::uint64_t> &a)
+    {
+        double r = 0;
+        for (int i = (int)a.size() - 1; i >= 0; --i) r = r * 18446744073709551616.0 + (double)a[i];
+        return r;
+    }
+
+    std::shared_ptr<SEALContext> ctx_;
+    std::vector<std::size_t> r1_, r2_;
+    std::vector<std::complex<double>> zeta_, tw_;
+};
+
+// BFV-only encoders: declared so that the drivers compile (vector_ops.cpp:101-195, 2_encoders.cpp); not built.
+class BatchEncoder {
+public:
+    template <class Ctx>
+    explicit BatchEncoder(const Ctx &)
+    {
+        throw std::logic_error("BFV (BatchEncoder) is not built in this shim");
+    }
+    std::size_t slot_count() const { return 0; }
+    template <class V>
+    void encode(const V &, Plaintext &) const {}
+    template <class V>
+    void decode(const Plaintext &, V &) const {}
+};
+class IntegerEncoder {
+public:
+    template <class Ctx>
+    explicit IntegerEncoder(const Ctx &)
+    {
+        throw std::logic_error("BFV (IntegerEncoder) is not built in this shim");
+    }
+    Plaintext encode(std::int64_t) const { return Plaintext(); }
+    std::int64_t decode_int32(const Plaintext &) const { return 0; }
+    std::int64_t decode_int64(const Plaintext &) const { return 0; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Evaluator: every method is a hefx_* dispatch (GPU); SEAL's checks and messages stay on the host
+// ------------------------------------------------------------------------------------------------
+class Evaluator {
+public:
+    template <class Ctx>
+    explicit Evaluator(const Ctx &context) : ctx_(shim::as_ptr(context))
+    {
+    }
+
+    // ---- add / sub / negate (helper.h:219,247,259,464,475; logistic_regression_ckks.cpp:288,341-342)
+    void add(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest) const { addsub(a, b, dest, false); }
+    void add_inplace(Ciphertext &a, const Ciphertext &b) const { addsub(a, b, a, false); }
+    void sub(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest) const { addsub(a, b, dest, true); }
+    void sub_inplace(Ciphertext &a, const Ciphertext &b) const { addsub(a, b, a, true); }
+    void add_many(const std::vector<Ciphertext> &cts, Ciphertext &dest) const
+    {
+        if (cts.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+        bool uniform = true;
+        for (auto &c : cts) {
+            check_ct(c);
+            uniform = uniform && c.size() == cts[0].size();
+            if (c.parms_id() != cts[0].parms_id()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+            if (!close(c.scale(), cts[0].scale())) throw std::invalid_argument("scale mismatch");
+        }
+        if (!uniform) {  // SEAL's definition: dest = cts[0]; add_inplace the rest
+            Ciphertext acc = cts[0];
+            for (std::size_t i = 1; i < cts.size(); ++i) add_inplace(acc, cts[i]);
+            dest = acc;
+            return;
+        }
+        auto &e = eng();
+        const int L = cts[0].rows;
+        std::vector<const std::uint64_t *> ptrs;
+        for (auto &c : cts) ptrs.push_back(c.buf->p);
+        auto out = shim::new_buf(e, words(cts[0].size(), L));
+        shim::check(hefx_add_many(e->ctx, L, (int)cts[0].size(), (int)cts.size(), ptrs.data(), out->p, nullptr));
+        dest.set(out, cts[0].size(), L, cts[0].parms_id(), cts[0].scale());
+    }
+    void negate(const Ciphertext &a, Ciphertext &dest) const
+    {
+        check_ct(a);
+        auto out = shim::new_buf(eng(), a.buf->words);
+        shim::check(hefx_negate(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
+        dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
+    }
+    void negate_inplace(Ciphertext &a) const { negate(a, a); }
+    void add_plain(const Ciphertext &a, const Plaintext &p, Ciphertext &dest) const
+    {
+        check_ct(a);
+        check_pt(a, p);
+        if (!close(a.scale(), p.scale())) throw std::invalid_argument("scale mismatch");
+        auto out = shim::new_buf(eng(), a.buf->words);
+        shim::check(hefx_add_plain(eng()->ctx, a.rows, (int)a.size(), a.buf->p, p.buf->p, out->p, nullptr));
+        dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
+    }
+    void add_plain_inplace(Ciphertext &a, const Plaintext &p) const { add_plain(a, p, a); }
+
+    // ---- multiply (helper.h:222,228,250,256,432; matrix_multiplication.cpp:104,127; vector_ops.cpp:269)
+    void multiply_plain(const Ciphertext &a, const Plaintext &p, Ciphertext &dest) const
+    {
+        check_ct(a);
+        check_pt(a, p);
+        const double ns = a.scale() * p.scale();
+        check_scale(ns, a.parms_id());
+        auto out = shim::new_buf(eng(), a.buf->words);
+        shim::check(hefx_multiply_plain(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, p.buf->p, out->p, nullptr));
+        // a valid ciphertext's c1 is uniformly random, so the product is transparent exactly when the plaintext
+        // is zero -- known on the host since encode time; no device sync needed (why the reference adds 1e-8).
+        if (p.is_zero()) throw std::logic_error("result ciphertext is transparent");
+        dest.set(out, a.size(), a.rows, a.parms_id(), ns);
+    }
+    void multiply_plain_inplace(Ciphertext &a, const Plaintext &p) const { multiply_plain(a, p, a); }
+    void multiply(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest) const
+    {
+        check_ct(a);
+        check_ct(b);
+        if (a.parms_id() != b.parms_id()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (a.size() != 2 || b.size() != 2)
+            throw std::invalid_argument("multiply: only size-2 operands are built (every reference call site)");
+        const double ns = a.scale() * b.scale();
+        check_scale(ns, a.parms_id());
+        auto out = shim::new_buf(eng(), words(3, a.rows));
+        if (a.buf == b.buf)
+            shim::check(hefx_square(eng()->ctx, a.rows, a.buf->p, out->p, nullptr));
+        else
+            shim::check(hefx_multiply(eng()->ctx, a.rows, a.buf->p, b.buf->p, out->p, nullptr));
+        dest.set(out, 3, a.rows, a.parms_id(), ns);
+    }
+    void multiply_inplace(Ciphertext &a, const Ciphertext &b) const { multiply(a, b, a); }
+    void square(const Ciphertext &a, Ciphertext &dest) const { multiply(a, a, dest); }
+    void square_inplace(Ciphertext &a) const { multiply(a, a, a); }
+
+    // ---- relinearize / rescale / mod switch (helper.h:440-441; matrix_multiplication.cpp:71-72,112)
+    void relinearize_inplace(Ciphertext &a, const RelinKeys &rk) const
+    {
+        check_ct(a);
+        if (a.size() == 2) return;  // SEAL: nothing to do
+        if (a.size() != 3) throw std::invalid_argument("encrypted size must be 2 or 3");
+        if (!rk.has_key(0)) throw std::invalid_argument("not enough relinearization keys");
+        auto out = shim::new_buf(eng(), words(2, a.rows));
+        shim::check(hefx_relinearize(eng()->ctx, a.rows, a.buf->p, rk.keys.at(0)->p, out->p, nullptr));
+        a.set(out, 2, a.rows, a.parms_id(), a.scale());
+    }
+    void relinearize(const Ciphertext &a, const RelinKeys &rk, Ciphertext &dest) const
+    {
+        dest = a;
+        relinearize_inplace(dest, rk);
+    }
+    void rescale_to_next(const Ciphertext &a, Ciphertext &dest) const
+    {
+        check_ct(a);
+        if (a.rows <= 1) throw std::invalid_argument("end of modulus switching chain reached");
+        auto out = shim::new_buf(eng(), words(a.size(), a.rows - 1));
+        shim::check(hefx_rescale_to_next(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
+        dest.set(out, a.size(), a.rows - 1, ctx_->id_of_rows(a.rows - 1), a.scale() / (double)ctx_->primes()[a.rows - 1]);
+    }
+    void rescale_to_next_inplace(Ciphertext &a) const { rescale_to_next(a, a); }
+    void mod_switch_to_inplace(Ciphertext &a, const parms_id_type &id) const
+    {
+        check_ct(a);
+        const int L = target_rows(a.rows, id);
+        if (L == a.rows) return;
+        auto out = shim::new_buf(eng(), words(a.size(), L));
+        shim::check(hefx_mod_drop(eng()->ctx, a.rows, L, (int)a.size(), a.buf->p, out->p, nullptr));
+        a.set(out, a.size(), L, id, a.scale());
+    }
+    void mod_switch_to_inplace(Plaintext &p, const parms_id_type &id) const
+    {
+        if (!p.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
+        const int L = target_rows(p.rows, id);
+        if (L == p.rows) return;
+        auto out = shim::new_buf(eng(), words(1, L));
+        shim::check(hefx_mod_drop(eng()->ctx, p.rows, L, 1, p.buf->p, out->p, nullptr));
+        p.buf = out;
+        p.rows = L;
+        p.parms_id() = id;
+    }
+    void mod_switch_to_next_inplace(Ciphertext &a) const
+    {
+        if (a.rows <= 1) throw std::invalid_argument("end of modulus switching chain reached");
+        mod_switch_to_inplace(a, ctx_->id_of_rows(a.rows - 1));
+    }
+    void mod_switch_to_next_inplace(Plaintext &p) const
+    {
+        if (p.rows <= 1) throw std::invalid_argument("end of modulus switching chain reached");
+        mod_switch_to_inplace(p, ctx_->id_of_rows(p.rows - 1));
+    }
+    void mod_switch_to_next(const Ciphertext &a, Ciphertext &dest) const
+    {
+        dest = a;
+        mod_switch_to_next_inplace(dest);
+    }
+    void mod_switch_to(const Ciphertext &a, const parms_id_type &id, Ciphertext &dest) const
+    {
+        dest = a;
+        mod_switch_to_inplace(dest, id);
+    }
+
+    // ---- rotations (helper.h:216,227,244,255,316,352,455,474; 5_rotation.cpp:215): rotate_internal of
+    //      App. A.7 -- direct key if present, otherwise the NAF chain, least significant term first
+    void rotate_vector(const Ciphertext &a, int steps, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        check_ct(a);
+        if (a.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+        std::vector<std::uint32_t> plan;
+        rotation_plan(steps, gk, plan);
+        shim::BufPtr cur = a.buf;
+        for (std::uint32_t elt : plan) {
+            auto out = shim::new_buf(eng(), words(2, a.rows));
+            shim::check(hefx_apply_galois(eng()->ctx, a.rows, cur->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+            cur = out;
+        }
+        dest.set(cur, 2, a.rows, a.parms_id(), a.scale());
+    }
+    void rotate_vector_inplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { rotate_vector(a, steps, gk, a); }
+    void complex_conjugate(const Ciphertext &a, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        check_ct(a);
+        const std::uint32_t elt = (std::uint32_t)(2 * ctx_->n() - 1);
+        if (!gk.has_key(elt)) throw std::invalid_argument("Galois key not present");
+        auto out = shim::new_buf(eng(), words(2, a.rows));
+        shim::check(hefx_apply_galois(eng()->ctx, a.rows, a.buf->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+        dest.set(out, 2, a.rows, a.parms_id(), a.scale());
+    }
+    void complex_conjugate_inplace(Ciphertext &a, const GaloisKeys &gk) const { complex_conjugate(a, gk, a); }
+    // BFV only
+    void rotate_rows_inplace(Ciphertext &, int, const GaloisKeys &) const { throw std::logic_error("BFV is not built in this shim"); }
+    void rotate_columns_inplace(Ciphertext &, const GaloisKeys &) const { throw std::logic_error("BFV is not built in this shim"); }
+
+    void rotation_plan(int steps, const GaloisKeys &gk, std::vector<std::uint32_t> &plan) const
+    {
+        if (steps == 0) return;
+        const std::size_t n = ctx_->n();
+        const std::uint32_t elt = shim::galois_elt_from_step(steps, n);
+        if (gk.has_key(elt)) {
+            plan.push_back(elt);
+            return;
+        }
+        const std::vector<int> terms = shim::naf(steps);
+        if (terms.size() == 1) throw std::invalid_argument("Galois key not present");
+        for (int t : terms) {
+            if ((std::size_t)std::abs(t) == n / 2) continue;
+            rotation_plan(t, gk, plan);
+        }
+    }
+
+private:
+    const std::shared_ptr<shim::Engine> &eng() const { return ctx_->engine(); }
+    std::size_t words(std::size_t size, int rows) const { return size * (std::size_t)rows * ctx_->n(); }
+    static bool close(double a, double b) { return a == b || std::fabs(a - b) <= std::max(std::fabs(a), std::fabs(b)) * 9.094947017729282e-13; }
+    void check_ct(const Ciphertext &c) const
+    {
+        if (!c.buf || ctx_->rows_of(c.parms_id()) != c.rows) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+    }
+    void check_pt(const Ciphertext &c, const Plaintext &p) const
+    {
+        if (!p.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
+        if (c.parms_id() != p.parms_id()) throw std::invalid_argument("encrypted_ntt and plain_ntt parameter mismatch");
+    }
+    void check_scale(double s, const parms_id_type &id) const
+    {
+        if (s <= 0 || (int)std::log2(s) >= ctx_->get_context_data(id)->total_coeff_modulus_bit_count())
+            throw std::invalid_argument("scale out of bounds");
+    }
+    int target_rows(int rows, const parms_id_type &id) const
+    {
+        const int L = ctx_->rows_of(id);
+        if (L == 0) throw std::invalid_argument("parms_id is not valid for encryption parameters");
+        if (L > rows) throw std::invalid_argument("cannot switch to higher level modulus");
+        return L;
+    }
+    void addsub(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest, bool sub) const
+    {
+        check_ct(a);
+        check_ct(b);
+        if (a.parms_id() != b.parms_id()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (!close(a.scale(), b.scale())) throw std::invalid_argument("scale mismatch");
+        auto &e = eng();
+        const int L = a.rows;
+        const std::size_t mx = std::max(a.size(), b.size()), mn = std::min(a.size(), b.size());
+        auto out = shim::new_buf(e, words(mx, L));
+        auto f = sub ? hefx_sub : hefx_add;
+        shim::check(f(e->ctx, L, (int)mn, 1, a.buf->p, b.buf->p, out->p, nullptr));
+        if (mx > mn) {  // result size = max; extra polys are copied (negated when they come from b in a sub)
+            const Ciphertext &big = a.size() > b.size() ? a : b;
+            const std::size_t off = words(mn, L), cnt = words(mx - mn, L);
+            if (sub && &big == &b)
+                shim::check(hefx_negate(e->ctx, L, (int)(mx - mn), 1, b.buf->p + off, out->p + off, nullptr));
+            else
+                shim::check(hefx_copy(e->ctx, out->p + off, big.buf->p + off, cnt * 8, nullptr));
+        }
+        dest.set(out, mx, L, a.parms_id(), a.scale());
+    }
+
+    std::shared_ptr<SEALContext> ctx_;
+};
+
+}  // namespace seal

@@ -153,3 +153,30 @@ def test_cc_matrix_multiplication_n4_known_answer():
     assert (bits(eg, cg) == bits(eo, co)).all()
     got = decode(eg, cg, n * n).reshape(n, n)
     assert np.allclose(got, want, rtol=1e-4, atol=1e-2), got
+
+
+def _driver(name):
+    import os
+    p = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "drivers", "_ref", name)
+    if not os.path.exists(p):
+        pytest.skip(f"{name} not built (make -C drivers needs /root/reference, absent on the GPU box unless prebuilt)")
+    return p
+
+
+def test_cpp_shim_selftest():
+    """include/seal/seal.h over the C-ABI: values, levels, NAF rotations, SEAL's exceptions (drivers/shim_selftest.cpp)"""
+    import subprocess
+    r = subprocess.run([_driver("shim_selftest")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SELFTEST PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_reference_matrix_multiplication_driver_unchanged():
+    """The reference's own matrix_multiplication.cpp (config 3), compiled unchanged against the shim, prints A*A."""
+    import re
+    import subprocess
+    r = subprocess.run([_driver("matrix_multiplication")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    tail = r.stdout[r.stdout.rindex("Resulting matrix"):]
+    nums = [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", tail)][:16]
+    want = (np.arange(1, 17).reshape(4, 4) @ np.arange(1, 17).reshape(4, 4)).reshape(-1)
+    assert np.allclose(nums, want, atol=0.05), nums  # the driver adds 1e-8 to every diagonal entry (:239)
