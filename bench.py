@@ -177,6 +177,17 @@ def main():
         # roofline of the path on THIS rank: algorithmic bytes of one step / HIP-event time of one step
         step_ms = gpu_ms / args.steps
         achieved = B * bytes_op / (step_ms * 1e-3) / 1e9
+        # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc passes of this same command
+        # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
+        if args.set == "C3" and os.path.exists(pmc):
+            try:
+                pb = json.load(open(pmc))["per_op_bytes"]
+                traffic = (pb["fetch_x2"] + pb["write"]) * B / 1e9  # GB per step, same unit basis as achieved*time
+                traffic_src = "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); GB per step"
+            except Exception:
+                pass
         dom = max(stage_ms, key=stage_ms.get)
         tot = sum(stage_ms.values())
         line = {
@@ -207,8 +218,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "launch": "one step = the 5-kernel key-switch sequence over the whole batch "
+                "traffic": traffic,
+                "traffic_source": traffic_src,
+                "launch": "one step = the 6-kernel key-switch sequence over the whole batch "
                           f"({nchunks} chunks); achieved = {B} ops x {bytes_op} B / {step_ms:.3f} ms (HIP events)",
                 "dominant_kernel": dom,
                 "kernel_avg_us": {kname: ms / max(nchunks, 1) * 1e3 for kname, ms in stage_ms.items()},

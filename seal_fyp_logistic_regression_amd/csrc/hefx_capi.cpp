@@ -115,7 +115,7 @@ struct hefx_context {
     // scratch (grown on demand, reused across calls so it stays cache-resident)
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
-    int chunk = 32;
+    int chunk = 64;
     int *d_flag = nullptr;  // [0] transparent count, [1] per-call "non-zero seen"
     hipStream_t streams[2] = {nullptr, nullptr};  // internal streams for chunk pipelining
     hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};

@@ -112,6 +112,10 @@ class Engine:
         capi.check(capi.lib().hefx_copy(self._h, dst.ptr, src.ptr, src.nbytes, stream))
         return dst
 
+    def copy_raw(self, dst_ptr: int, src_ptr: int, nbytes: int, stream=None):
+        """device-to-device copy between raw pointers (e.g. a torch tensor's data_ptr)"""
+        capi.check(capi.lib().hefx_copy(self._h, int(dst_ptr), int(src_ptr), int(nbytes), stream))
+
     def sync(self, stream=None):
         capi.check(capi.lib().hefx_stream_sync(self._h, stream))
 
