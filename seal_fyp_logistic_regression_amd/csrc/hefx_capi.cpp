@@ -115,11 +115,18 @@ struct hefx_context {
     // scratch (grown on demand, reused across calls so it stays cache-resident)
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
-    int chunk = 64;
+    int chunk = 0;  // items per launch sequence; 0 = sized from the scratch budget (HEFX_CHUNK overrides)
     int *d_flag = nullptr;  // [0] transparent count, [1] per-call "non-zero seen"
-    hipStream_t streams[2] = {nullptr, nullptr};  // internal streams for chunk pipelining
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    static constexpr int MAX_STREAMS = 4;
+    hipStream_t streams[MAX_STREAMS] = {};  // internal streams for chunk pipelining
+    hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {};
+    int nstreams = 2;
     bool use_streams = true;
+    // descriptor ring: pinned host mirror + device copy + "slot free" events
+    KsItem *h_items = nullptr, *d_items = nullptr;
+    hipEvent_t ring_ev[KS_RING] = {};
+    bool ring_busy[KS_RING] = {};
+    unsigned ring_next = 0;
     // profiling session (hefx_profile_begin/end): per-chunk event sextets, serial on the caller's stream
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;
@@ -192,18 +199,20 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     const size_t tw_bytes = sizeof(ulonglong2) * n * k;
     const size_t mods_bytes = sizeof(ModConst) * k;
     const size_t inv_bytes = sizeof(ulonglong2) * k * k;
-    const size_t half_bytes = sizeof(u64) * k * k;
+    const size_t half_bytes = (sizeof(u64) * k * k + 15) & ~(size_t)15;  // padded: 16-byte records follow
     const size_t modsf_bytes = sizeof(ModConstF) * k;
-    const size_t total = 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes;
+    const size_t invf_bytes = sizeof(double2) * k * k;
+    const size_t total = 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes + invf_bytes;
     std::vector<unsigned char> host(total);
     ulonglong2 *tw = reinterpret_cast<ulonglong2 *>(host.data());
     ulonglong2 *itw = tw + n * k;
     ModConst *mods = reinterpret_cast<ModConst *>(itw + n * k);
     ulonglong2 *invmod = reinterpret_cast<ulonglong2 *>(mods + k);
     u64 *halfmod = reinterpret_cast<u64 *>(invmod + (size_t)k * k);
-    double2 *twf = reinterpret_cast<double2 *>(halfmod + (size_t)k * k);
+    double2 *twf = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(halfmod) + half_bytes);
     double2 *itwf = twf + n * k;
     ModConstF *modsf = reinterpret_cast<ModConstF *>(itwf + n * k);
+    double2 *invmodf = reinterpret_cast<double2 *>(modsf + k);
     static_assert(sizeof(double2) == sizeof(ulonglong2), "twiddle record size");
 
     for (int j = 0; j < k; ++j) {
@@ -255,12 +264,14 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         for (int j = 0; j < k; ++j) {
             if (l == j) {
                 invmod[(size_t)l * k + j] = make_ulonglong2(0, 0);
+                invmodf[(size_t)l * k + j] = make_double2(0.0, 0.0);
                 halfmod[(size_t)l * k + j] = 0;
                 continue;
             }
             const u64 q = primes[j];
             const u64 inv = h_invmod(primes[l] % q, q);
             invmod[(size_t)l * k + j] = make_ulonglong2(inv, h_shoup(inv, q));
+            invmodf[(size_t)l * k + j] = make_double2((double)inv, (double)inv / (double)q);  // used only if q < 2^41
             halfmod[(size_t)l * k + j] = (primes[l] >> 1) % q;
         }
 
@@ -268,12 +279,19 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
-    for (int s = 0; s < 2 && e == hipSuccess; ++s) {
+    for (int s = 0; s < hefx_context::MAX_STREAMS && e == hipSuccess; ++s) {
         e = hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[s], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
-    if (const char *ev = getenv("HEFX_STREAMS")) c->use_streams = atoi(ev) != 0;
+    if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
+    for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
+    if (const char *ev = getenv("HEFX_STREAMS")) {
+        const int v = atoi(ev);
+        c->use_streams = v != 0;
+        if (v >= 2 && v <= hefx_context::MAX_STREAMS) c->nstreams = v;
+    }
     if (e != hipSuccess) {
         if (c->d_tables) (void)hipFree(c->d_tables);
         delete c;
@@ -288,6 +306,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     c->T.twf = reinterpret_cast<const double2 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
     c->T.itwf = c->T.twf + n * k;
     c->T.modsf = reinterpret_cast<const ModConstF *>(base + 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
+    c->T.invmodf = reinterpret_cast<const double2 *>(base + 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes);
     c->T.k = k;
     c->T.logn = logn;
     *out = c;
@@ -301,11 +320,15 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     (void)hipDeviceSynchronize();
     for (auto &kv : c->perm) (void)hipFree(kv.second);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < hefx_context::MAX_STREAMS; ++s) {
         if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
         if (c->ev_join[s]) (void)hipEventDestroy(c->ev_join[s]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (int s = 0; s < KS_RING; ++s)
+        if (c->ring_ev[s]) (void)hipEventDestroy(c->ring_ev[s]);
+    if (c->h_items) (void)hipHostFree(c->h_items);
+    if (c->d_items) (void)hipFree(c->d_items);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -572,25 +595,31 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
     if (!relin && (!elts || !keys)) return fail(HEFX_ERR_INVALID, "missing Galois elements / keys");
     if (relin && !single_key) return fail(HEFX_ERR_INVALID, "missing relinearization key");
-    const int chunk = c->chunk;
     const size_t per = ks_words_per_item(c, L);
+    int chunk = c->chunk;
+    if (chunk <= 0) {  // auto: about 1 GiB of scratch per in-flight chunk, multiple of 8, at most KS_MAX_CHUNK
+        chunk = (int)(((size_t)1 << 30) / (per * sizeof(u64)));
+        chunk = chunk > KS_MAX_CHUNK ? KS_MAX_CHUNK : (chunk < 16 ? 16 : chunk & ~7);
+    }
     const int nchunks = (n + chunk - 1) / chunk;
     const bool two = nchunks > 1 && c->use_streams && !c->profiling;
     const size_t half_words = per * (size_t)(n < chunk ? n : chunk);
-    if (int rc = ensure_scratch(c, half_words * (two ? 2 : 1))) return rc;
+    const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
+    if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (two) {
         HIPCHK(hipEventRecord(c->ev_fork, user));
-        HIPCHK(hipStreamWaitEvent(c->streams[0], c->ev_fork, 0));
-        HIPCHK(hipStreamWaitEvent(c->streams[1], c->ev_fork, 0));
+        for (int s = 0; s < ns; ++s) HIPCHK(hipStreamWaitEvent(c->streams[s], c->ev_fork, 0));
     }
     const size_t N = c->n;
     int ci = 0;
     for (int base = 0; base < n; base += chunk, ++ci) {
         const int cnt = (n - base < chunk) ? n - base : chunk;
-        KsBatch B{};
+        const unsigned slot = c->ring_next++ % KS_RING;
+        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));  // its previous chunk has drained
+        KsItem *hb = c->h_items + (size_t)slot * KS_MAX_CHUNK, *db = c->d_items + (size_t)slot * KS_MAX_CHUNK;
         for (int i = 0; i < cnt; ++i) {
-            KsItem &it = B.it[i];
+            KsItem &it = hb[i];
             it.c_in = (const u64 *)ct_in[base + i];
             it.c_out = (u64 *)ct_out[base + i];
             if (!it.c_in || !it.c_out) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
@@ -607,7 +636,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             }
         }
         KsScratch S;
-        S.d = c->scratch + (two ? (size_t)(ci & 1) * half_words : 0);
+        S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
         S.x = S.d + (size_t)cnt * L * N;
         S.acc = S.x + (size_t)cnt * L * (L + 1) * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
@@ -622,10 +651,14 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             ev = &c->prof_events[c->prof_used];
             c->prof_used += KS_STAGES + 1;
         }
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, B, relin, S, two ? c->streams[ci & 1] : user, ev));
+        hipStream_t cs = two ? c->streams[ci % ns] : user;
+        HIPCHK(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, cs, ev));
+        HIPCHK(hipEventRecord(c->ring_ev[slot], cs));
+        c->ring_busy[slot] = true;
     }
     if (two) {
-        for (int s = 0; s < 2; ++s) {
+        for (int s = 0; s < ns; ++s) {
             HIPCHK(hipEventRecord(c->ev_join[s], c->streams[s]));
             HIPCHK(hipStreamWaitEvent(user, c->ev_join[s], 0));
         }

@@ -18,6 +18,7 @@ struct DevTables {
     const ModConstF *modsf;    // [k]     q == 0 marks a prime too wide for the FP64 policy
     const ulonglong2 *invmod;  // [k][k]  invmod[l*k+j] = {q_l^-1 mod q_j, Shoup companion} (l != j)
     const u64 *halfmod;        // [k][k]  (q_l >> 1) mod q_j
+    const double2 *invmodf;    // [k][k]  FP64 policy: {q_l^-1 mod q_j, RN(that / q_j)} for q_j < 2^41
     int k;
     int logn;
 };
@@ -42,10 +43,10 @@ struct KsItem {
     u64 *c_out;        // [2][L][N]
 };
 
-constexpr int KS_MAX_CHUNK = 64;
-struct KsBatch {
-    KsItem it[KS_MAX_CHUNK];
-};
+// Items of one chunk live in a device-side descriptor ring (filled through a pinned host mirror with one async
+// copy per chunk), so a chunk is not limited by the 4 KiB kernel-argument segment.
+constexpr int KS_MAX_CHUNK = 256;
+constexpr int KS_RING = 8;
 
 // Scratch layout for one chunk of key-switch items, in units of N words per item.
 struct KsScratch {
@@ -74,7 +75,7 @@ hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
 // ev: nullptr, or KS_STAGES+1 events recorded around the launches of one chunk (profiling)
 constexpr int KS_STAGES = 6;
-hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, hipStream_t s, hipEvent_t *ev);
 // out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
 hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,

@@ -44,6 +44,19 @@ __device__ static __forceinline__ void split_decode(int bid, int &p, int &h)
     h = (bid >> 3) & 1;
     p = ((bid >> 4) << 3) | (bid & 7);
 }
+// Grouped mapping for kernels in which `fan` rows read the SAME source row (a digit feeds L target moduli, a
+// mod-down remainder feeds L data primes): all 2*fan half-workgroups of a source get block ids that are equal
+// modulo 8, i.e. the same XCD under round-robin dispatch, and adjacent in dispatch order -- the source row is
+// fetched into that XCD's L2 once and the other 2*fan-1 reads hit it.  Speed hint only.
+__host__ __device__ static inline int group_grid(int groups, int fan) { return ((groups + 7) / 8) * 2 * fan * 8; }
+__device__ static __forceinline__ void group_decode(int bid, int fan, int &g, int &member, int &h)
+{
+    const int x = bid & 7, rest = bid >> 3;
+    const int slot = rest % (2 * fan), sg = rest / (2 * fan);
+    g = sg * 8 + x;
+    member = slot >> 1;
+    h = slot & 1;
+}
 // index of coefficient j in a row stored de-interleaved
 __device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j >> 1); }
 
@@ -51,12 +64,13 @@ __device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j
 // (0) preparation: x[b][i][i] = perm_g(c1[i]) (or c2[i] for relinearisation), p0[b][j] = perm_g(c0[j]).
 // Plain gather at full occupancy; two outputs (16 B store) per lane.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, KsBatch B, int L, int relin, KsScratch S)
+__global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+                                                         KsScratch S)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
     const int row = blockIdx.y, b = blockIdx.z;
-    const KsItem it = B.it[b];
+    const KsItem it = items[b];
     const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const u64 *__restrict__ src;
     u64 *__restrict__ dst;
@@ -112,20 +126,20 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_k
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
     extern __shared__ __align__(16) u64 lds[];
-    int p, h;
-    split_decode(blockIdx.x, p, h);
-    if (p >= rows) return;
+    int g, jj, h;
+    group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
+    if (g >= rows) return;
     const int t = threadIdx.x;
-    const int b = p / (L * L), rem = p % (L * L);
-    const int i = rem / L;
-    int jj = rem % L;
+    const int b = g / L, i = g % L;
     if (jj >= i) ++jj;  // skip the diagonal; jj == L is the special prime
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
     const u64 qi = T.mods[i].q;
     const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N;
     u64 v[16];
-    const bool reduce = qi > mc.q;
+    // [d_i]_m: the U64 policy needs it only when q_i > m; the FP64 policy takes any integer below 2^49 as input,
+    // so a digit of a prime < 2^41 needs no reduction at all (the transform is linear and ends canonical)
+    const bool reduce = T.modsf[m].q != 0.0 ? T.modsf[i].q == 0.0 : qi > mc.q;
     auto ld = [&](int r, u64 &x, u64 &y) {
         const int e = eo(C::idx_nat(t, r), SC::H);
         x = dd[e];
@@ -144,7 +158,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_k
 // ------------------------------------------------------------------------------------------------
 // (3) acc[b][c][jj] = sum_i x[b][i][jj] * key[i][c][m]  (128-bit lazy accumulation, one Barrett at the end)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, KsBatch B, int L, KsScratch S)
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, KsScratch S)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
@@ -152,7 +166,7 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, KsBatch B, int
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
-    const KsItem it = B.it[b];
+    const KsItem it = items[b];
     u64 a0xl = 0, a0xh = 0, a0yl = 0, a0yh = 0, a1xl = 0, a1xh = 0, a1yl = 0, a1yh = 0;
     for (int i = 0; i < L; ++i) {
         const ulonglong2 x =
@@ -201,34 +215,41 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_intt
 }
 
 // ------------------------------------------------------------------------------------------------
-// (5) out[b][c][j] = (acc[b][c][j] - NTT_j((u mod q_j) - (P/2 mod q_j))) * P^-1 + add-in, optionally * pt
+// (5) out[b][c][j] = (acc[b][c][j] - NTT_j((u mod q_j) - (P/2 mod q_j))) * P^-1 + add-in, optionally * pt.
+// The epilogue runs in the row's arithmetic policy directly on the unfinished transform values.
 // ------------------------------------------------------------------------------------------------
-template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_finish_kernel(DevTables T, KsBatch B, int L,
-                                                                                 int relin, int rows, KsScratch S)
+__device__ __forceinline__ u64 md_epilogue(ArithU64, u64 f, u64 acc, u64 sadd, u64 pt, bool has_pt,
+                                           const ArithU64::Ctx &cx, const DevTables &T, int sp, int j,
+                                           const ModConst &mc)
+{
+    return ArithU64::moddown(f, acc, sadd, pt, has_pt, cx, T.invmod[(size_t)sp * T.k + j], mc);
+}
+__device__ __forceinline__ u64 md_epilogue(ArithF64, double f, u64 acc, u64 sadd, u64 pt, bool has_pt,
+                                           const ArithF64::Ctx &cx, const DevTables &T, int sp, int j,
+                                           const ModConst &)
+{
+    return ArithF64::moddown(f, acc, sadd, pt, has_pt, cx, T.invmodf[(size_t)sp * T.k + j]);
+}
+
+template <int LOGN, class A>
+__device__ __forceinline__ void moddown_finish_body(const DevTables &T, const KsItem &it, int L, int relin,
+                                                    const KsScratch &S, u64 *lds,
+                                                    const typename A::TW *__restrict__ tw, const typename A::Ctx &cx,
+                                                    const ModConst &mc, int b, int c, int j, int t, int h)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
-    extern __shared__ __align__(16) u64 lds[];
-    int p, h;
-    split_decode(blockIdx.x, p, h);
-    if (p >= rows) return;
-    const int t = threadIdx.x;
-    const int b = p / (2 * L), c = (p / L) & 1, j = p % L;
     const int sp = T.k - 1;
-    const ModConst mc = T.mods[j];
     const u64 q = mc.q;
     const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
-    const ulonglong2 pinv = T.invmod[(size_t)sp * T.k + j];
-    const KsItem it = B.it[b];
     const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
-    u64 v[16];
     auto ld = [&](int r, u64 &x, u64 &y) {  // barrett64 is exact for any 64-bit input, also when P <= q
         const int e = eo(C::idx_nat(t, r), SC::H);
         x = submod(barrett64(ud[e], q, mc.r1), half_j, q);
         y = submod(barrett64(ud[e + SC::H / 2], q, mc.r1), half_j, q);
     };
-    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    typename A::V f[16];
+    split_fwd_raw<LOGN, A>(f, ld, lds, tw, cx, t, h);
     // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (0) left in S.p0.
     // The operand loads of a group of 4 coefficients are issued before any of its stores.
     const size_t off = (size_t)h * SC::H;
@@ -249,15 +270,31 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_fini
             pp[r] = pt ? pt[idx] : 0;
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = C::idx_out(t, 4 * hh + r);
-            u64 z = submod(a[r], v[4 * hh + r], q);
-            z = csub(shoup_lazy(z, pinv.x, pinv.y, q), q);
-            z = addmod(z, sadd[r], q);
-            if (pt) z = mulmod(z, pp[r], mc);
-            dst[idx] = z;
-        }
+        for (int r = 0; r < 4; ++r)
+            dst[C::idx_out(t, 4 * hh + r)] =
+                md_epilogue(A{}, f[4 * hh + r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
     }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_finish_kernel(DevTables T,
+                                                                                 const KsItem *__restrict__ items, int L,
+                                                                                 int relin, int rows, KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    int g, j, h;
+    group_decode(blockIdx.x, L, g, j, h);  // g = remainder polynomial (b, c); j = one of the L data primes
+    if (g >= rows) return;
+    const int t = threadIdx.x;
+    const int b = g >> 1, c = g & 1;
+    const ModConst mc = T.mods[j];
+    const ModConstF mf = T.modsf[j];
+    const NttTables nt = ntt_tables(T, j);
+    const KsItem it = items[b];
+    if (mf.q != 0.0)
+        moddown_finish_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, h);
+    else
+        moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
 }
 
 template <typename K>
@@ -268,7 +305,7 @@ static void set_lds(K kernel, size_t bytes)
 }
 
 template <int LOGN>
-static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
 {
     using SC = SplitCfg<LOGN>;
@@ -297,15 +334,15 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     HEFX_EV(1);
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
     HEFX_EV(2);
-    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(split_grid(n * L * L)), dim3(SC::T), lds, s, T, L,
-                       n * L * L, scr);
+    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds, s, T, L, n * L,
+                       scr);
     HEFX_EV(3);
     hipLaunchKernelGGL(ks_mac_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
     HEFX_EV(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
     HEFX_EV(5);
-    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(split_grid(n * 2 * L)), dim3(SC::T), lds, s, T, batch, L,
-                       rl, n * 2 * L, scr);
+    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch, L,
+                       rl, n * 2, scr);
     HEFX_EV(6);
 #undef HEFX_EV
     return hipGetLastError();
@@ -321,7 +358,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         default: return hipErrorInvalidValue; \
     }
 
-hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsBatch &batch, bool relin,
+hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
 {
 #define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, s, ev)

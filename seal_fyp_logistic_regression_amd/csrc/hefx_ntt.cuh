@@ -111,6 +111,16 @@ struct ArithU64 {
     __device__ static __forceinline__ void inv_pass_begin(V (&)[16], const Ctx &) {}
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return csub(csub(x, c.two_q), c.q); }
+    // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 4q):
+    // ((acc - f) * P^-1 + sadd) [* pt] mod q, canonical
+    __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
+                                                  const ulonglong2 &pinv, const ModConst &mc)
+    {
+        u64 z = acc + (c.two_q << 1) - f;                // < 5q
+        z = shoup_lazy(z, pinv.x, pinv.y, c.q) + sadd;   // < 3q
+        if (has_pt) return mulmod(z, pt, mc);            // product < 3q*q < q*2^64: Barrett128 gives [0,q)
+        return csub(csub(z, c.two_q), c.q);
+    }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return csub(x, c.q); }
 };
 
@@ -184,16 +194,75 @@ struct ArithF64 {
 #pragma unroll
         for (int e = 0; e < 16; ++e) v[e] = red(v[e], c);
     }
-    __device__ static __forceinline__ V from_u64(u64 x) { return (double)x; }  // exact: x < 2^53
+    // u64 <-> double for integers in [0, 2^52) by exponent splicing: one integer OR/AND on the high word plus one
+    // v_add_f64, instead of the v_cvt/v_ldexp/v_trunc/v_floor sequences of a generic conversion
+    __device__ static __forceinline__ V from_u64(u64 x)
+    {
+        return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
+    }
+    __device__ static __forceinline__ u64 to_u64(double r)
+    {
+        return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
+    }
     __device__ static __forceinline__ u64 canon(double x, const Ctx &c)
     {
         double r = red(x, c);
         r = r < 0.0 ? r + c.q : r;
-        return (u64)r;
+        return to_u64(r);
     }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return canon(x, c); }
+    // y*p mod q for a NON-constant p (no precomputed p/q): c = rint(RN(y*p) * RN(1/q)); same exactness argument
+    __device__ static __forceinline__ double mm_var(double y, double p, const Ctx &c)
+    {
+        const double h = y * p;
+        const double l = __builtin_fma(y, p, -h);
+        const double k = __builtin_rint(h * c.qinv);
+        const double s = __builtin_fma(-k, c.q, h);
+        return s + l;
+    }
+    __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
+                                                  const double2 &pinv)
+    {
+        double z = from_u64(acc) - f;  // exact: |f| < 2^45
+        z = mm(z, pinv.x, pinv.y, c.q) + from_u64(sadd);
+        if (has_pt) z = mm_var(z, from_u64(pt), c);
+        return canon(z, c);
+    }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
 };
+
+// ---- twiddle prefetch ---------------------------------------------------------------------------
+// A radix-16 pass needs 1+2+4+8 = 15 twiddle records per thread (slot (1<<u)-1+k for stage u, k < 2^u); the
+// remainder pass needs NG*(G-1) <= 14.  They are loaded into registers ONE PASS AHEAD -- right after the math of
+// the previous pass, i.e. before its LDS exchange and barrier -- so their L2 latency overlaps the exchange instead
+// of being exposed at every stage (measured: exposed twiddle latency was ~25 % of the kernel).
+template <int LOGN, class A>
+__device__ __forceinline__ void load_pass_tw(typename A::TW (&w)[15], const typename A::TW *__restrict__ tw, int p,
+                                             int t, int pre)
+{
+    const int LOGS = LOGN - 4 * (p + 1);
+    int b = t >> LOGS;
+    if (LOGS >= 6) b = __builtin_amdgcn_readfirstlane(b);  // wave-uniform -> scalar loads
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int k = 0; k < (1 << u); ++k) w[(1 << u) - 1 + k] = tw[(pre << (4 * p + u)) + (b << u) + k];
+}
+template <int LOGN, class A>
+__device__ __forceinline__ void load_rem_tw(typename A::TW (&w)[15], const typename A::TW *__restrict__ tw, int t,
+                                            int pre)
+{
+    using C = NttCfg<LOGN>;
+#pragma unroll
+    for (int c = 0; c < C::NG; ++c) {
+        const int g = t + C::T * c;
+#pragma unroll
+        for (int u = 0; u < C::R; ++u)
+#pragma unroll
+            for (int k = 0; k < (1 << u); ++k)
+                w[c * (C::G - 1) + (1 << u) - 1 + k] = tw[(pre << (4 * C::FP + u)) + (g << u) + k];
+    }
+}
 
 // v[r] holds coefficient idx_nat(t,r) on entry (U64: any value < 4q; F64: |v| <= ~2q) and the NTT value
 // idx_out(t,r) on exit, NOT yet canonical (apply A::fwd_finish).
@@ -205,28 +274,31 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
                                              int pre)
 {
     using C = NttCfg<LOGN>;
+    typename A::TW w[15];
+    load_pass_tw<LOGN, A>(w, tw, 0, t, pre);
 #pragma unroll
     for (int p = 0; p < C::FP; ++p) {
         const int LOGS = LOGN - 4 * (p + 1);
         const int S = 1 << LOGS;
-        int b = t >> LOGS;
+        const int b = t >> LOGS;
         const int base = b * (16 * S) + (t & (S - 1));
         if (p > 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
         }
-        if (LOGS >= 6) b = __builtin_amdgcn_readfirstlane(b);  // wave-uniform -> scalar twiddle loads
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int half = 8 >> u;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (e & half) continue;
-                const typename A::TW w = tw[(pre << (4 * p + u)) + (b << u) + (e >> (4 - u))];
-                A::ct(v[e], v[e | half], w, cx);
+                A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (4 - u))], cx);
             }
-            HEFX_STAGE_FENCE();
         }
+        if (p + 1 < C::FP)
+            load_pass_tw<LOGN, A>(w, tw, p + 1, t, pre);
+        else if (C::R > 0)
+            load_rem_tw<LOGN, A>(w, tw, t, pre);
         if (p + 1 < C::FP || C::R > 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) lds[C::phys(base + S * e)] = v[e];
@@ -245,15 +317,13 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
             const int half = C::G >> (u + 1);
 #pragma unroll
             for (int c = 0; c < C::NG; ++c) {
-                const int g = t + C::T * c;
 #pragma unroll
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
-                    const typename A::TW w = tw[(pre << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
-                    A::ct(v[c * C::G + e], v[c * C::G + (e | half)], w, cx);
+                    A::ct(v[c * C::G + e], v[c * C::G + (e | half)],
+                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx);
                 }
             }
-            HEFX_STAGE_FENCE();
         }
     }
 }
@@ -265,23 +335,24 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
 {
     using C = NttCfg<LOGN>;
+    typename A::TW w[15];
     if (C::R > 0) {
+        load_rem_tw<LOGN, A>(w, itw, t, 1);
         A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = C::R - 1; u >= 0; --u) {
             const int half = C::G >> (u + 1);
 #pragma unroll
             for (int c = 0; c < C::NG; ++c) {
-                const int g = t + C::T * c;
 #pragma unroll
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
-                    const typename A::TW w = itw[(1 << (4 * C::FP + u)) + (g << u) + (e >> (C::R - u))];
-                    A::gs(v[c * C::G + e], v[c * C::G + (e | half)], w, cx);
+                    A::gs(v[c * C::G + e], v[c * C::G + (e | half)],
+                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx);
                 }
             }
-            HEFX_STAGE_FENCE();
         }
+        load_pass_tw<LOGN, A>(w, itw, C::FP - 1, t, 1);  // next pass's twiddles travel during the exchange
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
             const int g = t + C::T * c;
@@ -289,19 +360,20 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
             for (int e = 0; e < C::G; ++e) lds[C::phys(g * C::G + e)] = v[c * C::G + e];
         }
         __syncthreads();
+    } else {
+        load_pass_tw<LOGN, A>(w, itw, C::FP - 1, t, 1);
     }
 #pragma unroll
     for (int p = C::FP - 1; p >= 0; --p) {
         const int LOGS = LOGN - 4 * (p + 1);
         const int S = 1 << LOGS;
-        int b = t >> LOGS;
+        const int b = t >> LOGS;
         const int base = b * (16 * S) + (t & (S - 1));
         if (p < C::FP - 1 || C::R > 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
         }
         A::inv_pass_begin(v, cx);
-        if (LOGS >= 6) b = __builtin_amdgcn_readfirstlane(b);
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
             const int half = 8 >> u;
@@ -312,13 +384,12 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
 #pragma unroll
                 for (int e = 0; e < 16; ++e) {
                     if (e & half) continue;
-                    const typename A::TW w = itw[(1 << (4 * p + u)) + (b << u) + (e >> (4 - u))];
-                    A::gs(v[e], v[e | half], w, cx);
+                    A::gs(v[e], v[e | half], w[(1 << u) - 1 + (e >> (4 - u))], cx);
                 }
             }
-            HEFX_STAGE_FENCE();
         }
         if (p > 0) {
+            load_pass_tw<LOGN, A>(w, itw, p - 1, t, 1);
 #pragma unroll
             for (int e = 0; e < 16; ++e) lds[C::phys(base + S * e)] = v[e];
             __syncthreads();
@@ -375,11 +446,10 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 // ld(r, x, y) must deliver the canonical coefficients idx_nat(t,r) and idx_nat(t,r)+N/2; on return
 // v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
 template <int LOGN, class A, class LD>
-__device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, u64 *lds,
-                                            const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                            int h)
+__device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, u64 *lds,
+                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                              int h)
 {
-    typename A::V f[16];
     const typename A::TW w1 = tw[1];
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
@@ -391,6 +461,15 @@ __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, u64 *lds
         HEFX_STAGE_FENCE();
     }
     ntt_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
+}
+
+template <int LOGN, class A, class LD>
+__device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, u64 *lds,
+                                            const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                            int h)
+{
+    typename A::V f[16];
+    split_fwd_raw<LOGN, A>(f, ld, lds, tw, cx, t, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = A::fwd_finish(f[r], cx);
 }
