@@ -127,10 +127,13 @@ struct hefx_context {
     hipEvent_t ring_ev[KS_RING] = {};
     bool ring_busy[KS_RING] = {};
     unsigned ring_next = 0;
-    // profiling session (hefx_profile_begin/end): per-chunk event sextets, serial on the caller's stream
+    // profiling session (hefx_profile_begin/end): one event per launch, serial on the caller's stream
     bool profiling = false;
     std::vector<hipEvent_t> prof_events;
-    size_t prof_used = 0;
+    std::vector<int> prof_stage;
+    KsProf prof{nullptr, nullptr, 0, 0};
+    size_t prof_chunks = 0;
+    int sub = 0;  // items per K2+MAC sub-chunk; 0 = auto (HEFX_SUB overrides)
 };
 
 static int ensure_scratch(hefx_context *c, size_t words)
@@ -287,6 +290,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
     for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
+    if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
     if (const char *ev = getenv("HEFX_STREAMS")) {
         const int v = atoi(ev);
         c->use_streams = v != 0;
@@ -579,9 +583,10 @@ static int get_perm(hefx_context *c, uint32_t elt, const uint32_t **out)
 // ---------------------------------------------------------------------------------------------
 static size_t ks_words_per_item(const hefx_context *c, int L)
 {
-    // d: L, x: L(L+1), acc: 2(L+1), u: 2, p0: L   (units of N words)
-    return (size_t)c->n * ((size_t)L + (size_t)L * (L + 1) + 2 * (size_t)(L + 1) + 2 + (size_t)L);
+    // d: L, xd: L, acc: 2(L+1), u: 2, p0: L   (units of N words); x is per sub-chunk, see ks_x_words
+    return (size_t)c->n * (3 * (size_t)L + 2 * (size_t)(L + 1) + 2);
 }
+static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t)c->n * sub * L * (L + 1); }
 
 // Chunks of a batch alternate between two internal streams (each with its own scratch half) so that the
 // small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
@@ -603,7 +608,12 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     }
     const int nchunks = (n + chunk - 1) / chunk;
     const bool two = nchunks > 1 && c->use_streams && !c->profiling;
-    const size_t half_words = per * (size_t)(n < chunk ? n : chunk);
+    int sub = c->sub;
+    // HEFX_SUB > 0 restricts the digit x modulus scratch to `sub` items at a time (K2 + MAC per sub-chunk).
+    // Measured neutral on MI355X (the scratch traffic is not what binds), so the default is one sub-chunk.
+    if (sub <= 0 || sub > chunk) sub = chunk;
+    const int cmax = n < chunk ? n : chunk;
+    const size_t half_words = per * (size_t)cmax + ks_x_words(c, L, sub < cmax ? sub : cmax);
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
@@ -637,23 +647,29 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
         KsScratch S;
         S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
-        S.x = S.d + (size_t)cnt * L * N;
-        S.acc = S.x + (size_t)cnt * L * (L + 1) * N;
+        S.xd = S.d + (size_t)cnt * L * N;
+        S.acc = S.xd + (size_t)cnt * L * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.p0 = S.u + (size_t)cnt * 2 * N;
-        hipEvent_t *ev = nullptr;
+        S.x = S.p0 + (size_t)cnt * L * N;
+        KsProf *prof = nullptr;
         if (c->profiling) {
-            while (c->prof_events.size() < c->prof_used + (KS_STAGES + 1)) {
+            const size_t need = (size_t)c->prof.used + 8 + 2 * ((size_t)cnt / sub + 1);
+            while (c->prof_events.size() < need) {
                 hipEvent_t e;
                 HIPCHK(hipEventCreate(&e));
                 c->prof_events.push_back(e);
             }
-            ev = &c->prof_events[c->prof_used];
-            c->prof_used += KS_STAGES + 1;
+            c->prof_stage.resize(c->prof_events.size());
+            c->prof.ev = c->prof_events.data();
+            c->prof.stage = c->prof_stage.data();
+            c->prof.cap = (int)c->prof_events.size();
+            prof = &c->prof;
+            ++c->prof_chunks;
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
         HIPCHK(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, cs, ev));
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, sub, cs, prof));
         HIPCHK(hipEventRecord(c->ring_ev[slot], cs));
         c->ring_busy[slot] = true;
     }
@@ -764,7 +780,8 @@ extern "C" int hefx_profile_begin(hefx_context *c)
     CTXCHK(c);
     HIPCHK(hipDeviceSynchronize());
     c->profiling = true;
-    c->prof_used = 0;
+    c->prof.used = 0;
+    c->prof_chunks = 0;
     return HEFX_OK;
 }
 extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *launches)
@@ -773,15 +790,16 @@ extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *lau
     if (!stage_ms || !launches) return fail(HEFX_ERR_INVALID, "null out pointer");
     HIPCHK(hipDeviceSynchronize());
     for (int k = 0; k < KS_STAGES; ++k) stage_ms[k] = 0.0;
-    *launches = c->prof_used / (KS_STAGES + 1);
-    for (size_t base = 0; base + KS_STAGES + 1 <= c->prof_used; base += KS_STAGES + 1)
-        for (int k = 0; k < KS_STAGES; ++k) {
-            float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, c->prof_events[base + k], c->prof_events[base + k + 1]));
-            stage_ms[k] += ms;
-        }
+    *launches = c->prof_chunks;
+    for (int i = 0; i + 1 < c->prof.used; ++i) {
+        const int st = c->prof_stage[i];
+        if (st < 0 || st >= KS_STAGES) continue;
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, c->prof_events[i], c->prof_events[i + 1]));
+        stage_ms[st] += ms;
+    }
     c->profiling = false;
-    c->prof_used = 0;
+    c->prof.used = 0;
     return HEFX_OK;
 }
 extern "C" const char *hefx_profile_stage_name(int k)

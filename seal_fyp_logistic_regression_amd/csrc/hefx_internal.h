@@ -51,7 +51,9 @@ constexpr int KS_RING = 8;
 // Scratch layout for one chunk of key-switch items, in units of N words per item.
 struct KsScratch {
     u64 *d;    // [chunk][L][N]        digits in coefficient form
-    u64 *x;    // [chunk][L][L+1][N]   digit i transformed to modulus slot jj (jj==L: special prime)
+    u64 *xd;   // [chunk][L][N]        digit i in NTT form mod its own prime (Galois-permuted c1 / c2)
+    u64 *x;    // [sub][L][L+1][N]     digit i transformed to modulus slot jj != i (jj==L: special prime); only a
+               //                      SUB-chunk of items at a time, so this largest scratch array stays cache-resident
     u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
     u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
     u64 *p0;   // [chunk][L][N]        perm_g(c0) of a rotation (added in by the mod-down epilogue)
@@ -73,10 +75,15 @@ hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int 
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
-// ev: nullptr, or KS_STAGES+1 events recorded around the launches of one chunk (profiling)
+// profiling: an event is recorded before every launch (tagged with its stage) and one after the last
 constexpr int KS_STAGES = 6;
+struct KsProf {
+    hipEvent_t *ev;  // capacity `cap`
+    int *stage;      // stage[i] = launch kind that follows ev[i]; -1 terminates a chunk
+    int cap, used;
+};
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
-                                  const KsScratch &scr, hipStream_t s, hipEvent_t *ev);
+                                  const KsScratch &scr, int sub, hipStream_t s, KsProf *prof);
 // out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
 hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
                               int mod_first, hipStream_t s);

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, const KsIt
     u64 *__restrict__ dst;
     if (row < L) {
         src = it.c_in + ((size_t)(relin ? 2 * L : L) + row) * n;
-        dst = S.x + (((size_t)b * L + row) * (L + 1) + row) * n;
+        dst = S.xd + ((size_t)b * L + row) * n;
     } else {
         src = it.c_in + (size_t)(row - L) * n;
         dst = S.p0 + ((size_t)b * L + (row - L)) * n;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_intt_digits_
     const int t = threadIdx.x;
     const int b = p / L, i = p % L;
     const ulonglong2 *__restrict__ src =
-        reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)b * L + i) * (L + 1) + i) * SC::N);
+        reinterpret_cast<const ulonglong2 *>(S.xd + ((size_t)b * L + i) * SC::N);
     u64 v[16];
     split_inv<LOGN>(v, src, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
@@ -121,7 +121,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_intt_digits_
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
-                                                                             KsScratch S)
+                                                                             int item0, KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -130,7 +130,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_k
     group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
     if (g >= rows) return;
     const int t = threadIdx.x;
-    const int b = g / L, i = g % L;
+    const int bl = g / L, i = g % L;  // bl: item index inside the sub-chunk
+    const int b = item0 + bl;
     if (jj >= i) ++jj;  // skip the diagonal; jj == L is the special prime
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_k
         }
     };
     split_fwd<LOGN>(v, ld, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
-    u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
+    u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
 }
@@ -158,19 +159,20 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_k
 // ------------------------------------------------------------------------------------------------
 // (3) acc[b][c][jj] = sum_i x[b][i][jj] * key[i][c][m]  (128-bit lazy accumulation, one Barrett at the end)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, KsScratch S)
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int item0,
+                                                     KsScratch S)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
-    const int jj = blockIdx.y, b = blockIdx.z;
+    const int jj = blockIdx.y, bl = blockIdx.z, b = item0 + bl;
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
     const KsItem it = items[b];
     u64 a0xl = 0, a0xh = 0, a0yl = 0, a0yh = 0, a1xl = 0, a1xh = 0, a1yl = 0, a1yh = 0;
     for (int i = 0; i < L; ++i) {
-        const ulonglong2 x =
-            reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)b * L + i) * (L + 1) + jj) * n)[w];
+        const u64 *xrow = i == jj ? S.xd + ((size_t)b * L + i) * n : S.x + (((size_t)bl * L + i) * (L + 1) + jj) * n;
+        const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(xrow)[w];
         const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
         const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
         const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
@@ -306,7 +308,7 @@ static void set_lds(K kernel, size_t bytes)
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                           const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
+                                           const KsScratch &scr, int sub, hipStream_t s, KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -325,26 +327,33 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         attr_done = true;
     }
     const int rl = relin ? 1 : 0;
-    // optional profiling: ev[0..6] bracket the six launches (hefx_profile_*), recorded on the same stream
-#define HEFX_EV(i) \
-    if (ev) (void)hipEventRecord(ev[i], s)
-    HEFX_EV(0);
+    // optional profiling (hefx_profile_*): an event before every launch, tagged with its stage
+    auto mark = [&](int stage) {
+        if (prof && prof->used < prof->cap) {
+            (void)hipEventRecord(prof->ev[prof->used], s);
+            prof->stage[prof->used++] = stage;
+        }
+    };
+    mark(0);
     hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, relin ? L : 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
                        scr);
-    HEFX_EV(1);
+    mark(1);
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
-    HEFX_EV(2);
-    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds, s, T, L, n * L,
-                       scr);
-    HEFX_EV(3);
-    hipLaunchKernelGGL(ks_mac_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
-    HEFX_EV(4);
+    // digit x modulus products only ever exist for `sub` items: K2 writes them, the MAC consumes them right away
+    for (int item0 = 0; item0 < n; item0 += sub) {
+        const int m = n - item0 < sub ? n - item0 : sub;
+        mark(2);
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds, s, T, L, m * L,
+                           item0, scr);
+        mark(3);
+        hipLaunchKernelGGL(ks_mac_kernel, dim3(SC::N / 2 / 256, L + 1, m), dim3(256), 0, s, T, batch, L, item0, scr);
+    }
+    mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
-    HEFX_EV(5);
+    mark(5);
     hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch, L,
                        rl, n * 2, scr);
-    HEFX_EV(6);
-#undef HEFX_EV
+    mark(-1);
     return hipGetLastError();
 }
 
@@ -359,9 +368,9 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     }
 
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                  const KsScratch &scr, hipStream_t s, hipEvent_t *ev)
+                                  const KsScratch &scr, int sub, hipStream_t s, KsProf *prof)
 {
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, s, ev)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }
