@@ -188,3 +188,138 @@ def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, di
     for k in range(dimension - 1):
         ev.add_inplace(ctAB, ev.multiply(ctAk[k], ctBk[k]))          # :123-129
     return ctAB
+
+
+# ---- polynomial evaluation and encrypted logistic regression (logistic_regression_ckks.cpp) -------------------
+def tree_cipher(ev: Evaluator, encoder: CKKSEncoder, encryptor, ctx: Ciphertext, degree: int, scale: float,
+                coeffs: Sequence[float], relin_keys: KSwitchKeys) -> Ciphertext:
+    """Tree_cipher, /root/reference/logistic_regression_ckks.cpp:55-137 (= polynomial.cpp:233-359)."""
+    plain = [None if coeffs[i] == 0 else encoder.encode(float(coeffs[i]), scale) for i in range(degree + 1)]  # :71-83
+    powers = compute_all_powers(ev, ctx, degree, relin_keys)                                              # :93
+    result = encryptor.encrypt(plain[0])                                                                   # :102
+    for i in range(1, degree + 1):                                                                         # :110
+        ev.mod_switch_to_inplace(plain[i], powers[i].parms_id())                                          # :113
+        temp = ev.multiply_plain(powers[i], plain[i])                                                      # :116
+        ev.rescale_to_next_inplace(temp)                                                                   # :119
+        ev.mod_switch_to_inplace(result, temp.parms_id())                                                  # :122
+        result.scale = 2.0 ** int(np.log2(result.scale))                                                   # :126-127
+        temp.scale = 2.0 ** int(np.log2(result.scale))
+        ev.add_inplace(result, temp)                                                                       # :130
+    return result
+
+
+def horner_cipher(ev: Evaluator, encoder: CKKSEncoder, encryptor, ctx: Ciphertext, degree: int,
+                  coeffs: Sequence[float], scale: float, relin_keys: KSwitchKeys) -> Ciphertext:
+    """Horner_cipher, /root/reference/logistic_regression_ckks.cpp:139-205."""
+    plain = [encoder.encode(float(coeffs[i]), scale) for i in range(degree + 1)]                          # :147-157
+    temp = encryptor.encrypt(plain[degree])                                                                # :162
+    ctx = ctx.copy()
+    for i in range(degree - 1, -1, -1):                                                                    # :168
+        if ctx.parms_id() > temp.parms_id():                                                               # :172-182
+            ev.mod_switch_to_inplace(ctx, temp.parms_id())
+        elif ctx.parms_id() < temp.parms_id():
+            ev.mod_switch_to_inplace(temp, ctx.parms_id())
+        ev.multiply_inplace(temp, ctx)                                                                     # :184
+        ev.relinearize_inplace(temp, relin_keys)                                                           # :187
+        ev.rescale_to_next_inplace(temp)                                                                   # :189
+        ev.mod_switch_to_inplace(plain[i], temp.parms_id())                                                # :192
+        temp.scale = 2.0 ** 40                                                                             # :195 (the reference hard-codes 2^40)
+        ev.add_plain_inplace(temp, plain[i])                                                               # :198
+    return temp
+
+
+def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext], size: int,
+                            relin_keys: KSwitchKeys, gal_keys: KSwitchKeys) -> List[Ciphertext]:
+    """len(As) independent cipher_dot_product calls (helper.h:416-502) advanced in lockstep: the rotate-by-1 chain
+    inside one dot product is sequential, but the chains of different rows are independent, so every step is ONE
+    batched key-switch launch over all rows.  Same calls in the same order per row -> same bits as the loop at
+    logistic_regression_ckks.cpp:217-220."""
+    be, n = ev.be, len(As)
+    mults = [ev.multiply(a, b) for a, b in zip(As, Bs)]
+    L = mults[0].parms_id()
+    if hasattr(be, "engine"):
+        outs = be.engine.relinearize_batch(L, [m.data for m in mults], relin_keys.key(0))
+        for m, o in zip(mults, outs):
+            m._set(o, 2, L, m.scale)
+    else:
+        for m in mults:
+            ev.relinearize_inplace(m, relin_keys)
+    for m in mults:
+        ev.rescale_to_next_inplace(m)
+    L = mults[0].parms_id()
+
+    def rotate_all(cts, step):
+        plan = ev.rotation_plan(step, gal_keys)
+        data = [c.data for c in cts]
+        for elt in plan:
+            data = be.apply_galois_batch(L, data, [elt] * n, [gal_keys.key(elt)] * n)
+        return [Ciphertext()._set(d, 2, L, c.scale) for d, c in zip(data, cts)]
+
+    dups = [ev.add(m, z) for m, z in zip(mults, rotate_all(mults, -size))]
+    for _ in range(1, size):
+        dups = rotate_all(dups, 1)
+        for m, d in zip(mults, dups):
+            ev.add_inplace(m, d)
+    for m in mults:
+        m.scale = 2.0 ** int(np.log2(m.scale))
+    return mults
+
+
+SIGMOID_COEFFS = {3: [0.5, 1.20069, 0.00001, -0.81562],
+                  5: [0.5, 1.53048, 0.00001, -2.3533056, 0.00001, 1.3511295],
+                  7: [0.5, 1.73496, 0.00001, -4.19407, 0.00001, 5.43402, 0.00001, -2.50739]}
+
+
+def predict_cipher_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, features: Sequence[Ciphertext],
+                           weights: Ciphertext, num_weights: int, scale: float, gal_keys: KSwitchKeys,
+                           relin_keys: KSwitchKeys, degree: int = 3) -> Ciphertext:
+    """predict_cipher_weights, /root/reference/logistic_regression_ckks.cpp:208-266."""
+    num_rows = len(features)
+    results = cipher_dot_product_many(ev, features, [weights] * num_rows, num_weights, relin_keys, gal_keys)  # :220
+    for i in range(num_rows):
+        mask = np.zeros(num_rows)
+        mask[i] = 1
+        mask_pt = encoder.encode(mask, scale)                                                              # :222-225
+        ev.mod_switch_to_next_inplace(mask_pt)                                                             # :227
+        ev.multiply_plain_inplace(results[i], mask_pt)                                                     # :229
+    lin = ev.add_many(results)                                                                             # :233
+    ev.relinearize_inplace(lin, relin_keys)                                                                # :237 (no-op)
+    ev.rescale_to_next_inplace(lin)                                                                        # :239
+    lin.scale = 2.0 ** int(np.log2(lin.scale))                                                             # :242
+    coeffs = SIGMOID_COEFFS[degree]                                                                        # :245-262
+    return horner_cipher(ev, encoder, encryptor, lin, len(coeffs) - 1, coeffs, scale, relin_keys)         # :264
+
+
+def update_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, features: Sequence[Ciphertext],
+                   features_T: Sequence[Ciphertext], labels: Ciphertext, weights: Ciphertext, learning_rate: float,
+                   gal_keys: KSwitchKeys, relin_keys: KSwitchKeys, scale: float, degree: int = 3) -> Ciphertext:
+    """update_weights, /root/reference/logistic_regression_ckks.cpp:269-345.  As committed, the reference cannot
+    get past :336 with its own parameters: the gradient is at the last level (one 60-bit prime left) and the
+    multiply_plain pushes the scale to 2^80 -> SEAL throws invalid_argument("scale out of bounds").  The mirror
+    keeps that behaviour (ValueError from Evaluator._check_scale)."""
+    num_obs, num_weights = len(features), len(features_T)
+    pred = predict_cipher_weights(ev, encoder, encryptor, features, weights, num_weights, scale, gal_keys,
+                                  relin_keys, degree)                                                       # :282
+    labels = labels.copy()
+    ev.mod_switch_to_inplace(labels, pred.parms_id())                                                      # :286
+    pred_labels = ev.sub(pred, labels)                                                                     # :288
+    fT = [f.copy() for f in features_T]
+    for f in fT:
+        ev.mod_switch_to_inplace(f, pred_labels.parms_id())                                                # :298
+    grads = cipher_dot_product_many(ev, fT, [pred_labels] * num_weights, num_obs, relin_keys, gal_keys)    # :299
+    for i in range(num_weights):
+        mask = np.zeros(num_weights)
+        mask[i] = 1
+        mask_pt = encoder.encode(mask, scale)                                                              # :302-305
+        ev.mod_switch_to_inplace(mask_pt, grads[i].parms_id())                                             # :308
+        ev.multiply_plain_inplace(grads[i], mask_pt)                                                       # :310
+    gradient = ev.add_many(grads)                                                                          # :316
+    ev.relinearize_inplace(gradient, relin_keys)                                                           # :319
+    ev.rescale_to_next_inplace(gradient)                                                                   # :321
+    gradient.scale = 2.0 ** int(np.log2(gradient.scale))                                                   # :324
+    n_pt = encoder.encode(float(learning_rate) / num_obs, scale)                                           # :330-331
+    ev.mod_switch_to_inplace(n_pt, gradient.parms_id())                                                    # :333
+    ev.multiply_plain_inplace(gradient, n_pt)                                                              # :336  <- SEAL throws here
+    new_weights = ev.sub(gradient, weights)                                                                # :341
+    ev.negate_inplace(new_weights)                                                                         # :342
+    return new_weights

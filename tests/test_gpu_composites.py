@@ -180,3 +180,59 @@ def test_reference_matrix_multiplication_driver_unchanged():
     nums = [float(x) for x in re.findall(r"-?\d+\.?\d*(?:e-?\d+)?", tail)][:16]
     want = (np.arange(1, 17).reshape(4, 4) @ np.arange(1, 17).reshape(4, 4)).reshape(-1)
     assert np.allclose(nums, want, atol=0.05), nums  # the driver adds 1e-8 to every diagonal entry (:239)
+
+
+def test_matrix_encode_decode_and_ciphermatrix_plainvector_bit_exact():
+    """rows a3-a5: Linear_Transform_CipherMatrix_PlainVector, C_Matrix_Encode, C_Matrix_Decode"""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    n = 3
+    rows = [np.arange(n) + 10.0 * i for i in range(n)]
+
+    def run(e):
+        scale = 2.0 ** 30
+        cts = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in rows]
+        packed = alg.c_matrix_encode(e["ev"], cts, e["gk"])
+        back = alg.c_matrix_decode(e["ev"], e["encoder"], packed, n, scale, e["gk"])
+        pv = alg.linear_transform_ciphermatrix_plainvector(
+            e["ev"], [e["encoder"].encode(r[::-1].copy(), scale) for r in rows], cts)
+        return packed, back, pv
+
+    r = both(4096, [50, 30, 30, 50], run)
+    (eg, (pg, bg, vg)), (eo, (po, bo, vo)) = r["gpu"], r["oracle"]
+    assert (bits(eg, pg) == bits(eo, po)).all() and (bits(eg, vg) == bits(eo, vo)).all()
+    for i in range(n):
+        assert (bits(eg, bg[i]) == bits(eo, bo[i])).all()
+        assert np.allclose(decode(eg, bg[i], n), rows[i], atol=1e-2)
+    assert np.allclose(decode(eg, vg, n), sum(r * r[::-1] for r in rows), atol=1e-2)
+
+
+def test_logistic_regression_step_bit_exact():
+    """rows a9-a11 on the reference's LR chain {60,40x7,60}: Tree/Horner sigmoid, predict_cipher_weights (dot products
+    of all rows advanced in lockstep as batched key switches), update_weights raising where SEAL raises (:336)."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    X = np.array([[0.5, -1.0, 0.2, 0.1], [1.5, 0.25, -0.3, 0.4], [-0.75, 0.5, 0.6, -0.2]])
+    w = np.array([0.3, -0.6, 0.5, 0.25])
+    y = np.array([1.0, 0.0, 1.0])
+    c = alg.SIGMOID_COEFFS[3]
+
+    def run(e):
+        scale = 2.0 ** 40
+        feats = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in X]
+        featsT = [e["enc"].encrypt(e["encoder"].encode(col, scale)) for col in X.T]
+        cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+        cy = e["enc"].encrypt(e["encoder"].encode(y, scale))
+        x = e["enc"].encrypt(e["encoder"].encode([0.8, -0.3], scale))
+        t = alg.tree_cipher(e["ev"], e["encoder"], e["enc"], x, 3, scale, c, e["rk"])
+        pred = alg.predict_cipher_weights(e["ev"], e["encoder"], e["enc"], feats, cw, 4, scale, e["gk"], e["rk"])
+        with pytest.raises(ValueError, match="scale out of bounds"):
+            alg.update_weights(e["ev"], e["encoder"], e["enc"], feats, featsT, cy, cw, 0.1, e["gk"], e["rk"], scale)
+        return t, pred
+
+    r = both(4096, [60, 40, 40, 40, 40, 40, 40, 40, 60], run, seed=4)
+    (eg, (tg, pg)), (eo, (to, po)) = r["gpu"], r["oracle"]
+    assert (bits(eg, tg) == bits(eo, to)).all()
+    assert pg.parms_id() == po.parms_id() and (bits(eg, pg) == bits(eo, po)).all()
+    z = X @ w
+    assert np.allclose(decode(eg, pg, 3), c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3, atol=5e-3)
+    xs = np.array([0.8, -0.3])
+    assert np.allclose(decode(eg, tg, 2), c[0] + c[1] * xs + c[2] * xs ** 2 + c[3] * xs ** 3, atol=1e-3)

@@ -153,3 +153,31 @@ def test_matrix_encode_decode(env):
     back = alg.c_matrix_decode(ev, e["encoder"], packed, n, scale, e["gk"])
     for i in range(n):
         assert np.allclose(dec(e, back[i], n).real, rows[i], atol=1e-2)
+
+
+def test_polynomial_and_logistic_regression_step():
+    """rows a9-a11: Tree/Horner sigmoid, predict_cipher_weights, and update_weights stopping where SEAL stops."""
+    e = make(2048, [60, 40, 40, 40, 40, 40, 40, 40, 60], seed=4)  # the reference's LR chain (logistic_regression_ckks.cpp:420)
+    ev, scale = e["ev"], 2.0 ** 40
+    x = np.array([0.8, -0.3, 0.1])
+    cx = e["enc"].encrypt(e["encoder"].encode(x, scale))
+    c = alg.SIGMOID_COEFFS[3]
+    want = c[0] + c[1] * x + c[2] * x ** 2 + c[3] * x ** 3
+    t = alg.tree_cipher(ev, e["encoder"], e["enc"], cx, 3, scale, c, e["rk"])
+    assert np.allclose(dec(e, t, 3).real, want, atol=1e-3)
+    h = alg.horner_cipher(ev, e["encoder"], e["enc"], cx, 3, c, scale, e["rk"])
+    assert np.allclose(dec(e, h, 3).real, want, atol=1e-3)
+    # 3 observations x 4 features.  (The reference's masking at :222-229 reads slot i of dot product i, which
+    # holds the full sum only for i < num_weights -- reproduced, not fixed -- so the check uses rows <= weights.)
+    X = np.array([[0.5, -1.0, 0.2, 0.1], [1.5, 0.25, -0.3, 0.4], [-0.75, 0.5, 0.6, -0.2]])
+    w = np.array([0.3, -0.6, 0.5, 0.25])
+    y = np.array([1.0, 0.0, 1.0])
+    feats = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in X]
+    featsT = [e["enc"].encrypt(e["encoder"].encode(col, scale)) for col in X.T]
+    cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+    cy = e["enc"].encrypt(e["encoder"].encode(y, scale))
+    pred = alg.predict_cipher_weights(ev, e["encoder"], e["enc"], feats, cw, 4, scale, e["gk"], e["rk"])
+    z = X @ w
+    assert np.allclose(dec(e, pred, 3).real, c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3, atol=5e-3)
+    with pytest.raises(ValueError, match="scale out of bounds"):  # SURVEY fact 8: reference stops at :336
+        alg.update_weights(ev, e["encoder"], e["enc"], feats, featsT, cy, cw, 0.1, e["gk"], e["rk"], scale)
