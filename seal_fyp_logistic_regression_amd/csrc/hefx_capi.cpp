@@ -134,6 +134,10 @@ struct hefx_context {
     KsProf prof{nullptr, nullptr, 0, 0};
     size_t prof_chunks = 0;
     int sub = 0;  // items per K2+MAC sub-chunk; 0 = auto (HEFX_SUB overrides)
+    // fused digit-NTT + MAC kernel (HEFX_FUSED=1).  Off by default: bit-exact, removes the x scratch entirely, but at
+    // N=16384 its 1024-thread workgroup spills (64 VGPRs of accumulators + transform state under the 128 cap) and
+    // measured 1.75x slower than the two-kernel path on MI355X (profiles/README.md).
+    bool fused = false;
 };
 
 static int ensure_scratch(hefx_context *c, size_t words)
@@ -291,6 +295,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
     for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
+    if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
     if (const char *ev = getenv("HEFX_STREAMS")) {
         const int v = atoi(ev);
         c->use_streams = v != 0;
@@ -612,8 +617,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // HEFX_SUB > 0 restricts the digit x modulus scratch to `sub` items at a time (K2 + MAC per sub-chunk).
     // Measured neutral on MI355X (the scratch traffic is not what binds), so the default is one sub-chunk.
     if (sub <= 0 || sub > chunk) sub = chunk;
+    // fused digit-NTT + MAC kernel (no x scratch at all) when enabled and N <= 16384 (longer rows do not fit the
+    // 8-coefficient-per-thread workgroup); the launcher takes sub < 0 as "fused"
+    const bool fused = c->fused && c->logn <= 14;
     const int cmax = n < chunk ? n : chunk;
-    const size_t half_words = per * (size_t)cmax + ks_x_words(c, L, sub < cmax ? sub : cmax);
+    const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax));
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
@@ -669,7 +677,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
         HIPCHK(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, sub, cs, prof));
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, cs, prof));
         HIPCHK(hipEventRecord(c->ring_ev[slot], cs));
         c->ring_busy[slot] = true;
     }
@@ -806,6 +814,7 @@ extern "C" const char *hefx_profile_stage_name(int k)
 {
     static const char *names[KS_STAGES] = {"ks_prepare_kernel",      "ks_intt_digits_kernel",
                                            "ks_ntt_digits_kernel",   "ks_mac_kernel",
-                                           "ks_moddown_intt_kernel", "ks_moddown_finish_kernel"};
+                                           "ks_moddown_intt_kernel", "ks_moddown_finish_kernel",
+                                           "ks_ntt_mac_kernel"};
     return (k >= 0 && k < KS_STAGES) ? names[k] : "";
 }

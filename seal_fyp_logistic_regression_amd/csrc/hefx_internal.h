@@ -76,7 +76,7 @@ hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &
                            u64 *out, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
 // profiling: an event is recorded before every launch (tagged with its stage) and one after the last
-constexpr int KS_STAGES = 6;
+constexpr int KS_STAGES = 7;
 struct KsProf {
     hipEvent_t *ev;  // capacity `cap`
     int *stage;      // stage[i] = launch kind that follows ev[i]; -1 terminates a chunk

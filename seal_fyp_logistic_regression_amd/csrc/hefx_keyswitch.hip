@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include "hefx_internal.h"
 #include "hefx_ntt.cuh"
+#include "hefx_ntt8.cuh"
 
 // minimum waves per SIMD the NTT workgroups are register-allocated for (second __launch_bounds__ argument)
 #ifndef HEFX_WAVES
@@ -191,6 +192,95 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
 }
 
 // ------------------------------------------------------------------------------------------------
+// (2+3 fused) acc[b][c][jj] = sum_i NTT_m([d[b][i]]_m) * key[i][c][m] for one half h of one target modulus jj:
+// the workgroup walks the L digits, transforms each one (8 coefficients per thread, hefx_ntt8.cuh) and multiplies
+// the result straight into two 128-bit accumulators per coefficient that live in registers for the whole loop.
+// The digit x modulus products ("x", L(L+1) rows per item -- the largest scratch array of the unfused path, written
+// by (2) and re-read by (3) at HBM speed) are never stored.  All 2(L+1) workgroups of an item share an XCD, so the
+// L digit rows they all read are served by that XCD's L2.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+struct FusedCfg {
+    using C = Ntt8Cfg<LOGN - 1>;
+    static constexpr int N = 1 << LOGN;
+    static constexpr int H = N / 2;
+    static constexpr int T = C::T;  // N/16 threads
+    static constexpr size_t LDS_BYTES = sizeof(u64) * C::LDS_WORDS;
+};
+
+template <int LOGN>
+__global__ __launch_bounds__(FusedCfg<LOGN>::T, (FusedCfg<LOGN>::T >= 1024 ? 4 : 2)) void ks_ntt_mac_kernel(
+    DevTables T, const KsItem *__restrict__ items, int L, int groups, KsScratch S)
+{
+    using FC = FusedCfg<LOGN>;
+    using C = typename FC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int b, jj, h;
+    group_decode(blockIdx.x, L + 1, b, jj, h);  // b = item; jj = target modulus slot (L = special prime)
+    if (b >= groups) return;
+    const int t = threadIdx.x;
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const ModConstF mf = T.modsf[m];
+    const NttTables nt = ntt_tables(T, m);
+    const KsItem it = items[b];
+    const size_t off = (size_t)h * FC::H;
+    u64 a0l[8], a0h[8], a1l[8], a1h[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) a0l[r] = a0h[r] = a1l[r] = a1h[r] = 0;
+    for (int i = 0; i < L; ++i) {
+        u64 xv[8];
+        if (i == jj) {  // the digit is already in NTT form modulo its own prime
+            const u64 *__restrict__ xr = S.xd + ((size_t)b * L + i) * FC::N + off;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) xv[r] = xr[C::idx_out(t, r)];
+        } else {
+            const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * FC::N;
+            const bool reduce = mf.q != 0.0 ? T.modsf[i].q == 0.0 : T.mods[i].q > mc.q;
+            auto ld = [&](int r, u64 &x, u64 &y) {
+                const int e = eo(C::idx_nat(t, r), FC::H);
+                x = dd[e];
+                y = dd[e + FC::H / 2];
+                if (reduce) {
+                    x = barrett64(x, mc.q, mc.r1);
+                    y = barrett64(y, mc.q, mc.r1);
+                }
+            };
+            if (mf.q != 0.0)
+                split8_fwd_a<LOGN, ArithF64>(xv, ld, lds, nt.twf, ArithF64::make(mf), t, h);
+            else
+                split8_fwd_a<LOGN, ArithU64>(xv, ld, lds, nt.tw, ArithU64::make(mc), t, h);
+            __syncthreads();  // the next digit's first exchange reuses the LDS this one just read
+        }
+        const u64 *__restrict__ k0 = it.key + ((size_t)i * 2 * T.k + m) * FC::N + off;
+        const u64 *__restrict__ k1 = k0 + (size_t)T.k * FC::N;
+        HEFX_STAGE_FENCE();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {  // two batches of four: the key words are only live for one batch
+            u64 kv0[4], kv1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                kv0[r] = k0[C::idx_out(t, 4 * g + r)];
+                kv1[r] = k1[C::idx_out(t, 4 * g + r)];
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                mac128(a0l[4 * g + r], a0h[4 * g + r], xv[4 * g + r], kv0[r]);
+                mac128(a1l[4 * g + r], a1h[4 * g + r], xv[4 * g + r], kv1[r]);
+            }
+            HEFX_STAGE_FENCE();
+        }
+    }
+    u64 *__restrict__ o0 = S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * FC::N + off;
+    u64 *__restrict__ o1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * FC::N + off;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        o0[C::idx_out(t, r)] = barrett128(a0l[r], a0h[r], mc);
+        o1[C::idx_out(t, r)] = barrett128(a1l[r], a1h[r], mc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // (4) u[b][c] (EO) = (INTT_P(acc[b][c][P]) + floor(P/2)) mod P
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
@@ -339,6 +429,18 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                        scr);
     mark(1);
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
+    if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
+        if constexpr (LOGN <= 14) {
+            static bool fattr = false;
+            if (!fattr) {
+                set_lds(ks_ntt_mac_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
+                fattr = true;
+            }
+            mark(6);
+            hipLaunchKernelGGL((ks_ntt_mac_kernel<LOGN>), dim3(group_grid(n, L + 1)), dim3(FusedCfg<LOGN>::T),
+                               FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, n, scr);
+        }
+    } else
     // digit x modulus products only ever exist for `sub` items: K2 writes them, the MAC consumes them right away
     for (int item0 = 0; item0 < n; item0 += sub) {
         const int m = n - item0 < sub ? n - item0 : sub;

@@ -218,3 +218,32 @@ def test_invalid_arguments_raise(c2):
         e.apply_galois(4, a, 3, key)  # level above top data level
     with pytest.raises(ValueError):
         e.rescale_to_next(1, 2, a)
+
+
+def test_alternative_launch_paths_bit_exact(c3):
+    """The optional paths must give the same bits as the default one: fused digit-NTT+MAC kernel (HEFX_FUSED=1),
+    integer-only arithmetic policy (HEFX_NO_FP64=1), serial chunks (HEFX_STREAMS=0), small chunks + sub-chunks."""
+    import subprocess, sys, os, json
+    from oracle import oracle as O
+    o, e, primes = c3
+    L, n = 5, 9
+    key = _rand_key(o, 77)
+    cts = [o.uniform(L, 2, 900 + i) for i in range(n)]
+    pts = [o.uniform(L, 1, 950 + i)[0] for i in range(n)]
+    want = [o.rotate_mulplain(cts[i], 3, key, pts[i]) for i in range(n)]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np; sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "from seal_fyp_logistic_regression_amd import Engine\n"
+        "primes=%r; o=O.Oracle(16384, primes); e=Engine(16384, primes); L=5; n=9\n"
+        "key=o.uniform(o.k, 2*(o.k-1), 77).reshape(o.k-1,2,o.k,o.N); dk=e.to_device(key)\n"
+        "cts=[o.uniform(L,2,900+i) for i in range(n)]; pts=[o.uniform(L,1,950+i)[0] for i in range(n)]\n"
+        "outs=e.rotate_multiply_plain_batch(L,[e.to_device(c) for c in cts],[3]*n,[dk]*n,[e.to_device(p) for p in pts])\n"
+        "ok=all((outs[i].download()==o.rotate_mulplain(cts[i],3,key,pts[i])).all() for i in range(n))\n"
+        "print('PARITY', ok)\n") % (root, primes)
+    for env in ({"HEFX_FUSED": "1"}, {"HEFX_NO_FP64": "1"}, {"HEFX_STREAMS": "0"}, {"HEFX_CHUNK": "4", "HEFX_SUB": "2"},
+                {"HEFX_FUSED": "1", "HEFX_NO_FP64": "1", "HEFX_CHUNK": "5"}):
+        r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
+                           timeout=600)
+        assert "PARITY True" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
