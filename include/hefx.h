@@ -135,6 +135,15 @@ int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint6
  *      partial ciphertexts (<= `addends` canonical addends per word), bring every word back to [0,q_j). */
 int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, int addends, void *stream);
 
+/* ---- CKKSEncoder::encode(vector<double>, scale, plain) on the GPU (call sites
+ *      matrix_mult_benchmark.cpp:291-323, logistic_regression_ckks.cpp:222-225,302-305, helper.h:333-343):
+ *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->
+ *      `count` contiguous NTT-form plaintexts of L rows at d_out.  Canonical embedding with slot i <-> root
+ *      zeta^(3^i), coefficients rounded half away from zero like std::round.  Floating point: matches any other
+ *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit.  N <= 16384. */
+int hefx_ckks_encode(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
+                     double scale, uint64_t *d_out, void *stream);
+
 /* ---- measurement helpers (no reference counterpart; the reference times with std::chrono around the L3
  *      call, e.g. linear_transformation2.cpp:363-365).  HIP events recorded on the stream the kernels use. */
 int hefx_event_create(hefx_context *ctx, void **event);

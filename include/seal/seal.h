@@ -793,6 +793,7 @@ public:
         const std::size_t n = ctx_->n();
         if (values.size() > n / 2) throw std::invalid_argument("values has invalid size");
         const int L = rows_checked(id, scale);
+        if (encode_on_device(values, L, id, scale, dest)) return;
         std::vector<std::complex<double>> A(n, 0.0);
         for (std::size_t i = 0; i < values.size(); ++i) {
             A[r1_[i]] = values[i];
@@ -885,6 +886,34 @@ private:
         if (scale <= 0 || (int)std::log2(scale) >= ctx_->get_context_data(id)->total_coeff_modulus_bit_count())
             throw std::invalid_argument("scale out of bounds");
         return L;
+    }
+    // hefx_ckks_encode (FFT + rounding + RNS + NTT on the GPU) when N is in the kernel's range, every coefficient
+    // provably fits 62 bits (|p_k| <= max|v|) and zero-ness follows from norms (Parseval: max|p_k| >=
+    // sqrt(2 sum v^2)/N); otherwise the host FFT below.  SEAL_SHIM_HOST_ENCODE=1 forces the host path.
+    bool encode_on_device(const std::vector<double> &values, int L, const parms_id_type &id, double scale,
+                          Plaintext &dest) const
+    {
+        const std::size_t n = ctx_->n();
+        if (n < 1024 || n > 16384 || values.empty()) return false;
+        static const bool host_only = [] {
+            const char *s = std::getenv("SEAL_SHIM_HOST_ENCODE");
+            return s && *s && *s != '0';
+        }();
+        if (host_only) return false;
+        double mx = 0, ss = 0;
+        for (double v : values) {
+            if (!std::isfinite(v)) return false;
+            mx = std::max(mx, std::fabs(v));
+            ss += v * v;
+        }
+        if (mx * scale >= 4611686018427387904.0) return false;
+        const bool zero = mx * scale < 0.499, nonzero = std::sqrt(2.0 * ss) / (double)n * scale > 0.501;
+        if (!zero && !nonzero) return false;
+        auto &e = ctx_->engine();
+        dest.buf = shim::new_buf(e, (std::size_t)L * n);
+        shim::check(hefx_ckks_encode(e->ctx, L, values.data(), nullptr, (int)values.size(), 1, scale, dest.buf->p, nullptr));
+        finish(dest, L, id, scale, zero);
+        return true;
     }
     void finish(Plaintext &dest, int L, const parms_id_type &id, double scale, bool zero) const
     {

@@ -7,8 +7,8 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libhefx.so")
-SOURCES = ["hefx_kernels.hip", "hefx_keyswitch.hip", "hefx_capi.cpp"]
-DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "../../include/hefx.h"]
+SOURCES = ["hefx_kernels.hip", "hefx_keyswitch.hip", "hefx_encode.hip", "hefx_capi.cpp"]
+DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cuh", "../../include/hefx.h"]
 
 
 def hipcc() -> str:

@@ -4,6 +4,7 @@
 // compute entry point dispatches HIP kernels from hefx_kernels.hip or fails.
 #include "../../include/hefx.h"
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <mutex>
@@ -122,6 +123,11 @@ struct hefx_context {
     hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {};
     int nstreams = 2;
     bool use_streams = true;
+    // CKKS encode: tables built on first use, value staging buffer
+    void *d_enc_tables = nullptr;
+    EncodeTables E{};
+    double *d_vals = nullptr;
+    size_t vals_cap = 0;
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
     hipEvent_t ring_ev[KS_RING] = {};
@@ -341,6 +347,8 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
+    if (c->d_enc_tables) (void)hipFree(c->d_enc_tables);
+    if (c->d_vals) (void)hipFree(c->d_vals);
     delete c;
 }
 
@@ -817,4 +825,71 @@ extern "C" const char *hefx_profile_stage_name(int k)
                                            "ks_moddown_intt_kernel", "ks_moddown_finish_kernel",
                                            "ks_ntt_mac_kernel"};
     return (k >= 0 && k < KS_STAGES) ? names[k] : "";
+}
+
+// ---------------------------------------------------------------------------------------------
+// CKKS encode on the GPU
+// ---------------------------------------------------------------------------------------------
+static int ensure_encode_tables(hefx_context *c)
+{
+    if (c->d_enc_tables) return HEFX_OK;
+    const size_t n = c->n, half = n / 2;
+    const size_t slot_b = sizeof(int) * half, w_b = sizeof(double2) * (n / 4), pre_b = sizeof(double2) * half,
+                 post_b = sizeof(double2) * n;
+    const size_t slot_pad = (slot_b + 15) & ~(size_t)15;
+    std::vector<unsigned char> host(slot_pad + w_b + pre_b + post_b);
+    int *slot = reinterpret_cast<int *>(host.data());
+    double2 *w = reinterpret_cast<double2 *>(host.data() + slot_pad);
+    double2 *pre = w + n / 4;
+    double2 *post = pre + half;
+    for (size_t r = 0; r < half; ++r) slot[r] = -1;
+    u64 pos = 1;
+    for (size_t i = 0; i < half; ++i) {
+        const size_t r1 = (size_t)((pos - 1) >> 1);
+        if (r1 < half)
+            slot[r1] = (int)(i << 1);
+        else
+            slot[n - 1 - r1] = (int)((i << 1) | 1);
+        pos = (pos * 3) & (2 * n - 1);
+    }
+    const double pi = 3.14159265358979323846264338327950288;
+    for (size_t m = 0; m < n / 4; ++m) w[m] = make_double2(cos(-2.0 * pi * (double)m / (double)half), sin(-2.0 * pi * (double)m / (double)half));
+    for (size_t r = 0; r < half; ++r) pre[r] = make_double2(cos(-2.0 * pi * (double)r / (double)n), sin(-2.0 * pi * (double)r / (double)n));
+    for (size_t k = 0; k < n; ++k) post[k] = make_double2(cos(-pi * (double)k / (double)n), sin(-pi * (double)k / (double)n));
+    HIPCHK(hipMalloc(&c->d_enc_tables, host.size()));
+    HIPCHK(hipMemcpy(c->d_enc_tables, host.data(), host.size(), hipMemcpyHostToDevice));
+    unsigned char *b = static_cast<unsigned char *>(c->d_enc_tables);
+    c->E.slot = reinterpret_cast<const int *>(b);
+    c->E.wfft = reinterpret_cast<const double2 *>(b + slot_pad);
+    c->E.pre = c->E.wfft + n / 4;
+    c->E.post = c->E.pre + half;
+    return HEFX_OK;
+}
+
+extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, const double *h_im, int nvalues,
+                                int count, double scale, uint64_t *d_out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (c->logn < 10 || c->logn > 14) return fail(HEFX_ERR_UNSUPPORTED, "GPU encode is built for poly_degree in [1024, 16384]");
+    if (!h_re || !d_out || count < 1 || nvalues < 1 || (size_t)nvalues > c->n / 2)
+        return fail(HEFX_ERR_INVALID, "values has invalid size");
+    if (!(scale > 0)) return fail(HEFX_ERR_INVALID, "scale out of bounds");
+    if (int rc = ensure_encode_tables(c)) return rc;
+    const size_t nv = (size_t)nvalues * count, need = nv * (h_im ? 2 : 1);
+    if (c->vals_cap < need) {
+        if (c->d_vals) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(c->d_vals));
+        }
+        HIPCHK(hipMalloc((void **)&c->d_vals, need * sizeof(double)));
+        c->vals_cap = need;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(c->d_vals, h_re, nv * sizeof(double), hipMemcpyHostToDevice, s));
+    if (h_im) HIPCHK(hipMemcpyAsync(c->d_vals + nv, h_im, nv * sizeof(double), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // the host arrays may be transient
+    HIPCHK(launch_encode(c->T, c->E, c->d_vals, h_im ? c->d_vals + nv : nullptr, nvalues, count, scale, L, (u64 *)d_out, s));
+    HIPCHK(launch_ntt(c->T, false, (u64 *)d_out, count, L, 0, s));
+    return HEFX_OK;
 }

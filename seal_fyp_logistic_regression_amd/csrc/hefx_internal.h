@@ -87,6 +87,15 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 // out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
 hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
                               int mod_first, hipStream_t s);
+// CKKS encode (hefx_encode.hip)
+struct EncodeTables {
+    const int *slot;      // [N/2]  r -> (i << 1) | conj
+    const double2 *wfft;  // [N/4]  exp(-2 pi i m / (N/2))
+    const double2 *pre;   // [N/2]  exp(-2 pi i r / N)
+    const double2 *post;  // [N]    exp(-pi i k / N)
+};
+hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double *re, const double *im, int nvalues,
+                         int count, double scale, int L, u64 *out, hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

@@ -15,7 +15,7 @@ from . import capi
 class DeviceArray:
     """A uint64 device buffer owned by an Engine (hefx_malloc/hefx_free)."""
 
-    __slots__ = ("engine", "ptr", "shape", "_owned")
+    __slots__ = ("engine", "ptr", "shape", "_owned", "_parent")
 
     def __init__(self, engine: "Engine", shape, ptr: Optional[int] = None):
         self.engine = engine
@@ -53,8 +53,9 @@ class DeviceArray:
         return out
 
     def view(self, offset_words: int, shape) -> "DeviceArray":
-        """Non-owning window into this buffer (keeps the parent alive through .engine only)."""
+        """Non-owning window into this buffer; holds a reference to the parent so the memory outlives it."""
         v = DeviceArray(self.engine, shape, ptr=self.ptr + 8 * int(offset_words))
+        v._parent = self
         return v
 
     def free(self):
@@ -228,6 +229,18 @@ class Engine:
     def reduce_canonical(self, L, size, buf, addends=8, stream=None):
         capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
         return buf
+
+    # ---- CKKS encode on the GPU
+    def ckks_encode(self, L, values, scale, out=None, stream=None):
+        """values: [count][nvalues] (or [nvalues]) real or complex -> [count][L][N] NTT-form plaintexts"""
+        v = np.atleast_2d(np.asarray(values))
+        count, nvalues = v.shape
+        re = np.ascontiguousarray(v.real, dtype=np.float64)
+        im = np.ascontiguousarray(v.imag, dtype=np.float64) if np.iscomplexobj(v) else None
+        out = out if out is not None else DeviceArray(self, (count, L, self.N))
+        capi.check(capi.lib().hefx_ckks_encode(self._h, L, re.ctypes.data, im.ctypes.data if im is not None else None,
+                                               nvalues, count, float(scale), out.ptr, stream))
+        return out
 
     # ---- measurement
     def event(self):

@@ -164,6 +164,12 @@ class GpuBackend:
     def reduce_canonical(self, L, size, h, addends):
         return self.engine.reduce_canonical(L, size, h, addends)
 
+    def ckks_encode(self, L, values, scale):
+        """[count][nvalues] slot values -> [count][L][N] NTT-form plaintexts, or None if N is outside the kernel's range"""
+        if not 1024 <= self.N <= 16384:
+            return None
+        return self.engine.ckks_encode(L, values, scale)
+
 
 # ----------------------------------------------------------------------------------------------
 # SEAL-shaped objects
@@ -457,10 +463,14 @@ class Decryptor:
 
 
 class CKKSEncoder:
-    """Canonical embedding with slot i <-> root zeta^(3^i) (App. A.12); FFT on the host, NTT on the backend."""
+    """Canonical embedding with slot i <-> root zeta^(3^i) (App. A.12).  encode runs on the GPU
+    (hefx_ckks_encode: FFT + rounding + RNS + NTT in two launches) when the backend offers it; decode, scalars,
+    coefficients wider than 62 bits and N = 32768 use the host FFT + the backend NTT.  device_encode=False forces
+    the host FFT (bit-identical across backends -- what the evaluator parity tests use)."""
 
-    def __init__(self, context: SEALContext):
+    def __init__(self, context: SEALContext, device_encode: bool = True):
         self.ctx = context
+        self.device_encode = bool(device_encode)
         N = context.N
         pos = np.empty(N // 2, dtype=np.int64)
         p = 1
@@ -499,9 +509,15 @@ class CKKSEncoder:
                 rows[j, :] = c % ctx.primes[j]
             out.data, out.is_zero = be.from_host(rows), c == 0
         else:
-            v = np.asarray(values, dtype=np.complex128)
+            v = np.asarray(values)
             if v.size > N // 2:
                 raise ValueError("values has invalid size")
+            dev = self._encode_device(v.reshape(1, -1), scale, L) if v.size else None
+            if dev is not None:
+                out.data, out.is_zero = dev[0].view(0, (L, N)), dev[1][0]
+                out._parms_id, out._scale = L, float(scale)
+                return out
+            v = v.astype(np.complex128)
             A = np.zeros(N, dtype=np.complex128)
             A[self._r1[: v.size]] = v
             A[self._r2[: v.size]] = np.conj(v)
@@ -514,6 +530,45 @@ class CKKSEncoder:
         if math.log2(scale) >= ContextData(ctx, L).total_coeff_modulus_bit_count():
             raise ValueError("scale out of bounds")
         return out
+
+    def _encode_device(self, v2d: np.ndarray, scale: float, L: int):
+        """GPU encode (hefx_ckks_encode) when the backend has it and every coefficient provably fits 62 bits and
+        zero-ness is decidable from norms; returns (slab [count][L][N], is_zero[count]) or None -> host path."""
+        be, N = self.ctx.backend, self.ctx.N
+        enc = getattr(be, "ckks_encode", None) if self.device_encode else None
+        if enc is None or not (scale > 0) or math.log2(scale) >= ContextData(self.ctx, L).total_coeff_modulus_bit_count():
+            return None
+        mag = np.abs(v2d)
+        if not np.all(np.isfinite(mag)) or float(mag.max(initial=0.0)) * scale >= 2.0 ** 62:
+            return None  # |p_k| <= max|v|: wide coefficients take the exact big-int host path
+        # Parseval: sum p_k^2 = (2/N) sum |v_i|^2, so max|p_k| >= sqrt(2 sum|v|^2)/N; and max|p_k| <= max|v|
+        hi = mag.max(axis=1) * scale
+        lo = np.sqrt(2.0 * (mag.astype(np.float64) ** 2).sum(axis=1)) / N * scale
+        zero, nonzero = hi < 0.499, lo > 0.501
+        if not np.all(zero | nonzero):
+            return None
+        slab = enc(L, v2d, scale)
+        if slab is None:
+            return None
+        return slab, [bool(z) for z in zero]
+
+    def encode_many(self, vectors, scale: float, parms_id: Optional[int] = None) -> List[Plaintext]:
+        """Encodes equally long vectors in one launch (the d diagonals of Linear_Transform_Plain,
+        matrix_mult_benchmark.cpp:291-323; the one-hot masks of logistic_regression_ckks.cpp:222-225)."""
+        ctx, N = self.ctx, self.ctx.N
+        L = parms_id if parms_id is not None else ctx.first_parms_id()
+        vs = [np.asarray(v) for v in vectors]
+        if vs and all(v.ndim == 1 and v.size == vs[0].size and 0 < v.size <= N // 2 for v in vs):
+            dev = self._encode_device(np.stack(vs), scale, L)
+            if dev is not None:
+                outs = []
+                for i in range(len(vs)):
+                    pt = Plaintext()
+                    pt.data, pt.is_zero = dev[0].view(i * L * N, (L, N)), dev[1][i]
+                    pt._parms_id, pt._scale = L, float(scale)
+                    outs.append(pt)
+                return outs
+        return [self.encode(v, scale, None, L) for v in vs]
 
     def decode(self, plain: Plaintext) -> np.ndarray:
         ctx, be, N, L = self.ctx, self.ctx.backend, self.ctx.N, plain.parms_id()

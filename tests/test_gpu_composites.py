@@ -17,7 +17,7 @@ def make(N, bits, backend_kind, seed=1, galois_steps=None):
     ctx = S.SEALContext.Create(parms, backend=backend)
     kg = S.KeyGenerator(ctx, seed)
     return dict(ctx=ctx, kg=kg, enc=S.Encryptor(ctx, kg.public_key(), seed + 1), dec=S.Decryptor(ctx, kg.secret_key()),
-                encoder=S.CKKSEncoder(ctx), ev=S.Evaluator(ctx), rk=kg.relin_keys(), gk=kg.galois_keys(galois_steps))
+                encoder=S.CKKSEncoder(ctx, device_encode=False), ev=S.Evaluator(ctx), rk=kg.relin_keys(), gk=kg.galois_keys(galois_steps))
 
 
 def bits(e, ct):
