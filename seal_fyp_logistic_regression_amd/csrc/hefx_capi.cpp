@@ -215,18 +215,18 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     const size_t half_bytes = (sizeof(u64) * k * k + 15) & ~(size_t)15;  // padded: 16-byte records follow
     const size_t modsf_bytes = sizeof(ModConstF) * k;
     const size_t invf_bytes = sizeof(double2) * k * k;
-    const size_t total = 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes + invf_bytes;
+    const size_t twf_bytes = sizeof(double) * n * k;  // FP64 policy: 8-byte twiddles (the quotient estimate is h * 1/q)
+    const size_t total = 2 * tw_bytes + 2 * twf_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes + invf_bytes;
     std::vector<unsigned char> host(total);
     ulonglong2 *tw = reinterpret_cast<ulonglong2 *>(host.data());
     ulonglong2 *itw = tw + n * k;
     ModConst *mods = reinterpret_cast<ModConst *>(itw + n * k);
     ulonglong2 *invmod = reinterpret_cast<ulonglong2 *>(mods + k);
     u64 *halfmod = reinterpret_cast<u64 *>(invmod + (size_t)k * k);
-    double2 *twf = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(halfmod) + half_bytes);
-    double2 *itwf = twf + n * k;
+    double *twf = reinterpret_cast<double *>(reinterpret_cast<unsigned char *>(halfmod) + half_bytes);
+    double *itwf = twf + n * k;
     ModConstF *modsf = reinterpret_cast<ModConstF *>(itwf + n * k);
     double2 *invmodf = reinterpret_cast<double2 *>(modsf + k);
-    static_assert(sizeof(double2) == sizeof(ulonglong2), "twiddle record size");
 
     for (int j = 0; j < k; ++j) {
         const u64 q = primes[j];
@@ -267,9 +267,8 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
             f.ilw = (double)m.ilw;
             f.ilw_r = (double)m.ilw / qd;
             for (size_t i = 0; i < n; ++i) {
-                const double w = (double)tw[(size_t)j * n + i].x, iw = (double)itw[(size_t)j * n + i].x;
-                twf[(size_t)j * n + i] = make_double2(w, w / qd);
-                itwf[(size_t)j * n + i] = make_double2(iw, iw / qd);
+                twf[(size_t)j * n + i] = (double)tw[(size_t)j * n + i].x;
+                itwf[(size_t)j * n + i] = (double)itw[(size_t)j * n + i].x;
             }
         }
     }
@@ -318,10 +317,11 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     c->T.mods = reinterpret_cast<const ModConst *>(base + 2 * tw_bytes);
     c->T.invmod = reinterpret_cast<const ulonglong2 *>(base + 2 * tw_bytes + mods_bytes);
     c->T.halfmod = reinterpret_cast<const u64 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes);
-    c->T.twf = reinterpret_cast<const double2 *>(base + 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
+    c->T.twf = reinterpret_cast<const double *>(base + 2 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
     c->T.itwf = c->T.twf + n * k;
-    c->T.modsf = reinterpret_cast<const ModConstF *>(base + 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes);
-    c->T.invmodf = reinterpret_cast<const double2 *>(base + 4 * tw_bytes + mods_bytes + inv_bytes + half_bytes + modsf_bytes);
+    const size_t f_off = 2 * tw_bytes + 2 * twf_bytes + mods_bytes + inv_bytes + half_bytes;
+    c->T.modsf = reinterpret_cast<const ModConstF *>(base + f_off);
+    c->T.invmodf = reinterpret_cast<const double2 *>(base + f_off + modsf_bytes);
     c->T.k = k;
     c->T.logn = logn;
     *out = c;

@@ -12,8 +12,8 @@ namespace hefx {
 struct DevTables {
     const ulonglong2 *tw;      // [k][N]  forward twiddles {w, floor(w*2^64/q)}, w[bitrev(i)] = psi^i
     const ulonglong2 *itw;     // [k][N]  inverse twiddles, itw[idx] = tw[idx]^-1
-    const double2 *twf;        // [k][N]  FP64-policy forward twiddles {w, RN(w/q)} (primes < 2^41 only)
-    const double2 *itwf;       // [k][N]  FP64-policy inverse twiddles
+    const double *twf;         // [k][N]  FP64-policy forward twiddles (primes < 2^41 only), 8 bytes each
+    const double *itwf;        // [k][N]  FP64-policy inverse twiddles
     const ModConst *mods;      // [k]
     const ModConstF *modsf;    // [k]     q == 0 marks a prime too wide for the FP64 policy
     const ulonglong2 *invmod;  // [k][k]  invmod[l*k+j] = {q_l^-1 mod q_j, Shoup companion} (l != j)

@@ -31,7 +31,7 @@ struct ModConstF {
 // Twiddle tables of one modulus (integer and FP64 policies).
 struct NttTables {
     const ulonglong2 *tw, *itw;  // [N] of this modulus
-    const double2 *twf, *itwf;   // [N] of this modulus (FP64 policy)
+    const double *twf, *itwf;    // [N] of this modulus (FP64 policy)
 };
 
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }

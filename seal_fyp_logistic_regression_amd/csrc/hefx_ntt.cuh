@@ -17,7 +17,8 @@
 //             wave and SIMD) per butterfly, ~105 cycles.
 //   ArithF64  primes < 2^41 (SEAL's 30..40-bit data primes): coefficients are kept as exact integers in
 //             doubles and x*w mod q is computed EXACTLY with FMA: h = x*w, l = fma(x,w,-h) (exact product),
-//             c = rint(x * (w/q)), t = fma(-c,q,h) + l, |t| < 0.52q; 6 fp64 instructions (~32 cycles measured),
+//             c = rint(h * (1/q)), t = fma(-c,q,h) + l, |t| < 0.52q; 6 fp64 instructions (~32 cycles measured),
+//             8-byte twiddles (no per-twiddle quotient),
 //             no range corrections in the forward transform (growth 0.52q per stage), one re-centering per
 //             radix-16 pass in the inverse.  Exactness argument in DESIGN.md ("FP64 modmul").
 #pragma once
@@ -129,10 +130,10 @@ struct ArithU64 {
 // ------------------------------------------------------------------------------------------------
 struct ArithF64 {
     typedef double V;
-    typedef double2 TW;  // {w, RN(w/q)}
+    typedef double TW;  // w only: the quotient estimate is rint(RN(y*w) * RN(1/q)), no per-twiddle w/q needed
     struct Ctx {
         double q, qinv;
-        double ninv, ninv_r, ilw, ilw_r;
+        double ninv, ilw;
     };
     __device__ static __forceinline__ Ctx make(const ModConstF &mf)
     {
@@ -140,18 +141,18 @@ struct ArithF64 {
         c.q = mf.q;
         c.qinv = mf.qinv;
         c.ninv = mf.ninv;
-        c.ninv_r = mf.ninv_r;
         c.ilw = mf.ilw;
-        c.ilw_r = mf.ilw_r;
         return c;
     }
-    // y*w mod q, exact, result in (-0.52q, 0.52q); y any integer with |y| < 2^49, 0 <= w < q < 2^41
-    __device__ static __forceinline__ double mm(double y, double w, double wr, double q)
+    // y*w mod q, exact, result in (-0.52q, 0.52q); y any integer with |y| < 2^45, w integer with |w| < 2^41:
+    // h + l = y*w exactly; k = rint(h/q) up to 3*2^-53 relative error of the argument (< 0.02 absolute); h - k*q is an
+    // integer below 2^41 in magnitude, hence exact in the FMA; adding l is exact for the same reason.
+    __device__ static __forceinline__ double mm(double y, double w, const Ctx &c)
     {
         const double h = y * w;
         const double l = __builtin_fma(y, w, -h);
-        const double c = __builtin_rint(y * wr);
-        const double s = __builtin_fma(-c, q, h);
+        const double k = __builtin_rint(h * c.qinv);
+        const double s = __builtin_fma(-k, c.q, h);
         return s + l;
     }
     // re-centre: x - q*rint(x/q), exact, result in [-0.5q, 0.5q]
@@ -161,32 +162,32 @@ struct ArithF64 {
     }
     __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
     {
-        const double t = mm(y, w.x, w.y, c.q);
+        const double t = mm(y, w, c);
         const double a = x;
         x = a + t;
         y = a - t;
     }
     __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
     {
-        const double t = mm(y, w.x, w.y, c.q);
+        const double t = mm(y, w, c);
         return h ? x - t : x + t;
     }
     __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
     {
         const double s = x + y, d = x - y;
         x = s;
-        y = mm(d, w.x, w.y, c.q);
+        y = mm(d, w, c);
     }
     __device__ static __forceinline__ void gs_last(V &x, V &y, const Ctx &c)
     {
         const double s = x + y, d = x - y;
-        x = mm(s, c.ninv, c.ninv_r, c.q);
-        y = mm(d, c.ilw, c.ilw_r, c.q);
+        x = mm(s, c.ninv, c);
+        y = mm(d, c.ilw, c);
     }
     __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
     __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
     {
-        return mm(a0 - a1, w.x, w.y, c.q);
+        return mm(a0 - a1, w, c);
     }
     // sums double per inverse stage: re-centre the 16 registers once per radix-16 pass (|x| <= 16*0.52q after it)
     __device__ static __forceinline__ void inv_pass_begin(V (&v)[16], const Ctx &c)
@@ -211,21 +212,12 @@ struct ArithF64 {
         return to_u64(r);
     }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return canon(x, c); }
-    // y*p mod q for a NON-constant p (no precomputed p/q): c = rint(RN(y*p) * RN(1/q)); same exactness argument
-    __device__ static __forceinline__ double mm_var(double y, double p, const Ctx &c)
-    {
-        const double h = y * p;
-        const double l = __builtin_fma(y, p, -h);
-        const double k = __builtin_rint(h * c.qinv);
-        const double s = __builtin_fma(-k, c.q, h);
-        return s + l;
-    }
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const double2 &pinv)
     {
         double z = from_u64(acc) - f;  // exact: |f| < 2^45
-        z = mm(z, pinv.x, pinv.y, c.q) + from_u64(sadd);
-        if (has_pt) z = mm_var(z, from_u64(pt), c);
+        z = mm(z, pinv.x, c) + from_u64(sadd);
+        if (has_pt) z = mm(z, from_u64(pt), c);
         return canon(z, c);
     }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
