@@ -128,9 +128,29 @@ int main()
         encoder.encode(vector<double>{1, 5, 9, 13}, scale, pv);
         Ciphertext cv;
         encryptor.encrypt(pv, cv);
-        auto r = dec(lt_plain(cv, diags, gk, params));
+        Ciphertext ref = lt_plain(cv, diags, gk, params);
+        auto r = dec(ref);
         CHECK(fabs(r[0] - 90) < 1e-3 && fabs(r[1] - 202) < 1e-3 && fabs(r[2] - 314) < 1e-3 && fabs(r[3] - 426) < 1e-3,
               "Linear_Transform_Plain 4x4 known answer [90,202,314,426]");
+        // the one-call engine path (extension) must give the same ciphertext bits as the op-by-op body
+        Ciphertext fast;
+        evaluator.hefx_linear_transform_plain(cv, diags, gk, fast);
+        CHECK(fast.scale() == ref.scale() && fast.parms_id() == ref.parms_id() &&
+                  shim::download(fast.buf) == shim::download(ref.buf),
+              "hefx_linear_transform_plain == op-by-op Linear_Transform_Plain, bit for bit");
+        // d = 13: NAF chains of different lengths, shared prefixes
+        vector<Plaintext> d13(13);
+        for (int l = 0; l < 13; l++) {
+            vector<double> dv(13);
+            for (int i = 0; i < 13; i++) dv[i] = 0.01 * (i + 1) * (l + 2);
+            encoder.encode(dv, scale, d13[l]);
+        }
+        evaluator.hefx_linear_transform_plain(cv, d13, gk, fast);
+        ref = lt_plain(cv, d13, gk, params);
+        CHECK(shim::download(fast.buf) == shim::download(ref.buf), "hefx_linear_transform_plain d=13 bit for bit");
+        CHECK(throws_invalid([&] { GaloisKeys none; Ciphertext t; evaluator.hefx_linear_transform_plain(cv, diags, none, t); },
+                             "Galois key not present"),
+              "hefx_linear_transform_plain: missing keys throw");
     }
 
     // SEAL's error behaviour at the boundary

@@ -135,6 +135,16 @@ int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint6
  *      partial ciphertexts (<= `addends` canonical addends per word), bring every word back to [0,q_j). */
 int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, int addends, void *stream);
 
+/* ---- Linear_Transform_Plain(ct, U_diagonals[d], gal_keys) (helper.h:237-262 = linear_transformation2.cpp:149-174)
+ *      as one call: ct_new = ct + rotate(ct, -d); out = sum_l rotate(ct_new, l) * diag[l].  Rotations follow SEAL's
+ *      rotate_internal (direct key when (key_elts, keys) holds it, else the NAF terms of the step); the NAF plans,
+ *      their de-duplication, batching and the fusion of each plan's last key switch with multiply_plain happen
+ *      behind the call.  Bit-identical to the op-by-op sequence.  HEFX_ERR_INVALID "Galois key not present" when a
+ *      needed element is missing; the caller checks plaintext zero-ness (transparent result) beforehand. */
+int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
+                                const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
+                                const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
+
 /* ---- CKKSEncoder::encode(vector<double>, scale, plain) on the GPU (call sites
  *      matrix_mult_benchmark.cpp:291-323, logistic_regression_ckks.cpp:222-225,302-305, helper.h:333-343):
  *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->

@@ -1222,6 +1222,43 @@ public:
         }
     }
 
+    // ---- EXTENSION (not part of SEAL): the reference's Linear_Transform_Plain (helper.h:237-262) as one engine
+    // call, hefx_linear_transform_plain -- same checks, exceptions and result bits as the op-by-op body in helper.h,
+    // with the rotations of one NAF depth batched.  A maintainer switches helper.h to it with one line:
+    //     evaluator.hefx_linear_transform_plain(ct, U_diagonals, gal_keys, ct_prime); return ct_prime;
+    void hefx_linear_transform_plain(const Ciphertext &ct, const std::vector<Plaintext> &diags, const GaloisKeys &gk,
+                                     Ciphertext &dest) const
+    {
+        check_ct(ct);
+        if (ct.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+        if (diags.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+        const int d = (int)diags.size();
+        double ns = 0;
+        std::vector<const std::uint64_t *> pts;
+        for (const Plaintext &p : diags) {
+            check_pt(ct, p);
+            const double s = ct.scale() * p.scale();
+            check_scale(s, ct.parms_id());
+            if (!pts.empty() && !close(ns, s)) throw std::invalid_argument("scale mismatch");
+            if (pts.empty()) ns = s;
+            if (p.is_zero()) throw std::logic_error("result ciphertext is transparent");
+            pts.push_back(p.buf->p);
+        }
+        std::vector<std::uint32_t> plan;  // SEAL's exceptions for missing keys / too large steps
+        rotation_plan(-d, gk, plan);
+        for (int l = 1; l < d; ++l) rotation_plan(l, gk, plan);
+        std::vector<std::uint32_t> elts;
+        std::vector<const std::uint64_t *> keys;
+        for (const auto &kv : gk.keys) {
+            elts.push_back(kv.first);
+            keys.push_back(kv.second->p);
+        }
+        auto out = shim::new_buf(eng(), words(2, ct.rows));
+        shim::check(::hefx_linear_transform_plain(eng()->ctx, ct.rows, ct.buf->p, d, pts.data(), (int)keys.size(),
+                                                  elts.data(), keys.data(), out->p, nullptr));
+        dest.set(out, 2, ct.rows, ct.parms_id(), ns);
+    }
+
 private:
     const std::shared_ptr<shim::Engine> &eng() const { return ctx_->engine(); }
     std::size_t words(std::size_t size, int rows) const { return size * (std::size_t)rows * ctx_->n(); }

@@ -85,11 +85,38 @@ def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[
                            gal_keys: KSwitchKeys) -> Ciphertext:
     """Linear_Transform_Plain, helper.h:237-262 (= linear_transformation2.cpp:149-174)."""
     d = len(U_diagonals)
+    native = getattr(ev.be, "linear_transform_plain", None)
+    if native is not None:  # the HIP engine runs the whole transform behind one C-ABI call, same bits
+        return _linear_transform_plain_native(ev, native, ct, U_diagonals, gal_keys)
     ct_rot = ev.rotate_vector(ct, -d, gal_keys)                      # :244  fill with duplicate
     ct_new = ev.add(ct, ct_rot)                                      # :247
     res = [ev.multiply_plain(ct_new, U_diagonals[0])]                # :250
     res += _rotations_batched(ev, ct_new, list(range(1, d)), gal_keys, U_diagonals[1:])   # :252-257
     return ev.add_many(res)                                          # :259
+
+
+def _linear_transform_plain_native(ev: Evaluator, native, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
+                                   gal_keys: KSwitchKeys) -> Ciphertext:
+    """Same checks and bookkeeping as the op-by-op path (SEAL's exceptions), arithmetic in hefx_linear_transform_plain."""
+    L = ct.parms_id()
+    if ct.size() != 2:
+        raise ValueError("encrypted size must be 2")
+    scale = None
+    for p in U_diagonals:
+        if p.parms_id() != L:
+            raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
+        s = ct.scale * p.scale
+        ev._check_scale(s, L)
+        if scale is not None and not ev._close(scale, s):
+            raise ValueError("scale mismatch")
+        scale = s if scale is None else scale
+        if p.is_zero:
+            raise RuntimeError("result ciphertext is transparent")
+    for l in [-len(U_diagonals)] + list(range(1, len(U_diagonals))):
+        ev.rotation_plan(l, gal_keys)  # raises "Galois key not present" / "step count too large" like rotate_vector
+    elts = sorted(gal_keys.keys)
+    data = native(L, ct.data, [p.data for p in U_diagonals], elts, [gal_keys.key(e) for e in elts])
+    return Ciphertext()._set(data, 2, L, scale)
 
 
 def linear_transform_cipher(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Ciphertext],

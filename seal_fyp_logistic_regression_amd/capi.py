@@ -66,6 +66,7 @@ _SIGS = {
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "hefx_linear_transform_plain": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_ckks_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp]),
     "hefx_event_create": (_i, [_vp, _pp]),
     "hefx_event_destroy": (_i, [_vp, _vp]),

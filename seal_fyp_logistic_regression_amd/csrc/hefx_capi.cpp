@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <mutex>
+#include <tuple>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -128,6 +130,9 @@ struct hefx_context {
     EncodeTables E{};
     double *d_vals = nullptr;
     size_t vals_cap = 0;
+    // linear-transform workspace (rotated copies and products of one hefx_linear_transform_plain call)
+    u64 *lt_ws = nullptr;
+    size_t lt_cap = 0;
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
     hipEvent_t ring_ev[KS_RING] = {};
@@ -349,6 +354,7 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_enc_tables) (void)hipFree(c->d_enc_tables);
     if (c->d_vals) (void)hipFree(c->d_vals);
+    if (c->lt_ws) (void)hipFree(c->lt_ws);
     delete c;
 }
 
@@ -892,4 +898,160 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
     HIPCHK(launch_encode(c->T, c->E, c->d_vals, h_im ? c->d_vals + nv : nullptr, nvalues, count, scale, L, (u64 *)d_out, s));
     HIPCHK(launch_ntt(c->T, false, (u64 *)d_out, count, L, 0, s));
     return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Linear_Transform_Plain (helper.h:237-262 = linear_transformation2.cpp:149-174) as ONE call: the rotation plans
+// (SEAL rotate_internal: the direct key if present, else the NAF terms of the step, App. A.7), their batching and
+// the final sum all stay on this side of the C-ABI.  The result is bit-identical to the reference's sequence of
+// rotate_vector / multiply_plain / add_many calls: every key switch is deterministic, so (a) a (source, Galois
+// element) pair shared by several plans is computed once, (b) independent key switches of one depth run as one
+// batch, (c) the last key switch of each plan is fused with its multiply_plain.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct LtKeys {
+    std::unordered_map<uint32_t, const uint64_t *> m;
+    bool has(uint32_t e) const { return m.count(e) != 0; }
+};
+uint32_t lt_elt_from_step(int step, size_t n)
+{
+    const uint64_t m = 2 * n;
+    if (step == 0) return (uint32_t)(m - 1);
+    uint64_t pos = step > 0 ? (uint64_t)step : (uint64_t)((long long)(n / 2) + step);
+    uint64_t r = 1, b = 3;
+    while (pos) {
+        if (pos & 1) r = (r * b) & (m - 1);
+        b = (b * b) & (m - 1);
+        pos >>= 1;
+    }
+    return (uint32_t)r;
+}
+void lt_naf(int value, std::vector<int> &out)  // SEAL util::naf: least significant term first, signed like value
+{
+    const bool neg = value < 0;
+    unsigned v = (unsigned)(neg ? -value : value);
+    for (int i = 0; v; ++i) {
+        const int zi = (v & 1) ? 2 - (int)(v & 3) : 0;
+        v = (unsigned)((int)v - zi) >> 1;
+        if (zi) out.push_back((neg ? -zi : zi) * (1 << i));
+    }
+}
+// Galois elements rotate_vector(steps) applies, in order; false if a key is missing / the step is out of range
+bool lt_plan(int steps, size_t n, const LtKeys &keys, std::vector<uint32_t> &plan)
+{
+    if (steps == 0) return true;
+    if ((size_t)(steps < 0 ? -steps : steps) >= n / 2) return false;
+    const uint32_t e = lt_elt_from_step(steps, n);
+    if (keys.has(e)) {
+        plan.push_back(e);
+        return true;
+    }
+    std::vector<int> terms;
+    lt_naf(steps, terms);
+    if (terms.size() == 1) return false;
+    for (int t : terms) {
+        if ((size_t)(t < 0 ? -t : t) == n / 2) continue;
+        if (!lt_plan(t, n, keys, plan)) return false;
+    }
+    return true;
+}
+}  // namespace
+
+extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,
+                                           const uint64_t *const *diag_pts, int nkeys, const uint32_t *key_elts,
+                                           const uint64_t *const *keys, uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (!ct || !out || d < 1 || !diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+        return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    for (int i = 0; i < d; ++i)
+        if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    LtKeys K;
+    for (int i = 0; i < nkeys; ++i) {
+        if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
+        K.m[key_elts[i]] = keys[i];
+    }
+    const size_t N = c->n, ctw = 2 * (size_t)L * N;
+    // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
+    std::vector<uint32_t> first;
+    if (!lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, "Galois key not present");
+    struct Node {
+        int parent;  // -1: ct_new
+        uint32_t elt;
+        int fused;   // diagonal index whose plaintext multiplies this node's output, or -1
+        int depth;
+    };
+    std::vector<Node> nodes;
+    std::map<std::tuple<int, uint32_t, int>, int> index;
+    std::vector<int> leaf(d, -1);
+    int max_depth = 0;
+    std::vector<uint32_t> plan;
+    for (int l = 1; l < d; ++l) {
+        plan.clear();
+        if (!lt_plan(l, N, K, plan) || plan.empty()) return fail(HEFX_ERR_INVALID, "Galois key not present");
+        int cur = -1;
+        for (size_t t = 0; t < plan.size(); ++t) {
+            const int fused = t + 1 == plan.size() ? l : -1;
+            const auto key = std::make_tuple(cur, plan[t], fused);
+            auto it = index.find(key);
+            if (it == index.end()) {
+                nodes.push_back(Node{cur, plan[t], fused, (int)t});
+                it = index.emplace(key, (int)nodes.size() - 1).first;
+                if ((int)t + 1 > max_depth) max_depth = (int)t + 1;
+            }
+            cur = it->second;
+        }
+        leaf[l] = cur;
+    }
+    // ---- workspace: ping/pong for the first rotation chain, ct_new, product 0, one ciphertext per node
+    const size_t need = ctw * (4 + nodes.size());
+    if (c->lt_cap < need) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
+        c->lt_ws = nullptr;
+        c->lt_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->lt_ws, need * sizeof(u64)));
+        c->lt_cap = need;
+    }
+    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw,
+             *prod0 = ct_new + ctw, *node0 = prod0 + ctw;
+    auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
+    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247)
+    const uint64_t *src = ct;
+    for (size_t t = 0; t < first.size(); ++t) {
+        uint64_t *dst = (t & 1) ? pong : ping;
+        const uint64_t *key = K.m[first[t]];
+        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
+        src = dst;
+    }
+    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
+    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
+    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
+    // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth   (helper.h:252-257)
+    std::vector<const uint64_t *> in, kk, pp;
+    std::vector<uint64_t *> oo;
+    std::vector<uint32_t> ee;
+    for (int depth = 0; depth < max_depth; ++depth)
+        for (int fused = 0; fused < 2; ++fused) {
+            in.clear(), kk.clear(), pp.clear(), oo.clear(), ee.clear();
+            for (size_t i = 0; i < nodes.size(); ++i) {
+                const Node &nd = nodes[i];
+                if (nd.depth != depth || (nd.fused >= 0) != (fused != 0)) continue;
+                in.push_back(node_ptr(nd.parent));
+                ee.push_back(nd.elt);
+                kk.push_back(K.m[nd.elt]);
+                oo.push_back(node_ptr((int)i));
+                if (fused) pp.push_back(diag_pts[nd.fused]);
+            }
+            if (in.empty()) continue;
+            if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
+                                fused ? pp.data() : nullptr, oo.data(), stream))
+                return rc;
+        }
+    // ---- out = add_many(res)               (helper.h:259)
+    std::vector<const uint64_t *> res(d);
+    res[0] = prod0;
+    for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
+    return hefx_add_many(c, L, 2, d, res.data(), out, stream);
 }

@@ -230,6 +230,14 @@ class Engine:
         capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
         return buf
 
+    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, out=None, stream=None):
+        """Linear_Transform_Plain in one native call (hefx_linear_transform_plain)"""
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        capi.check(capi.lib().hefx_linear_transform_plain(
+            self._h, L, ct.ptr, len(diag_pts), capi.ptr_array([p.ptr for p in diag_pts]), len(keys),
+            capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
+        return out
+
     # ---- CKKS encode on the GPU
     def ckks_encode(self, L, values, scale, out=None, stream=None):
         """values: [count][nvalues] (or [nvalues]) real or complex -> [count][L][N] NTT-form plaintexts"""

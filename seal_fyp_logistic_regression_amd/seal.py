@@ -164,6 +164,9 @@ class GpuBackend:
     def reduce_canonical(self, L, size, h, addends):
         return self.engine.reduce_canonical(L, size, h, addends)
 
+    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys):
+        return self.engine.linear_transform_plain(L, ct, diag_pts, key_elts, keys)
+
     def ckks_encode(self, L, values, scale):
         """[count][nvalues] slot values -> [count][L][N] NTT-form plaintexts, or None if N is outside the kernel's range"""
         if not 1024 <= self.N <= 16384:
