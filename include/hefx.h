@@ -154,6 +154,28 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
 int hefx_ckks_encode(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
                      double scale, uint64_t *d_out, void *stream);
 
+/* ---- randomness, Encryptor::encrypt, Decryptor::decrypt on the GPU (call sites
+ *      linear_transformation2.cpp:344-350, logistic_regression_ckks.cpp:362-381, matrix_multiplication.cpp:419).
+ *      Counter-mode sampling: every 64-bit word is a pure function of (key32 = 32-byte ChaCha20 key, stream id,
+ *      position) -- specification in csrc/hefx_sample.hip and oracle/ckks_oracle.c (orc_sample_*), which give the
+ *      same bits.  Distributions as SEAL 3.4.5: uniform mod q (rejection), ternary {-1,0,1}, clipped normal
+ *      sigma 3.2 / bound 19.2 truncated toward zero.  Output [npoly][nrows][N], rows reduced mod
+ *      q_(mod_first+row); ternary / noise write ONE draw per coefficient into every row, COEFFICIENT form.
+ *      The caller owns the key: fresh 32 bytes from the OS per key generator / encryptor, a new stream id per call. */
+int hefx_sample_uniform(hefx_context *ctx, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                        int mod_first, uint64_t *d_out, void *stream);
+int hefx_sample_ternary(hefx_context *ctx, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                        int mod_first, uint64_t *d_out, void *stream);
+int hefx_sample_noise(hefx_context *ctx, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                      int mod_first, uint64_t *d_out, void *stream);
+/* out[2][L][N] = (pk0*u + e0 + plain, pk1*u + e1), NTT form; d_pk = [2][k][N] (key-level public key), d_plain may be
+ * NULL (encryption of zero); u ternary from sub-stream 4*stream_id, e0 / e1 noise from 4*stream_id+1 / +2. */
+int hefx_encrypt(hefx_context *ctx, int L, const uint64_t *d_pk, const uint64_t *d_plain, const uint8_t *key32,
+                 uint64_t stream_id, uint64_t *d_out, void *stream);
+/* out[L][N] = c0 + c1*s + ... + c_(size-1)*s^(size-1), NTT form; d_sk = NTT-form secret key rows [>=L][N] */
+int hefx_decrypt(hefx_context *ctx, int L, int size, const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_out,
+                 void *stream);
+
 /* ---- measurement helpers (no reference counterpart; the reference times with std::chrono around the L3
  *      call, e.g. linear_transformation2.cpp:363-365).  HIP events recorded on the stream the kernels use. */
 int hefx_event_create(hefx_context *ctx, void **event);

@@ -197,6 +197,30 @@ inline std::mt19937_64 &rng()
     return g;
 }
 
+// 32-byte key + stream counter of the engine's counter-mode sampler (hefx_sample_* / hefx_encrypt): one per
+// KeyGenerator / Encryptor.  Key bytes come from std::random_device (the OS entropy source), or -- tests only --
+// from the deterministic generator above when SEAL_SHIM_SEED is set.
+struct SamplerState {
+    std::array<std::uint8_t, 32> key{};
+    mutable std::uint64_t next = 0;
+    SamplerState()
+    {
+        if (std::getenv("SEAL_SHIM_SEED")) {
+            for (auto &b : key) b = (std::uint8_t)rng()();
+        } else {
+            std::random_device rd;
+            for (std::size_t i = 0; i < key.size(); i += 4) {
+                const std::uint32_t v = rd();
+                for (int b = 0; b < 4; ++b) key[i + b] = (std::uint8_t)(v >> (8 * b));
+            }
+        }
+    }
+    // a copy must never replay its source's streams (u / e reuse across messages): copies re-key themselves
+    SamplerState(const SamplerState &) : SamplerState() {}
+    SamplerState &operator=(const SamplerState &) { return *this; }
+    std::uint64_t stream() const { return ++next; }
+};
+
 inline std::uint32_t galois_elt_from_step(int step, std::size_t n)
 {
     const std::uint32_t m = (std::uint32_t)(2 * n);
@@ -517,7 +541,7 @@ class RelinKeys : public KSwitchKeys {};
 class GaloisKeys : public KSwitchKeys {};
 
 // ------------------------------------------------------------------------------------------------
-// KeyGenerator (App. A.11): sampling on the host, arithmetic on the GPU
+// KeyGenerator (App. A.11): sampling (hefx_sample_*) and arithmetic on the GPU, key assembly on the host
 // ------------------------------------------------------------------------------------------------
 class KeyGenerator {
 public:
@@ -525,17 +549,11 @@ public:
     explicit KeyGenerator(const Ctx &context) : ctx_(shim::as_ptr(context))
     {
         if (!ctx_->is_ckks()) return;  // BFV drivers only compile
-        const std::size_t n = ctx_->n();
         const int k = ctx_->k();
-        std::vector<int> tern(n);
-        std::uniform_int_distribution<int> d(-1, 1);
-        for (auto &t : tern) t = d(shim::rng());
-        std::vector<std::uint64_t> s((std::size_t)k * n);
-        for (int j = 0; j < k; ++j)
-            for (std::size_t i = 0; i < n; ++i)
-                s[(std::size_t)j * n + i] = tern[i] < 0 ? ctx_->primes()[j] - 1 : (std::uint64_t)tern[i];
-        sk_.buf = shim::upload(ctx_->engine(), s);
-        shim::check(hefx_ntt_forward(ctx_->engine()->ctx, sk_.buf->p, 1, k, 0, nullptr));
+        auto &e = ctx_->engine();
+        sk_.buf = shim::new_buf(e, (std::size_t)k * ctx_->n());
+        shim::check(hefx_sample_ternary(e->ctx, rnd_.key.data(), rnd_.stream(), 1, k, 0, sk_.buf->p, nullptr));
+        shim::check(hefx_ntt_forward(e->ctx, sk_.buf->p, 1, k, 0, nullptr));
         sk_.host = shim::download(sk_.buf);
     }
 
@@ -609,38 +627,16 @@ private:
         return gk;
     }
 
-    std::vector<std::uint64_t> noise(int npoly, int rows)
-    {
-        const std::size_t n = ctx_->n();
-        std::normal_distribution<double> nd(0.0, 3.2);
-        std::vector<std::uint64_t> out((std::size_t)npoly * rows * n);
-        for (int p = 0; p < npoly; ++p)
-            for (std::size_t i = 0; i < n; ++i) {
-                double v;
-                do v = nd(shim::rng());
-                while (std::fabs(v) > 19.2);
-                const long long e = (long long)v;
-                for (int j = 0; j < rows; ++j) {
-                    const std::uint64_t q = ctx_->primes()[j];
-                    out[((std::size_t)p * rows + j) * n + i] = e >= 0 ? (std::uint64_t)e : q - (std::uint64_t)(-e);
-                }
-            }
-        return out;
-    }
-
     // npoly fresh symmetric encryptions of zero over the first `rows` primes: (device c0, host c1)
     std::pair<shim::BufPtr, std::vector<std::uint64_t>> encrypt_zero(int npoly, int rows)
     {
         auto &e = ctx_->engine();
         const std::size_t n = ctx_->n();
-        std::vector<std::uint64_t> a((std::size_t)npoly * rows * n);
-        for (int p = 0; p < npoly; ++p)
-            for (int j = 0; j < rows; ++j) {
-                std::uniform_int_distribution<std::uint64_t> d(0, ctx_->primes()[j] - 1);
-                for (std::size_t i = 0; i < n; ++i) a[((std::size_t)p * rows + j) * n + i] = d(shim::rng());
-            }
-        auto da = shim::upload(e, a);
-        auto de = shim::upload(e, noise(npoly, rows));
+        const std::size_t words = (std::size_t)npoly * rows * n;
+        auto da = shim::new_buf(e, words), de = shim::new_buf(e, words);
+        shim::check(hefx_sample_uniform(e->ctx, rnd_.key.data(), rnd_.stream(), npoly, rows, 0, da->p, nullptr));
+        shim::check(hefx_sample_noise(e->ctx, rnd_.key.data(), rnd_.stream(), npoly, rows, 0, de->p, nullptr));
+        const std::vector<std::uint64_t> a = shim::download(da, words);
         shim::check(hefx_ntt_forward(e->ctx, de->p, npoly, rows, 0, nullptr));
         auto t = shim::new_buf(e, a.size());
         shim::check(hefx_multiply_plain(e->ctx, rows, npoly, 1, da->p, sk_.buf->p, t->p, nullptr));
@@ -677,6 +673,7 @@ private:
 
     std::shared_ptr<SEALContext> ctx_;
     SecretKey sk_;
+    shim::SamplerState rnd_;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -693,42 +690,17 @@ public:
         if (!ctx_->is_ckks()) throw std::logic_error("BFV is not built in this shim");
         if (!plain.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
         auto &e = ctx_->engine();
-        const std::size_t n = ctx_->n();
-        const int L = plain.rows, k = ctx_->k();
-        std::vector<std::uint64_t> u((std::size_t)L * n), err((std::size_t)2 * L * n);
-        std::uniform_int_distribution<int> td(-1, 1);
-        std::normal_distribution<double> nd(0.0, 3.2);
-        for (std::size_t i = 0; i < n; ++i) {
-            const int t = td(shim::rng());
-            long long en[2];
-            for (auto &x : en) {
-                double v;
-                do v = nd(shim::rng());
-                while (std::fabs(v) > 19.2);
-                x = (long long)v;
-            }
-            for (int j = 0; j < L; ++j) {
-                const std::uint64_t q = ctx_->primes()[j];
-                u[(std::size_t)j * n + i] = t < 0 ? q - 1 : (std::uint64_t)t;
-                for (int c = 0; c < 2; ++c)
-                    err[((std::size_t)c * L + j) * n + i] = en[c] >= 0 ? (std::uint64_t)en[c] : q - (std::uint64_t)(-en[c]);
-            }
-        }
-        auto du = shim::upload(e, u), de = shim::upload(e, err);
-        shim::check(hefx_ntt_forward(e->ctx, du->p, 1, L, 0, nullptr));
-        shim::check(hefx_ntt_forward(e->ctx, de->p, 2, L, 0, nullptr));
-        auto pkl = shim::new_buf(e, (std::size_t)2 * L * n);  // first L rows of each pk poly
-        shim::check(hefx_mod_drop(e->ctx, k, L, 2, pk_.buf->p, pkl->p, nullptr));
-        auto c = shim::new_buf(e, (std::size_t)2 * L * n);
-        shim::check(hefx_multiply_plain(e->ctx, L, 2, 1, pkl->p, du->p, c->p, nullptr));
-        shim::check(hefx_add(e->ctx, L, 2, 1, c->p, de->p, c->p, nullptr));
-        shim::check(hefx_add_plain(e->ctx, L, 2, c->p, plain.buf->p, c->p, nullptr));
+        const int L = plain.rows;
+        auto c = shim::new_buf(e, (std::size_t)2 * L * ctx_->n());
+        // sampling (u ternary, e0/e1 clipped normal), NTT and the dyadic arithmetic: one engine call
+        shim::check(hefx_encrypt(e->ctx, L, pk_.buf->p, plain.buf->p, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
         dest.set(c, 2, L, plain.parms_id(), plain.scale());
     }
 
 private:
     std::shared_ptr<SEALContext> ctx_;
     PublicKey pk_;
+    shim::SamplerState rnd_;
 };
 
 class Decryptor {
@@ -741,14 +713,9 @@ public:
     {
         if (!ct.buf) throw std::invalid_argument("encrypted is not valid for encryption parameters");
         auto &e = ctx_->engine();
-        const std::size_t n = ctx_->n(), w = (std::size_t)ct.rows * n;
         const int L = ct.rows;
-        auto acc = shim::new_buf(e, w);
-        shim::check(hefx_copy(e->ctx, acc->p, ct.buf->p + (ct.size() - 1) * w, w * 8, nullptr));
-        for (int p = (int)ct.size() - 2; p >= 0; --p) {
-            shim::check(hefx_multiply_plain(e->ctx, L, 1, 1, acc->p, sk_.buf->p, acc->p, nullptr));
-            shim::check(hefx_add(e->ctx, L, 1, 1, acc->p, ct.buf->p + (std::size_t)p * w, acc->p, nullptr));
-        }
+        auto acc = shim::new_buf(e, (std::size_t)L * ctx_->n());
+        shim::check(hefx_decrypt(e->ctx, L, (int)ct.size(), ct.buf->p, sk_.buf->p, acc->p, nullptr));
         dest.buf = acc;
         dest.rows = L;
         dest.parms_id() = ct.parms_id();

@@ -988,3 +988,125 @@ void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, doubl
     free(real);
     free(v);
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Counter-mode sampling: the CPU statement of csrc/hefx_sample.hip.
+ * SEAL 3.4.5 draws from a Blake2-based stream that cannot be reproduced by a parallel sampler, and SEAL itself
+ * seeds it from std::random_device -- randomness is an INPUT of the parity chain, never an output.  What is
+ * specified here instead: every random word is a pure function of (256-bit key, stream id, position), taken from
+ * the ChaCha20 keystream (RFC 7539 block function, 64-bit block counter in state words 12-13, 64-bit stream id in
+ * words 14-15), so a GPU thread and this loop produce the same bits in any order.
+ *   position  -> block counter = attempt << 48 | row << 16 | (index >> 3), 64-bit word (index & 7) of that block
+ *   uniform   mod q: accept r < q * floor(2^64 / q), value r mod q; else attempt + 1            (SEAL: rejection)
+ *   ternary   {-1,0,1}: r mod 3 - 1 with the same rejection rule                                 (App. A.11)
+ *   noise     trunc(N(0, 3.2^2) | |x| <= 19.2) by inverse CDF on r with a 39-entry threshold table built from
+ *             erfc in double precision -- exact integer comparisons, no libm call in the sampler itself
+ * ---------------------------------------------------------------------------------------------- */
+#define ROTL32(v, n) (((v) << (n)) | ((v) >> (32 - (n))))
+#define CHACHA_QR(a, b, c, d) \
+    a += b; d ^= a; d = ROTL32(d, 16); c += d; b ^= c; b = ROTL32(b, 12); \
+    a += b; d ^= a; d = ROTL32(d, 8);  c += d; b ^= c; b = ROTL32(b, 7);
+
+void orc_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16])
+{
+    uint32_t s[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3],
+                      key[4], key[5], key[6], key[7], (uint32_t)counter, (uint32_t)(counter >> 32),
+                      (uint32_t)nonce, (uint32_t)(nonce >> 32)};
+    uint32_t x[16];
+    memcpy(x, s, sizeof x);
+    for (int r = 0; r < 10; r++) {
+        CHACHA_QR(x[0], x[4], x[8], x[12]) CHACHA_QR(x[1], x[5], x[9], x[13])
+        CHACHA_QR(x[2], x[6], x[10], x[14]) CHACHA_QR(x[3], x[7], x[11], x[15])
+        CHACHA_QR(x[0], x[5], x[10], x[15]) CHACHA_QR(x[1], x[6], x[11], x[12])
+        CHACHA_QR(x[2], x[7], x[8], x[13]) CHACHA_QR(x[3], x[4], x[9], x[14])
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + s[i];
+}
+
+static uint64_t sample_word(const uint32_t key[8], uint64_t stream, uint64_t row, uint64_t idx, uint64_t attempt)
+{
+    uint32_t b[16];
+    orc_chacha20_block(key, (attempt << 48) | (row << 16) | (idx >> 3), stream, b);
+    const int w = (int)(idx & 7);
+    return (uint64_t)b[2 * w] | ((uint64_t)b[2 * w + 1] << 32);
+}
+
+/* thresholds t[0..38]: value = -19 + #{i : r >= t[i]}, t[i] = floor(2^64 * P(Y <= -19 + i)) */
+void orc_noise_thresholds(uint64_t t[39])
+{
+    const double sigma = 3.2, clip = 19.2, rs2 = 1.0 / (sigma * 1.4142135623730951);
+    const double tail = erfc(clip * rs2);           /* 2 * P(X > clip) */
+    const double total = 1.0 - tail;                /* P(|X| <= clip) */
+    /* P(Y <= k) for k = -19..19 with Y = trunc(X): for k < 0, Y <= k <=> X <= k (strictly below k+1 ... see below) */
+    for (int i = 0; i < 39; i++) {
+        const int k = -19 + i;
+        /* Y <= k  <=>  X < k + 1 for k >= 0;  X <= k for k < 0 (trunc toward zero); X continuous so < vs <= agree */
+        const double edge = k >= 0 ? (double)(k + 1) : (double)k;
+        double below; /* P(-clip <= X < edge) */
+        if (edge >= clip)
+            below = total;
+        else
+            below = 0.5 * erfc(-edge * rs2) - 0.5 * tail;
+        double cdf = below / total;
+        if (cdf >= 1.0 || i == 38) {
+            t[i] = ~(uint64_t)0;
+            continue;
+        }
+        long double scaled = (long double)cdf * 18446744073709551616.0L;
+        t[i] = (uint64_t)scaled;
+    }
+}
+
+void orc_sample_uniform(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                        int mod_first, uint64_t *out)
+{
+    const uint64_t n = c->N;
+    for (int p = 0; p < npoly; p++)
+        for (int j = 0; j < nrows; j++) {
+            const uint64_t q = c->t[mod_first + j].m.q;
+            const uint64_t bound = (~(uint64_t)0 / q) * q; /* q * floor((2^64-1)/q) == q * floor(2^64/q), q odd */
+            const uint64_t row = (uint64_t)p * nrows + j;
+            uint64_t *o = out + row * n;
+            for (uint64_t i = 0; i < n; i++) {
+                uint64_t r, a = 0;
+                do r = sample_word(key, stream, row, i, a++);
+                while (r >= bound);
+                o[i] = r % q;
+            }
+        }
+}
+
+void orc_sample_ternary(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                        int mod_first, uint64_t *out)
+{
+    const uint64_t n = c->N;
+    for (int p = 0; p < npoly; p++)
+        for (uint64_t i = 0; i < n; i++) {
+            uint64_t r, a = 0;
+            do r = sample_word(key, stream, (uint64_t)p, i, a++);
+            while (r >= 0xFFFFFFFFFFFFFFFFull); /* 3 * floor(2^64 / 3) */
+            const int v = (int)(r % 3) - 1;
+            for (int j = 0; j < nrows; j++) {
+                const uint64_t q = c->t[mod_first + j].m.q;
+                out[((size_t)p * nrows + j) * n + i] = v < 0 ? q - 1 : (uint64_t)v;
+            }
+        }
+}
+
+void orc_sample_noise(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                      int mod_first, uint64_t *out)
+{
+    const uint64_t n = c->N;
+    uint64_t t[39];
+    orc_noise_thresholds(t);
+    for (int p = 0; p < npoly; p++)
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t r = sample_word(key, stream, (uint64_t)p, i, 0);
+            int v = -19;
+            for (int e = 0; e < 38; e++) v += r >= t[e];
+            for (int j = 0; j < nrows; j++) {
+                const uint64_t q = c->t[mod_first + j].m.q;
+                out[((size_t)p * nrows + j) * n + i] = v < 0 ? q - (uint64_t)(-v) : (uint64_t)v;
+            }
+        }
+}

@@ -105,6 +105,17 @@ void orc_encode(const orc_ctx *c, int L, const double *vals_ri, int nvals, doubl
 /* CKKS decode: pt [L][N] NTT -> N/2 complex values (re,im interleaved). */
 void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, double *vals_ri);
 
+
+/* ---- counter-mode sampling: CPU statement of csrc/hefx_sample.hip (see ckks_oracle.c for the specification) */
+void orc_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
+void orc_noise_thresholds(uint64_t t[39]);
+void orc_sample_uniform(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                        int mod_first, uint64_t *out);
+void orc_sample_ternary(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                        int mod_first, uint64_t *out);
+void orc_sample_noise(const orc_ctx *c, const uint32_t key[8], uint64_t stream, int npoly, int nrows,
+                      int mod_first, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

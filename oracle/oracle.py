@@ -81,8 +81,25 @@ def lib():
     sig("orc_decrypt", None, vp, i, i, u64p, u64p, u64p)
     sig("orc_encode", None, vp, i, f64p, i, d, u64p)
     sig("orc_decode", None, vp, i, u64p, d, f64p)
+    sig("orc_chacha20_block", None, u32p, u64, u64, u32p)
+    sig("orc_noise_thresholds", None, u64p)
+    for name in ("orc_sample_uniform", "orc_sample_ternary", "orc_sample_noise"):
+        sig(name, None, vp, u32p, u64, i, i, i, u64p)
     _lib = L
     return L
+
+
+def chacha20_block(key32: bytes, counter: int, nonce: int) -> np.ndarray:
+    key = np.frombuffer(bytes(key32), dtype="<u4").copy()
+    out = np.zeros(16, dtype=np.uint32)
+    lib().orc_chacha20_block(key, counter, nonce, out)
+    return out
+
+
+def noise_thresholds() -> np.ndarray:
+    t = np.zeros(39, dtype=np.uint64)
+    lib().orc_noise_thresholds(t)
+    return t
 
 
 def coeff_modulus_create(N: int, bit_sizes) -> list[int]:
@@ -287,6 +304,17 @@ class Oracle:
         pt = self._new(ct.shape[1])
         lib().orc_decrypt(self._h, ct.shape[1], ct.shape[0], ct, sk, pt)
         return pt
+
+    # ---- counter-mode sampling (CPU statement of csrc/hefx_sample.hip)
+    def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
+        if len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        key = np.frombuffer(bytes(key32), dtype="<u4").copy()
+        out = np.empty((npoly, nrows, self.N), dtype=np.uint64)
+        f = {"uniform": lib().orc_sample_uniform, "ternary": lib().orc_sample_ternary,
+             "noise": lib().orc_sample_noise}[kind]
+        f(self._h, key, stream_id, npoly, nrows, mod_first, out)
+        return out
 
     def encode(self, L, values, scale):
         v = np.asarray(values, dtype=np.complex128)

@@ -68,6 +68,11 @@ _SIGS = {
     "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "hefx_linear_transform_plain": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_ckks_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp]),
+    "hefx_sample_uniform": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
+    "hefx_sample_ternary": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
+    "hefx_sample_noise": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
+    "hefx_encrypt": (_i, [_vp, _i, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
+    "hefx_decrypt": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "hefx_event_create": (_i, [_vp, _pp]),
     "hefx_event_destroy": (_i, [_vp, _vp]),
     "hefx_event_record": (_i, [_vp, _vp, _vp]),

@@ -130,6 +130,7 @@ struct hefx_context {
     EncodeTables E{};
     double *d_vals = nullptr;
     size_t vals_cap = 0;
+    NoiseTable noise{};  // inverse-CDF thresholds of the clipped normal (sigma 3.2, bound 19.2, truncated)
     // linear-transform workspace (rotated copies and products of one hefx_linear_transform_plain call)
     u64 *lt_ws = nullptr;
     size_t lt_cap = 0;
@@ -292,6 +293,20 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
             halfmod[(size_t)l * k + j] = (primes[l] >> 1) % q;
         }
 
+    {  // same formula as the CPU checker (orc_noise_thresholds under oracle/)
+        const double sigma = 3.2, clip = 19.2, rs2 = 1.0 / (sigma * 1.4142135623730951);
+        const double tail = erfc(clip * rs2), tot = 1.0 - tail;
+        for (int i = 0; i < 39; ++i) {
+            const int kk = -19 + i;
+            const double edge = kk >= 0 ? (double)(kk + 1) : (double)kk;
+            const double below = edge >= clip ? tot : 0.5 * erfc(-edge * rs2) - 0.5 * tail;
+            const double cdf = below / tot;
+            if (cdf >= 1.0 || i == 38)
+                c->noise.t[i] = ~(u64)0;
+            else
+                c->noise.t[i] = (u64)((long double)cdf * 18446744073709551616.0L);
+        }
+    }
     hipError_t e = hipMalloc(&c->d_tables, total);
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
@@ -1054,4 +1069,74 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
     res[0] = prod0;
     for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
     return hefx_add_many(c, L, 2, d, res.data(), out, stream);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Randomness, encrypt, decrypt on the GPU
+// ---------------------------------------------------------------------------------------------
+static SampleKey sample_key(const uint8_t *key32)
+{
+    SampleKey k;
+    for (int i = 0; i < 8; ++i)
+        k.w[i] = (uint32_t)key32[4 * i] | ((uint32_t)key32[4 * i + 1] << 8) | ((uint32_t)key32[4 * i + 2] << 16) |
+                 ((uint32_t)key32[4 * i + 3] << 24);
+    return k;
+}
+
+static int sample_common(hefx_context *c, int mode, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                         int mod_first, uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (!key32 || !out || npoly < 1 || nrows < 1 || mod_first < 0 || mod_first + nrows > c->k)
+        return fail(HEFX_ERR_INVALID, "bad sampling arguments");
+    if ((size_t)npoly * nrows >= ((size_t)1 << 32)) return fail(HEFX_ERR_INVALID, "too many rows in one sampling call");
+    HIPCHK(launch_sample(c->T, mode, sample_key(key32), c->noise, stream_id, npoly, nrows, mod_first, (u64 *)out,
+                         (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_sample_uniform(hefx_context *c, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                                   int mod_first, uint64_t *out, void *stream)
+{
+    return sample_common(c, SAMPLE_UNIFORM, key32, stream_id, npoly, nrows, mod_first, out, stream);
+}
+extern "C" int hefx_sample_ternary(hefx_context *c, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                                   int mod_first, uint64_t *out, void *stream)
+{
+    return sample_common(c, SAMPLE_TERNARY, key32, stream_id, npoly, nrows, mod_first, out, stream);
+}
+extern "C" int hefx_sample_noise(hefx_context *c, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
+                                 int mod_first, uint64_t *out, void *stream)
+{
+    return sample_common(c, SAMPLE_NOISE, key32, stream_id, npoly, nrows, mod_first, out, stream);
+}
+
+extern "C" int hefx_encrypt(hefx_context *c, int L, const uint64_t *pk, const uint64_t *plain, const uint8_t *key32,
+                            uint64_t stream_id, uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (!pk || !key32 || !out) return fail(HEFX_ERR_INVALID, "bad encrypt arguments");
+    if (stream_id >> 62) return fail(HEFX_ERR_INVALID, "stream id must be below 2^62");
+    const size_t N = c->n, rowsz = (size_t)L * N;
+    if (int rc = ensure_scratch(c, 3 * rowsz)) return rc;
+    u64 *u = c->scratch, *e = u + rowsz;
+    hipStream_t s = (hipStream_t)stream;
+    const SampleKey k = sample_key(key32);
+    // sub-streams 4*id + {0: u, 1: e0, 2: e1}
+    HIPCHK(launch_sample(c->T, SAMPLE_TERNARY, k, c->noise, 4 * stream_id + 0, 1, L, 0, u, s));
+    HIPCHK(launch_sample(c->T, SAMPLE_NOISE, k, c->noise, 4 * stream_id + 1, 1, L, 0, e, s));
+    HIPCHK(launch_sample(c->T, SAMPLE_NOISE, k, c->noise, 4 * stream_id + 2, 1, L, 0, e + rowsz, s));
+    HIPCHK(launch_ntt(c->T, false, u, 3, L, 0, s));
+    HIPCHK(launch_encrypt_combine(c->T, L, (const u64 *)pk, u, e, (const u64 *)plain, (u64 *)out, s));
+    return HEFX_OK;
+}
+
+extern "C" int hefx_decrypt(hefx_context *c, int L, int size, const uint64_t *ct, const uint64_t *sk, uint64_t *out,
+                            void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (!ct || !sk || !out || size < 1) return fail(HEFX_ERR_INVALID, "bad decrypt arguments");
+    HIPCHK(launch_decrypt(c->T, L, size, (const u64 *)ct, (const u64 *)sk, (u64 *)out, (hipStream_t)stream));
+    return HEFX_OK;
 }

@@ -96,6 +96,19 @@ struct EncodeTables {
 };
 hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double *re, const double *im, int nvalues,
                          int count, double scale, int L, u64 *out, hipStream_t s);
+// sampling + encrypt/decrypt arithmetic (hefx_sample.hip)
+struct SampleKey {
+    uint32_t w[8];  // ChaCha20 key, little-endian words of the 32 key bytes
+};
+struct NoiseTable {
+    u64 t[39];  // value = -19 + #{i < 38 : r >= t[i]}
+};
+enum { SAMPLE_UNIFORM = 0, SAMPLE_TERNARY = 1, SAMPLE_NOISE = 2 };
+hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, const NoiseTable &tab, u64 stream,
+                         int npoly, int nrows, int mod_first, u64 *out, hipStream_t s);
+hipError_t launch_encrypt_combine(const DevTables &T, int L, const u64 *pk, const u64 *u, const u64 *e,
+                                  const u64 *plain, u64 *out, hipStream_t s);
+hipError_t launch_decrypt(const DevTables &T, int L, int size, const u64 *ct, const u64 *sk, u64 *out, hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

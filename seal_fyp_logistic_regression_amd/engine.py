@@ -238,6 +238,31 @@ class Engine:
             capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
         return out
 
+    # ---- randomness, encrypt, decrypt on the GPU
+    def sample(self, kind, key32: bytes, stream_id: int, npoly: int, nrows: int, mod_first: int = 0, out=None,
+               stream=None):
+        """kind in {'uniform', 'ternary', 'noise'} -> [npoly][nrows][N]; ternary / noise in coefficient form"""
+        if len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        f = {"uniform": capi.lib().hefx_sample_uniform, "ternary": capi.lib().hefx_sample_ternary,
+             "noise": capi.lib().hefx_sample_noise}[kind]
+        out = out if out is not None else DeviceArray(self, (npoly, nrows, self.N))
+        capi.check(f(self._h, key32, stream_id, npoly, nrows, mod_first, out.ptr, stream))
+        return out
+
+    def encrypt(self, L, pk, plain, key32: bytes, stream_id: int, out=None, stream=None):
+        if len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        capi.check(capi.lib().hefx_encrypt(self._h, L, pk.ptr, plain.ptr if plain is not None else None, key32,
+                                           stream_id, out.ptr, stream))
+        return out
+
+    def decrypt(self, L, size, ct, sk, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (L, self.N))
+        capi.check(capi.lib().hefx_decrypt(self._h, L, size, ct.ptr, sk.ptr, out.ptr, stream))
+        return out
+
     # ---- CKKS encode on the GPU
     def ckks_encode(self, L, values, scale, out=None, stream=None):
         """values: [count][nvalues] (or [nvalues]) real or complex -> [count][L][N] NTT-form plaintexts"""

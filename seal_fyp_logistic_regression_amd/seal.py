@@ -10,6 +10,7 @@ complex FFT of CKKSEncoder run on the host in numpy; their NTTs run on the GPU.
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -166,6 +167,15 @@ class GpuBackend:
 
     def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys):
         return self.engine.linear_transform_plain(L, ct, diag_pts, key_elts, keys)
+
+    def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
+        return self.engine.sample(kind, key32, stream_id, npoly, nrows, mod_first)
+
+    def encrypt(self, L, pk, plain, key32, stream_id):
+        return self.engine.encrypt(L, pk, plain, key32, stream_id)
+
+    def decrypt(self, L, size, ct, sk):
+        return self.engine.decrypt(L, size, ct, sk)
 
     def ckks_encode(self, L, values, scale):
         """[count][nvalues] slot values -> [count][L][N] NTT-form plaintexts, or None if N is outside the kernel's range"""
@@ -324,56 +334,46 @@ GaloisKeys = KSwitchKeys
 RelinKeys = KSwitchKeys
 
 
-class KeyGenerator:
-    """Samples on the host (numpy Generator seeded by `seed`; SEAL seeds from random_device, so keys are inputs
-    to parity, never outputs); all modular arithmetic on the backend (App. A.11)."""
+def _key32(seed) -> bytes:
+    """32-byte ChaCha20 key of the backend sampler: fresh OS randomness when seed is None (production), else a
+    deterministic expansion of the integer seed (tests: randomness is an input of the parity chain)."""
+    import hashlib
+    if seed is None:
+        return os.urandom(32)
+    return hashlib.sha256(b"hefx-seed:" + str(int(seed)).encode()).digest()
 
-    def __init__(self, context: SEALContext, seed: int = 1):
+
+class KeyGenerator:
+    """Randomness from the backend's counter-mode sampler (hefx_sample_*: ChaCha20 keystream, SEAL 3.4.5's
+    distributions; SEAL seeds from random_device, so keys are inputs to parity, never outputs); all modular
+    arithmetic on the backend (App. A.11).  seed=None draws the sampler key from the OS."""
+
+    def __init__(self, context: SEALContext, seed: Optional[int] = 1):
         self.ctx = context
-        self.rng = np.random.default_rng(seed)
-        N, k, q = context.N, context.k, context.primes
-        tern = self.rng.integers(-1, 2, N)
-        sk = np.empty((k, N), dtype=np.uint64)
-        for j in range(k):
-            sk[j] = np.where(tern < 0, q[j] - 1, tern).astype(np.uint64)
-        h = context.backend.from_host(sk)
-        context.backend.ntt_forward(h, 1, k, 0)
-        self._sk = SecretKey(context.backend.to_host(h), h)
+        self._key32, self._stream = _key32(seed), 0
+        be, k = context.backend, context.k
+        h = be.sample("ternary", self._key32, self._next_stream(), 1, k)
+        be.ntt_forward(h, 1, k, 0)
+        self._sk = SecretKey(be.to_host(h).reshape(k, context.N), h)
+
+    def _next_stream(self) -> int:
+        self._stream += 1
+        return self._stream
 
     def secret_key(self) -> SecretKey:
         return self._sk
 
-    # -- sampling helpers
-    def _uniform(self, npoly: int, rows: int) -> np.ndarray:
-        q = self.ctx.primes
-        out = np.empty((npoly, rows, self.ctx.N), dtype=np.uint64)
-        for j in range(rows):
-            out[:, j, :] = self.rng.integers(0, q[j], (npoly, self.ctx.N), dtype=np.uint64)
-        return out
-
-    def _noise(self, npoly: int, rows: int) -> np.ndarray:
-        """clipped normal sigma=3.2, |e| <= 19.2, truncated toward zero; coefficient form in every row"""
-        e = self.rng.normal(0.0, 3.2, (npoly, self.ctx.N))
-        bad = np.abs(e) > 19.2
-        while bad.any():
-            e[bad] = self.rng.normal(0.0, 3.2, int(bad.sum()))
-            bad = np.abs(e) > 19.2
-        e = np.trunc(e).astype(np.int64)
-        out = np.empty((npoly, rows, self.ctx.N), dtype=np.uint64)
-        for j in range(rows):
-            out[:, j, :] = np.mod(e, self.ctx.primes[j]).astype(np.uint64)
-        return out
-
     def _encrypt_zero(self, npoly: int, rows: int):
         """npoly fresh symmetric encryptions of zero over the first `rows` primes: returns host (c0, c1)"""
         be, sk = self.ctx.backend, self._sk
-        a = self._uniform(npoly, rows)
-        e = be.from_host(self._noise(npoly, rows))
+        a = be.sample("uniform", self._key32, self._next_stream(), npoly, rows)
+        e = be.sample("noise", self._key32, self._next_stream(), npoly, rows)
         be.ntt_forward(e, npoly, rows, 0)
         sk_rows = be.from_host(sk.host[:rows])
-        as_ = be.multiply_plain(rows, npoly, be.from_host(a), sk_rows)
+        as_ = be.multiply_plain(rows, npoly, a, sk_rows)
         c0 = be.negate(rows, npoly, be.add(rows, npoly, as_, e))
-        return be.to_host(c0), a
+        return (be.to_host(c0).reshape(npoly, rows, self.ctx.N),
+                be.to_host(a).reshape(npoly, rows, self.ctx.N))
 
     def public_key(self):
         c0, c1 = self._encrypt_zero(1, self.ctx.k)
@@ -423,25 +423,18 @@ class KeyGenerator:
 
 
 class Encryptor:
-    def __init__(self, context: SEALContext, public_key: np.ndarray, seed: int = 2):
-        self.ctx, self.pk, self.rng = context, public_key, np.random.default_rng(seed)
+    """(pk0*u + e0 + m, pk1*u + e1) over the plaintext's level in ONE engine call (hefx_encrypt: sampling, NTT and
+    the dyadic arithmetic all on the GPU).  seed=None draws the sampler key from the OS."""
+
+    def __init__(self, context: SEALContext, public_key: np.ndarray, seed: Optional[int] = 2):
+        self.ctx, self.pk = context, public_key
+        self._pk_dev = context.backend.from_host(np.ascontiguousarray(public_key))  # [2][k][N]
+        self._key32, self._stream = _key32(seed), 0
 
     def encrypt(self, plain: Plaintext, destination: Optional[Ciphertext] = None) -> Ciphertext:
-        """(pk0*u + e0 + m, pk1*u + e1) over the plaintext's level (non-hot path)."""
-        ctx, be = self.ctx, self.ctx.backend
-        L, N, q = plain.parms_id(), ctx.N, ctx.primes
-        tern = self.rng.integers(-1, 2, N)
-        u = np.empty((1, L, N), dtype=np.uint64)
-        e = np.empty((2, L, N), dtype=np.uint64)
-        en = np.trunc(np.clip(self.rng.normal(0.0, 3.2, (2, N)), -19.2, 19.2)).astype(np.int64)
-        for j in range(L):
-            u[0, j] = np.where(tern < 0, q[j] - 1, tern).astype(np.uint64)
-            e[:, j, :] = np.mod(en, q[j]).astype(np.uint64)
-        uh = be.ntt_forward(be.from_host(u), 1, L, 0)
-        eh = be.ntt_forward(be.from_host(e), 2, L, 0)
-        pk = be.from_host(np.ascontiguousarray(self.pk[:, :L, :]))
-        c = be.add(L, 2, be.multiply_plain(L, 2, pk, uh), eh)
-        c = be.add_plain(L, 2, c, plain.data)
+        L = plain.parms_id()
+        self._stream += 1
+        c = self.ctx.backend.encrypt(L, self._pk_dev, plain.data, self._key32, self._stream)
         out = destination if destination is not None else Ciphertext()
         return out._set(c, 2, L, plain.scale)
 
@@ -451,16 +444,11 @@ class Decryptor:
         self.ctx, self.sk = context, secret_key
 
     def decrypt(self, encrypted: Ciphertext, destination: Optional[Plaintext] = None) -> Plaintext:
-        """c0 + c1 s (+ c2 s^2): handles size-3 ciphertexts (/root/reference/matrix_multiplication.cpp:419)."""
-        be, L, N = self.ctx.backend, encrypted.parms_id(), self.ctx.N
-        s = be.from_host(self.sk.host[:L])
-        host = be.to_host(encrypted.data)
-        acc = be.from_host(host[encrypted.size() - 1][None])
-        for p in range(encrypted.size() - 2, -1, -1):
-            acc = be.multiply_plain(L, 1, acc, s)
-            acc = be.add(L, 1, acc, be.from_host(host[p][None]))
+        """c0 + c1 s (+ c2 s^2): handles size-3 ciphertexts (/root/reference/matrix_multiplication.cpp:419);
+        one engine call (hefx_decrypt)."""
+        L = encrypted.parms_id()
         out = destination if destination is not None else Plaintext()
-        out.data = be.from_host(be.to_host(acc)[0])
+        out.data = self.ctx.backend.decrypt(L, encrypted.size(), encrypted.data, self.sk.data)
         out._parms_id, out._scale = L, encrypted.scale
         return out
 

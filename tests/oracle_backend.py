@@ -73,6 +73,30 @@ class OracleBackend:
         return [self.o.rotate_mulplain(self._ct(c, 2, L), e, k, np.ascontiguousarray(p).reshape(L, self.N))
                 for c, e, k, p in zip(cts, elts, keys, pts)]
 
+    # ---- sampling / encrypt / decrypt: the same composition hefx_encrypt / hefx_decrypt run on the GPU
+    def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
+        return self.o.sample(kind, key32, stream_id, npoly, nrows, mod_first)
+
+    def encrypt(self, L, pk, plain, key32, stream_id):
+        u = self.o.sample("ternary", key32, 4 * stream_id + 0, 1, L)
+        e = np.concatenate([self.o.sample("noise", key32, 4 * stream_id + 1, 1, L),
+                            self.o.sample("noise", key32, 4 * stream_id + 2, 1, L)])
+        self.ntt_forward(u, 1, L)
+        self.ntt_forward(e, 2, L)
+        pkL = np.ascontiguousarray(np.asarray(pk).reshape(2, self.k, self.N)[:, :L, :])
+        c = self.o.add(self.o.multiply_plain(pkL, u[0]), e)
+        if plain is not None:
+            c = self.o.add_plain(c, np.ascontiguousarray(plain).reshape(L, self.N))
+        return c
+
+    def decrypt(self, L, size, ct, sk):
+        s = np.ascontiguousarray(np.asarray(sk).reshape(-1, self.N)[:L])
+        c = self._ct(ct, size, L)
+        acc = c[size - 1][None].copy()
+        for p in range(size - 2, -1, -1):
+            acc = self.o.add(self.o.multiply_plain(acc, s), c[p][None])
+        return acc[0]
+
     def relinearize(self, L, ct3, key):
         return self.o.relinearize(self._ct(ct3, 3, L), key)
 
