@@ -145,6 +145,24 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
                                 const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                 const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
 
+/* ---- HOISTED rotations -- a separate fast mode, NOT bit-identical to Evaluator::rotate_vector.
+ *      n rotations of ONE ciphertext share its digit decomposition: INTT + digit x modulus NTTs of c1 are done once,
+ *      each rotation gathers them through its Galois table, multiplies with its key and mods down --
+ *      (L+1)(L+2) -> 2 + 2L transforms per rotation.  Difference to SEAL's sequence: the automorphism negates the
+ *      coefficients that wrap; SEAL re-decomposes the rotated polynomial (digit of -a = q_i - a, lifted as a
+ *      positive integer), the hoisted form carries the sign through the lift (-a).  Both are exact key switches of
+ *      the same rotated ciphertext with the same noise bound; the RNS words differ.  Parity: bit-exact against the
+ *      oracle's statement of THIS algorithm (orc_apply_galois_hoisted) and equal decryptions to CKKS precision.
+ *      d_pts may be NULL (no fused multiply_plain); outputs must not alias the source. */
+int hefx_rotate_hoisted_batch(hefx_context *ctx, int L, const uint64_t *d_ct_in, int n, const uint32_t *galois_elts,
+                              const uint64_t *const *d_keys, const uint64_t *const *d_pts, uint64_t *const *d_ct_out,
+                              void *stream);
+/* Linear_Transform_Plain with the d-1 rotations of ct_new hoisted; needs a DIRECT Galois key for every step 1..d-1
+ * (keygen.galois_keys(steps)); the -d rotation is a regular one. */
+int hefx_linear_transform_plain_hoisted(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
+                                        const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
+                                        const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
+
 /* ---- CKKSEncoder::encode(vector<double>, scale, plain) on the GPU (call sites
  *      matrix_mult_benchmark.cpp:291-323, logistic_regression_ckks.cpp:222-225,302-305, helper.h:333-343):
  *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->

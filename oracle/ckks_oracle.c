@@ -493,7 +493,13 @@ int orc_is_transparent(const orc_ctx *c, int L, int size, const uint64_t *ct)
 /* ------------------------------------------------------------------------------------------------
  * key switching (App. A.8): RNS digits, one special prime P = primes[k-1], rounded division by P.
  * ---------------------------------------------------------------------------------------------- */
-void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key)
+/* tab == NULL: SEAL's key switch of `target` (App. A.8).
+ * tab != NULL: the HOISTED variant (csrc/hefx_keyswitch.hip, ks_mac_hoisted_kernel): `target` is
+ * the UNROTATED c1; its digits are extended to every modulus once and each extended row is read through the Galois
+ * gather table, i.e. the automorphism is applied AFTER the decomposition.  Not SEAL's bits: where the automorphism
+ * negates a coefficient, SEAL's digit is q_i - a (positive lift) and this one is -a. */
+static void switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key,
+                            const uint32_t *tab)
 {
     const uint64_t n = c->N;
     const int k = c->k, sp = k - 1; /* special-prime index at key level */
@@ -512,6 +518,7 @@ void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *targe
     memset(acc, 0, acc_words * sizeof(u128));
     uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * n);
     uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t *xg = (uint64_t *)malloc(sizeof(uint64_t) * n);
 
     for (int i = 0; i < L; i++) {
         memcpy(d, target + (size_t)i * n, sizeof(uint64_t) * n);
@@ -529,6 +536,10 @@ void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *targe
                     memcpy(x, d, sizeof(uint64_t) * n);
                 orc_ntt_fwd(c, mi, x);
                 xs = x;
+            }
+            if (tab) {
+                for (uint64_t a = 0; a < n; a++) xg[a] = xs[tab[a]];
+                xs = xg;
             }
             for (int cc = 0; cc < 2; cc++) {
                 const uint64_t *kr = key + ((((size_t)i * 2 + cc) * k) + mi) * n;
@@ -563,6 +574,31 @@ void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *targe
     }
     free(d);
     free(x);
+    free(xg);
+}
+
+void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key)
+{
+    switch_key_impl(c, L, ct, target, key, NULL);
+}
+
+/* hoisted rotation: c0' = perm(c0) + ks0, c1' = ks1 with the key switch of the hoisted variant above */
+void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
+                              uint64_t *ct_out)
+{
+    const uint64_t n = c->N;
+    uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint64_t *res = (uint64_t *)calloc((size_t)2 * L * n, sizeof(uint64_t));
+    orc_galois_table(n, elt, tab);
+    for (int j = 0; j < L; j++) {
+        const uint64_t *s0 = ct_in + (size_t)j * n;
+        uint64_t *r0 = res + (size_t)j * n;
+        for (uint64_t i = 0; i < n; i++) r0[i] = s0[tab[i]];
+    }
+    switch_key_impl(c, L, res, ct_in + (size_t)L * n, key, tab);
+    memcpy(ct_out, res, sizeof(uint64_t) * (size_t)2 * L * n);
+    free(tab);
+    free(res);
 }
 
 /* apply_galois_inplace, CKKS size-2 (App. A.7): c0' = perm(c0) + ks0, c1' = ks1 */

@@ -106,6 +106,10 @@ void orc_encode(const orc_ctx *c, int L, const double *vals_ri, int nvals, doubl
 void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, double *vals_ri);
 
 
+/* hoisted rotation (fast mode of csrc/hefx_keyswitch.hip; not SEAL's bits, see ckks_oracle.c) */
+void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
+                              uint64_t *ct_out);
+
 /* ---- counter-mode sampling: CPU statement of csrc/hefx_sample.hip (see ckks_oracle.c for the specification) */
 void orc_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
 void orc_noise_thresholds(uint64_t t[39]);

@@ -68,6 +68,7 @@ def lib():
     sig("orc_is_transparent", i, vp, i, i, u64p)
     sig("orc_switch_key", None, vp, i, u64p, u64p, u64p)
     sig("orc_apply_galois", None, vp, i, u64p, u64, u64p, u64p)
+    sig("orc_apply_galois_hoisted", None, vp, i, u64p, u64, u64p, u64p)
     sig("orc_relinearize", None, vp, i, u64p, u64p, u64p)
     sig("orc_rescale", None, vp, i, i, u64p, u64p, i)
     sig("orc_mod_drop", None, vp, i, i, i, u64p, u64p)
@@ -214,6 +215,12 @@ class Oracle:
     def apply_galois(self, ct, elt, key):
         out = np.zeros_like(ct)
         lib().orc_apply_galois(self._h, ct.shape[1], ct, elt, key, out)
+        return out
+
+    def apply_galois_hoisted(self, ct, elt, key):
+        """hoisted-rotation fast mode (decompose, then permute): NOT SEAL's bits, see ckks_oracle.c"""
+        out = np.zeros_like(ct)
+        lib().orc_apply_galois_hoisted(self._h, ct.shape[1], np.ascontiguousarray(ct), elt, key, out)
         return out
 
     def switch_key(self, ct, target, key):

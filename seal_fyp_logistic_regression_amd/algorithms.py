@@ -82,9 +82,16 @@ def _rotations_batched(ev: Evaluator, ct: Ciphertext, steps: Sequence[int], gal_
 
 
 def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
-                           gal_keys: KSwitchKeys) -> Ciphertext:
-    """Linear_Transform_Plain, helper.h:237-262 (= linear_transformation2.cpp:149-174)."""
+                           gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
+    """Linear_Transform_Plain, helper.h:237-262 (= linear_transformation2.cpp:149-174).
+
+    hoisted=True is the fast mode of SURVEY 8f rank 3: the d-1 rotations of ct_new share one digit decomposition
+    (hefx_rotate_hoisted_batch).  It needs a direct Galois key per step (keygen.galois_keys(steps)) and is NOT
+    bit-identical to the reference's sequence (signed instead of positive digit lifts where the automorphism
+    negates a coefficient); it decrypts to the same values with the same noise bound."""
     d = len(U_diagonals)
+    if hoisted:
+        return _linear_transform_plain_hoisted(ev, ct, U_diagonals, gal_keys)
     native = getattr(ev.be, "linear_transform_plain", None)
     if native is not None:  # the HIP engine runs the whole transform behind one C-ABI call, same bits
         return _linear_transform_plain_native(ev, native, ct, U_diagonals, gal_keys)
@@ -95,8 +102,32 @@ def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[
     return ev.add_many(res)                                          # :259
 
 
+def _linear_transform_plain_hoisted(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
+                                    gal_keys: KSwitchKeys) -> Ciphertext:
+    d, L = len(U_diagonals), ct.parms_id()
+    plans = [ev.rotation_plan(l, gal_keys) for l in range(1, d)]
+    if any(len(p) != 1 for p in plans):
+        raise ValueError("hoisted linear transform needs a direct Galois key for every step 1..d-1")
+    native = getattr(ev.be, "linear_transform_plain", None)
+    if native is not None:  # one C-ABI call (hefx_linear_transform_plain_hoisted)
+        return _linear_transform_plain_native(ev, native, ct, U_diagonals, gal_keys, hoisted=True)
+    ct_new = ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))          # helper.h:244-247, regular rotation
+    res = [ev.multiply_plain(ct_new, U_diagonals[0])]                # :250
+    for p in U_diagonals[1:]:
+        if p.parms_id() != L:
+            raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
+        ev._check_scale(ct_new.scale * p.scale, L)
+        if p.is_zero:
+            raise RuntimeError("result ciphertext is transparent")
+    elts = [p[0] for p in plans]
+    outs = ev.be.rotate_hoisted_batch(L, ct_new.data, elts, [gal_keys.key(e) for e in elts],
+                                      [p.data for p in U_diagonals[1:]])
+    res += [Ciphertext()._set(o, 2, L, ct_new.scale * p.scale) for o, p in zip(outs, U_diagonals[1:])]
+    return ev.add_many(res)                                          # :259
+
+
 def _linear_transform_plain_native(ev: Evaluator, native, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
-                                   gal_keys: KSwitchKeys) -> Ciphertext:
+                                   gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
     """Same checks and bookkeeping as the op-by-op path (SEAL's exceptions), arithmetic in hefx_linear_transform_plain."""
     L = ct.parms_id()
     if ct.size() != 2:
@@ -112,10 +143,10 @@ def _linear_transform_plain_native(ev: Evaluator, native, ct: Ciphertext, U_diag
         scale = s if scale is None else scale
         if p.is_zero:
             raise RuntimeError("result ciphertext is transparent")
-    for l in [-len(U_diagonals)] + list(range(1, len(U_diagonals))):
-        ev.rotation_plan(l, gal_keys)  # raises "Galois key not present" / "step count too large" like rotate_vector
+    # missing keys / too large steps come back from the engine with SEAL's messages (ValueError)
     elts = sorted(gal_keys.keys)
-    data = native(L, ct.data, [p.data for p in U_diagonals], elts, [gal_keys.key(e) for e in elts])
+    data = native(L, ct.data, [p.data for p in U_diagonals], elts, [gal_keys.key(e) for e in elts],
+                  **({"hoisted": True} if hoisted else {}))
     return Ciphertext()._set(data, 2, L, scale)
 
 

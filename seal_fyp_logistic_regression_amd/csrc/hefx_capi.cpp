@@ -627,7 +627,7 @@ static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t
 // the next; the caller's stream is forked before and joined after.
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
-                  uint64_t *const *ct_out, void *stream)
+                  uint64_t *const *ct_out, void *stream, bool hoist = false)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
@@ -649,6 +649,13 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // fused digit-NTT + MAC kernel (no x scratch at all) when enabled and N <= 16384 (longer rows do not fit the
     // 8-coefficient-per-thread workgroup); the launcher takes sub < 0 as "fused"
     const bool fused = c->fused && c->logn <= 14;
+    // hoisting (explicit, hefx_*_hoisted): every item rotates the same source, decomposed once per chunk
+    if (hoist) {
+        if (relin) return fail(HEFX_ERR_INVALID, "hoisting applies to rotations only");
+        for (int i = 0; i < n; ++i)
+            if (ct_in[i] != ct_in[0] || ct_out[i] == ct_in[0])
+                return fail(HEFX_ERR_INVALID, "hoisted batch: one shared source, never overwritten");
+    }
     const int cmax = n < chunk ? n : chunk;
     const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax));
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
@@ -706,7 +713,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
         HIPCHK(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, cs, prof));
+        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, cs, prof));
         HIPCHK(hipEventRecord(c->ring_ev[slot], cs));
         c->ring_busy[slot] = true;
     }
@@ -951,30 +958,29 @@ void lt_naf(int value, std::vector<int> &out)  // SEAL util::naf: least signific
         if (zi) out.push_back((neg ? -zi : zi) * (1 << i));
     }
 }
-// Galois elements rotate_vector(steps) applies, in order; false if a key is missing / the step is out of range
-bool lt_plan(int steps, size_t n, const LtKeys &keys, std::vector<uint32_t> &plan)
+// Galois elements rotate_vector(steps) applies, in order; nullptr on success, else SEAL's exception text
+const char *lt_plan(int steps, size_t n, const LtKeys &keys, std::vector<uint32_t> &plan)
 {
-    if (steps == 0) return true;
-    if ((size_t)(steps < 0 ? -steps : steps) >= n / 2) return false;
+    if (steps == 0) return nullptr;
+    if ((size_t)(steps < 0 ? -steps : steps) >= n / 2) return "step count too large";
     const uint32_t e = lt_elt_from_step(steps, n);
     if (keys.has(e)) {
         plan.push_back(e);
-        return true;
+        return nullptr;
     }
     std::vector<int> terms;
     lt_naf(steps, terms);
-    if (terms.size() == 1) return false;
+    if (terms.size() == 1) return "Galois key not present";
     for (int t : terms) {
         if ((size_t)(t < 0 ? -t : t) == n / 2) continue;
-        if (!lt_plan(t, n, keys, plan)) return false;
+        if (const char *err = lt_plan(t, n, keys, plan)) return err;
     }
-    return true;
+    return nullptr;
 }
 }  // namespace
 
-extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,
-                                           const uint64_t *const *diag_pts, int nkeys, const uint32_t *key_elts,
-                                           const uint64_t *const *keys, uint64_t *out, void *stream)
+static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint64_t *const *diag_pts, int nkeys,
+                   const uint32_t *key_elts, const uint64_t *const *keys, uint64_t *out, void *stream, bool hoisted)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
@@ -990,7 +996,7 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
     const size_t N = c->n, ctw = 2 * (size_t)L * N;
     // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
     std::vector<uint32_t> first;
-    if (!lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, "Galois key not present");
+    if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
     struct Node {
         int parent;  // -1: ct_new
         uint32_t elt;
@@ -1004,7 +1010,9 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
     std::vector<uint32_t> plan;
     for (int l = 1; l < d; ++l) {
         plan.clear();
-        if (!lt_plan(l, N, K, plan) || plan.empty()) return fail(HEFX_ERR_INVALID, "Galois key not present");
+        if (const char *err = lt_plan(l, N, K, plan)) return fail(HEFX_ERR_INVALID, err);
+        if (hoisted && plan.size() != 1)
+            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
         int cur = -1;
         for (size_t t = 0; t < plan.size(); ++t) {
             const int fused = t + 1 == plan.size() ? l : -1;
@@ -1061,7 +1069,7 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
             }
             if (in.empty()) continue;
             if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
-                                fused ? pp.data() : nullptr, oo.data(), stream))
+                                fused ? pp.data() : nullptr, oo.data(), stream, hoisted))
                 return rc;
         }
     // ---- out = add_many(res)               (helper.h:259)
@@ -1069,6 +1077,31 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
     res[0] = prod0;
     for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
     return hefx_add_many(c, L, 2, d, res.data(), out, stream);
+}
+
+extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,
+                                           const uint64_t *const *diag_pts, int nkeys, const uint32_t *key_elts,
+                                           const uint64_t *const *keys, uint64_t *out, void *stream)
+{
+    return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, false);
+}
+extern "C" int hefx_linear_transform_plain_hoisted(hefx_context *c, int L, const uint64_t *ct, int d,
+                                                   const uint64_t *const *diag_pts, int nkeys,
+                                                   const uint32_t *key_elts, const uint64_t *const *keys,
+                                                   uint64_t *out, void *stream)
+{
+    return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, true);
+}
+extern "C" int hefx_rotate_hoisted_batch(hefx_context *c, int L, const uint64_t *ct_in, int n, const uint32_t *elts,
+                                         const uint64_t *const *keys, const uint64_t *const *pts,
+                                         uint64_t *const *ct_out, void *stream)
+{
+    if (n < 1 || !ct_in) return fail(HEFX_ERR_INVALID, "bad hoisted batch arguments");
+    if (pts)
+        for (int i = 0; i < n; ++i)
+            if (!pts[i]) return fail(HEFX_ERR_INVALID, "null plaintext pointer in batch");
+    std::vector<const uint64_t *> in((size_t)n, ct_in);
+    return ks_run(c, L, n, false, in.data(), elts, keys, nullptr, pts, ct_out, stream, true);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -83,7 +83,7 @@ struct KsProf {
     int cap, used;
 };
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
-                                  const KsScratch &scr, int sub, hipStream_t s, KsProf *prof);
+                                  const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof);
 // out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
 hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
                               int mod_first, hipStream_t s);

@@ -22,10 +22,24 @@
 #include "hefx_ntt.cuh"
 #include "hefx_ntt8.cuh"
 
-// minimum waves per SIMD the NTT workgroups are register-allocated for (second __launch_bounds__ argument)
-#ifndef HEFX_WAVES
-#define HEFX_WAVES 4
+// Minimum waves per SIMD the NTT workgroups are register-allocated for (second __launch_bounds__ argument):
+// 4 caps a kernel at 128 VGPRs, 2 lets it use 256.  Measured per kernel and size on MI355X (bench workload,
+// us per 256- / 192-item chunk, "4" vs "2"):
+//   N = 8192 : inverse digits 85 vs 52, digit NTTs 152 vs 124, mod-down finish 364 vs 285 -> 2 everywhere (at 4 the
+//              256-thread workgroups spill up to 148 B/lane; at 2 three of them still share a CU)
+//   N = 16384: inverse digits 138 vs 107 -> 2;  digit NTTs 455 vs 489, mod-down finish 318 vs 436 -> 4 (one
+//              512-thread workgroup per CU cannot overlap its memory phases with another's butterflies)
+//   N = 32768: 1024-thread workgroups own the whole register file at 128 VGPRs either way.
+// -DHEFX_WAVES=n overrides every kernel (tools/build_variant.sh).
+template <int LOGN>
+struct KsWaves {
+#ifdef HEFX_WAVES
+    static constexpr int INV = HEFX_WAVES, FWD = HEFX_WAVES;
+#else
+    static constexpr int INV = LOGN <= 14 ? 2 : 4;  // ks_intt_digits, ks_moddown_intt, rs_intt
+    static constexpr int FWD = LOGN <= 13 ? 2 : 4;  // ks_ntt_digits, ks_moddown_finish, rs_finish
 #endif
+};
 
 namespace hefx {
 
@@ -65,13 +79,16 @@ __device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j
 // (0) preparation: x[b][i][i] = perm_g(c1[i]) (or c2[i] for relinearisation), p0[b][j] = perm_g(c0[j]).
 // Plain gather at full occupancy; two outputs (16 B store) per lane.
 // ------------------------------------------------------------------------------------------------
+// row0 / noperm: the hoisted path prepares the shared source once (rows [0,L) of item 0, copied unpermuted) and
+// perm_g(c0) per item (rows [L,2L)).
 __global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
-                                                         KsScratch S)
+                                                         int row0, int noperm, KsScratch S)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
-    const int row = blockIdx.y, b = blockIdx.z;
-    const KsItem it = items[b];
+    const int row = blockIdx.y + row0, b = blockIdx.z;
+    KsItem it = items[b];
+    if (noperm) it.perm = nullptr;
     const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
     const u64 *__restrict__ src;
     u64 *__restrict__ dst;
@@ -97,7 +114,7 @@ __global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, const KsIt
 // (1) digit i of item b: d[b][i] (EO) = INTT_{q_i}(x[b][i][i])
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_intt_digits_kernel(DevTables T, int L, int rows,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_kernel(DevTables T, int L, int rows,
                                                                               KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
@@ -121,7 +138,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_intt_digits_
 // (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
                                                                              int item0, KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
@@ -230,6 +247,40 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
 }
 
 // ------------------------------------------------------------------------------------------------
+// (3h) hoisted MAC: all items of the chunk rotate the SAME source ciphertext (the d-1 rotations of a linear
+// transform with direct Galois keys).  The digit decomposition commutes with the Galois permutation --
+// [perm_g(c1)]_(q_i) = perm_g([c1]_(q_i)) coefficient-wise, and NTT_m(a(X^g)) = perm_g(NTT_m(a)) -- so the digit x
+// modulus products x[i][jj] of the UNPERMUTED source are computed once ((1),(2) with one item) and every item
+// reads them through its gather table:  acc[b][c][jj][w] = sum_i x[i][jj][perm_b[w]] * key_b[i][c][m][w].
+// Same integers as the per-item path, hence the same bits; per item only the MAC and the mod-down remain
+// ((L+1)(L+2) -> 2 + 2L transforms).  The gathered rows are L2-resident (one source), the keys stream from HBM.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const KsItem *__restrict__ items, int L,
+                                                             KsScratch S)
+{
+    const int logn = T.logn;
+    const size_t n = (size_t)1 << logn;
+    const int jj = blockIdx.y, b = blockIdx.z;
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
+    const KsItem it = items[b];
+    const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
+    MacAcc A;
+    for (int i = 0; i < L; ++i) {
+        const u64 *__restrict__ xrow = i == jj ? S.xd + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
+        ulonglong2 x;
+        x.x = xrow[pi.x];
+        x.y = xrow[pi.y];
+        const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
+        const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
+        const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
+        A.mac(x, k0, k1);
+    }
+    A.store(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n, w, mc);
+}
+
+// ------------------------------------------------------------------------------------------------
 // (2+3 fused) acc[b][c][jj] = sum_i NTT_m([d[b][i]]_m) * key[i][c][m] for one half h of one target modulus jj:
 // the workgroup walks the L digits, transforms each one (8 coefficients per thread, hefx_ntt8.cuh) and multiplies
 // the result straight into two 128-bit accumulators per coefficient that live in registers for the whole loop.
@@ -322,7 +373,7 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, (FusedCfg<LOGN>::T >= 1024 ? 4 :
 // (4) u[b][c] (EO) = (INTT_P(acc[b][c][P]) + floor(P/2)) mod P
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_intt_kernel(DevTables T, int L, int rows,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_moddown_intt_kernel(DevTables T, int L, int rows,
                                                                                KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
@@ -407,7 +458,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ks_moddown_finish_kernel(DevTables T,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_moddown_finish_kernel(DevTables T,
                                                                                  const KsItem *__restrict__ items, int L,
                                                                                  int relin, int rows, KsScratch S)
 {
@@ -436,7 +487,7 @@ static void set_lds(K kernel, size_t bytes)
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                           const KsScratch &scr, int sub, hipStream_t s, KsProf *prof)
+                                           const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -462,9 +513,28 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             prof->stage[prof->used++] = stage;
         }
     };
+    if (hoist) {  // one shared source (item 0's ciphertext, unpermuted); per item only perm(c0), MAC, mod-down
+        mark(0);
+        hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, batch, L, 0, 0, 1, scr);
+        hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, n), dim3(256), 0, s, T, batch, L, 0, L, 0, scr);
+        mark(1);
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
+        mark(2);
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, scr);
+        mark(3);
+        hipLaunchKernelGGL(ks_mac_hoisted_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
+        mark(4);
+        hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2,
+                           scr);
+        mark(5);
+        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch,
+                           L, 0, n * 2, scr);
+        mark(-1);
+        return hipGetLastError();
+    }
     mark(0);
     hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, relin ? L : 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
-                       scr);
+                       0, 0, scr);
     mark(1);
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
     if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
@@ -509,9 +579,9 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     }
 
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                  const KsScratch &scr, int sub, hipStream_t s, KsProf *prof)
+                                  const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof)
 {
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, s, prof)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }
@@ -520,7 +590,7 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 // K8: rescale_to_next, SEAL 3.4.x floor variant (App. A.9): per poly 1 INTT + (L-1) NTT.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void rs_intt_kernel(DevTables T, int L, int rows, const u64 *in,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt_kernel(DevTables T, int L, int rows, const u64 *in,
                                                                        u64 *d)
 {
     using SC = SplitCfg<LOGN>;
@@ -540,7 +610,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void rs_intt_kernel(
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void rs_finish_kernel(DevTables T, int L, int rows, const u64 *in,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_finish_kernel(DevTables T, int L, int rows, const u64 *in,
                                                                          const u64 *d, u64 *out)
 {
     using SC = SplitCfg<LOGN>;
@@ -613,7 +683,7 @@ hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const 
 // rows do not fit one workgroup's LDS; smaller N use the in-place single-workgroup kernels.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN, bool INV>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, HEFX_WAVES) void ntt_split_rows_kernel(DevTables T, const u64 *src, u64 *dst,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ntt_split_rows_kernel(DevTables T, const u64 *src, u64 *dst,
                                                                               int rows, int nrows, int mod_first)
 {
     using SC = SplitCfg<LOGN>;

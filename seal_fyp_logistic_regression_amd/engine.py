@@ -5,7 +5,7 @@ Payloads are flat uint64 arrays in SEAL's layout ([size][L][N], NTT form, canoni
 from __future__ import annotations
 
 import ctypes as C
-from typing import Optional, Sequence
+from typing import List,  Optional, Sequence
 
 import numpy as np
 
@@ -96,6 +96,15 @@ class Engine:
             pass
 
     # ---- memory
+    def empty_many(self, n: int, shape) -> List[DeviceArray]:
+        """n equally shaped buffers as views of ONE allocation (hipMalloc / hipFree are slow and hipFree synchronises
+        the device; a batch of outputs is one slab whose views keep it alive)"""
+        words = 1
+        for d in shape:
+            words *= int(d)
+        slab = DeviceArray(self, (max(n, 1) * words,))
+        return [slab.view(i * words, shape) for i in range(n)]
+
     def empty(self, *shape) -> DeviceArray:
         return DeviceArray(self, shape)
 
@@ -186,7 +195,7 @@ class Engine:
 
     def apply_galois_batch(self, L, cts, elts, keys, outs=None, stream=None):
         n = len(cts)
-        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
         capi.check(capi.lib().hefx_apply_galois_batch(
             self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
             capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([o.ptr for o in outs]), stream))
@@ -194,7 +203,7 @@ class Engine:
 
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs=None, stream=None):
         n = len(cts)
-        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
         capi.check(capi.lib().hefx_rotate_multiply_plain_batch(
             self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
             capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([p.ptr for p in pts]),
@@ -208,7 +217,7 @@ class Engine:
 
     def relinearize_batch(self, L, ct3s, key, outs=None, stream=None):
         n = len(ct3s)
-        outs = outs if outs is not None else [DeviceArray(self, (2, L, self.N)) for _ in range(n)]
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
         capi.check(capi.lib().hefx_relinearize_batch(
             self._h, L, n, capi.ptr_array([c.ptr for c in ct3s]), key.ptr,
             capi.ptr_array([o.ptr for o in outs]), stream))
@@ -230,10 +239,21 @@ class Engine:
         capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
         return buf
 
-    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, out=None, stream=None):
-        """Linear_Transform_Plain in one native call (hefx_linear_transform_plain)"""
+    def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None, outs=None, stream=None):
+        """n rotations of ONE ciphertext sharing its digit decomposition (fast mode, not bit-identical to rotate_vector)"""
+        n = len(elts)
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
+        capi.check(capi.lib().hefx_rotate_hoisted_batch(
+            self._h, L, ct.ptr, n, capi.u32_array(elts), capi.ptr_array([k.ptr for k in keys]),
+            capi.ptr_array([p.ptr for p in pts]) if pts is not None else None,
+            capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
+    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, out=None, stream=None, hoisted=False):
+        """Linear_Transform_Plain in one native call (hefx_linear_transform_plain[_hoisted])"""
         out = out if out is not None else DeviceArray(self, (2, L, self.N))
-        capi.check(capi.lib().hefx_linear_transform_plain(
+        f = capi.lib().hefx_linear_transform_plain_hoisted if hoisted else capi.lib().hefx_linear_transform_plain
+        capi.check(f(
             self._h, L, ct.ptr, len(diag_pts), capi.ptr_array([p.ptr for p in diag_pts]), len(keys),
             capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
         return out

@@ -165,8 +165,11 @@ class GpuBackend:
     def reduce_canonical(self, L, size, h, addends):
         return self.engine.reduce_canonical(L, size, h, addends)
 
-    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys):
-        return self.engine.linear_transform_plain(L, ct, diag_pts, key_elts, keys)
+    def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, hoisted=False):
+        return self.engine.linear_transform_plain(L, ct, diag_pts, key_elts, keys, hoisted=hoisted)
+
+    def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None):
+        return self.engine.rotate_hoisted_batch(L, ct, elts, keys, pts)
 
     def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
         return self.engine.sample(kind, key32, stream_id, npoly, nrows, mod_first)
@@ -584,6 +587,7 @@ class Evaluator:
 
     def __init__(self, context: SEALContext):
         self.ctx, self.be = context, context.backend
+        self._bitcount: Dict[int, int] = {}
 
     # ---- checks shared with SEAL
     @staticmethod
@@ -595,7 +599,10 @@ class Evaluator:
             raise ValueError("encrypted1 and encrypted2 parameter mismatch")
 
     def _check_scale(self, new_scale: float, parms_id: int):
-        if new_scale <= 0 or int(math.log2(new_scale)) >= ContextData(self.ctx, parms_id).total_coeff_modulus_bit_count():
+        bits = self._bitcount.get(parms_id)
+        if bits is None:
+            bits = self._bitcount[parms_id] = ContextData(self.ctx, parms_id).total_coeff_modulus_bit_count()
+        if new_scale <= 0 or int(math.log2(new_scale)) >= bits:
             raise ValueError("scale out of bounds")
 
     # ---- add / sub / negate

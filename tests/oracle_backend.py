@@ -97,6 +97,13 @@ class OracleBackend:
             acc = self.o.add(self.o.multiply_plain(acc, s), c[p][None])
         return acc[0]
 
+    def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None):
+        c = self._ct(ct, 2, L)
+        outs = [self.o.apply_galois_hoisted(c, e, k) for e, k in zip(elts, keys)]
+        if pts is not None:
+            outs = [self.o.multiply_plain(r, np.ascontiguousarray(p).reshape(L, self.N)) for r, p in zip(outs, pts)]
+        return outs
+
     def relinearize(self, L, ct3, key):
         return self.o.relinearize(self._ct(ct3, 3, L), key)
 

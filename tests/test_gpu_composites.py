@@ -236,3 +236,41 @@ def test_logistic_regression_step_bit_exact():
     assert np.allclose(decode(eg, pg, 3), c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3, atol=5e-3)
     xs = np.array([0.8, -0.3])
     assert np.allclose(decode(eg, tg, 2), c[0] + c[1] * xs + c[2] * xs ** 2 + c[3] * xs ** 3, atol=1e-3)
+
+
+def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
+    """Direct keys for every step (keygen.galois_keys(steps)): SEAL then applies ONE key switch per rotation and the
+    regular path stays bit-exact.  hoisted=True additionally shares the digit decomposition of ct_new across the
+    d-1 rotations: a different algorithm (not SEAL's bits) -- bit-exact against the oracle twin running the hoisted
+    oracle, and the same decrypted values to CKKS precision."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    rng = np.random.default_rng(9)
+    d = 12
+    M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
+    steps = [-d] + list(range(1, d))
+
+    def run(e):
+        scale = 2.0 ** 40
+        diags = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+        ct = e["enc"].encrypt(e["encoder"].encode(v, scale))
+        assert all(len(e["ev"].rotation_plan(s, e["gk"])) == 1 for s in steps)
+        return (alg.linear_transform_plain(e["ev"], ct, diags, e["gk"]),
+                alg.linear_transform_plain(e["ev"], ct, diags, e["gk"], hoisted=True))
+
+    r = both(8192, [60, 40, 40, 60], run, galois_steps=steps)
+    (eg, (cg, hg)), (eo, (co, ho)) = r["gpu"], r["oracle"]
+    assert (bits(eg, cg) == bits(eo, co)).all()
+    assert (bits(eg, hg) == bits(eo, ho)).all()
+    assert (bits(eg, hg) != bits(eg, cg)).any()
+    assert np.allclose(decode(eg, cg, d), M @ v, atol=1e-5)
+    assert np.allclose(decode(eg, hg, d), M @ v, atol=1e-5)
+    assert np.abs(decode(eg, hg, d) - decode(eg, cg, d)).max() < 1e-5  # two noise samples of ~1e-6
+    # (the GPU side ran hefx_linear_transform_plain_hoisted in one call, the oracle twin the Python composition)
+    e = eg
+    scale = 2.0 ** 40
+    # without direct keys the hoisted mode refuses
+    e2 = make(8192, [60, 40, 40, 60], "gpu")
+    with pytest.raises(ValueError):
+        alg.linear_transform_plain(e2["ev"], e2["enc"].encrypt(e2["encoder"].encode(v, scale)),
+                                   [e2["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)], e2["gk"],
+                                   hoisted=True)

@@ -181,3 +181,32 @@ def test_polynomial_and_logistic_regression_step():
     assert np.allclose(dec(e, pred, 3).real, c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3, atol=5e-3)
     with pytest.raises(ValueError, match="scale out of bounds"):  # reference stops at :336
         alg.update_weights(ev, e["encoder"], e["enc"], feats, featsT, cy, cw, 0.1, e["gk"], e["rk"], scale)
+
+
+def test_hoisted_rotation_is_a_valid_key_switch_but_not_seals_bits(env):
+    """The hoisted fast mode (decompose once, permute the digit transforms): decrypts like rotate_vector, differs in
+    the RNS words, and the hoisted linear transform gives M.v."""
+    e = env
+    ctx, ev, kg = e["ctx"], e["ev"], e["kg"]
+    d = 6
+    steps = [-d] + list(range(1, d))
+    gk = kg.galois_keys(steps)
+    v = np.arange(1.0, 17.0)
+    scale = 2.0 ** 30
+    ct = e["enc"].encrypt(e["encoder"].encode(np.tile(v, ctx.N // 2 // 16), scale))
+    L, be = ct.parms_id(), ctx.backend
+    elts = [S.galois_elt_from_step(s, ctx.N) for s in (1, 3, 5)]
+    outs = be.rotate_hoisted_batch(L, ct.data, elts, [gk.key(x) for x in elts])
+    for s, o_, x in zip((1, 3, 5), outs, elts):
+        got = dec(e, S.Ciphertext()._set(o_, 2, L, ct.scale), 16).real
+        assert np.abs(got - np.roll(v, -s)).max() < 1e-3
+        assert (o_ != be.apply_galois(L, ct.data, x, gk.key(x))).any()
+    rng = np.random.default_rng(1)
+    M, w = rng.standard_normal((d, d)), rng.standard_normal(d)
+    diags = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+    cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+    a = alg.linear_transform_plain(ev, cw, diags, gk)
+    h = alg.linear_transform_plain(ev, cw, diags, gk, hoisted=True)
+    assert np.abs(dec(e, a, d).real - M @ w).max() < 1e-2 and np.abs(dec(e, h, d).real - M @ w).max() < 1e-2
+    with pytest.raises(ValueError, match="direct Galois key"):
+        alg.linear_transform_plain(ev, cw, diags, e["gk"], hoisted=True)

@@ -1,6 +1,9 @@
 """Linear_Transform_Plain (helper.h:237-262) wall time on the MI355X for the dimensions the reference charted
 (FYP Presentation slide 27: N=8192 {60,40,40,60}, d = 10 / 100 / 1000), compute phase only, like the reference's
-timer at linear_transformation.cpp:540-542.  Also times the CPU oracle on the smallest size for scale."""
+timer at linear_transformation.cpp:540-542.  Three modes:
+  naf      the reference's setup: default power-of-two Galois keys, NAF chains (bit-exact to the op-by-op sequence)
+  direct   a direct Galois key per step (keygen.galois_keys(steps)): one key switch per rotation (bit-exact)
+  hoisted  direct keys + shared digit decomposition (fast mode, not SEAL's bits; same decryption)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -10,23 +13,35 @@ from seal_fyp_logistic_regression_amd import seal as S
 N, bits, scale = 8192, [60, 40, 40, 60], 2.0 ** 40
 parms = S.EncryptionParameters("ckks"); parms.set_poly_modulus_degree(N); parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
 ctx = S.SEALContext.Create(parms)
-kg = S.KeyGenerator(ctx, 1); gk = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key()); dec = S.Decryptor(ctx, kg.secret_key())
+kg = S.KeyGenerator(ctx, 1); gk_default = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key()); dec = S.Decryptor(ctx, kg.secret_key())
 encoder, ev = S.CKKSEncoder(ctx), S.Evaluator(ctx)
 rng = np.random.default_rng(0)
-out = {"params": "N=8192 {60,40,40,60} scale 2^40, default (power-of-two) Galois keys", "published_us": {"10": 1.4e5, "100": 1.3e6, "1000": 1.8e7}, "runs": []}
+out = {"params": "N=8192 {60,40,40,60} scale 2^40", "published_us": {"10": 1.4e5, "100": 1.3e6, "1000": 1.8e7}, "runs": []}
 for d in [int(x) for x in (sys.argv[1:] or ["10", "100", "1000"])]:
     M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
-    diags = [encoder.encode(x, scale) for x in alg.get_all_diagonals(M)]
+    diags = encoder.encode_many(list(alg.get_all_diagonals(M)), scale)
     ct = enc.encrypt(encoder.encode(v, scale))
-    ks = sum(len(ev.rotation_plan(s, gk)) for s in [-d] + list(range(1, d)))
-    alg.linear_transform_plain(ev, ct, diags, gk); ctx.backend.engine.sync()
-    reps = 3 if d >= 1000 else 10
-    t = time.perf_counter()
-    for _ in range(reps):
-        r = alg.linear_transform_plain(ev, ct, diags, gk)
-    ctx.backend.engine.sync()
-    dt = (time.perf_counter() - t) / reps
-    err = float(np.abs(encoder.decode(dec.decrypt(r))[:d].real - M @ v).max())
-    out["runs"].append({"d": d, "key_switches_in_SEAL_order": ks, "gpu_us": dt * 1e6, "max_abs_err": err})
-    print(out["runs"][-1], flush=True)
+    steps = [-d] + list(range(1, d))
+    t0 = time.perf_counter()
+    gk_direct = kg.galois_keys(steps)
+    keygen_s = time.perf_counter() - t0
+    for mode, gk, hoisted in (("naf", gk_default, False), ("direct", gk_direct, False), ("hoisted", gk_direct, True)):
+        ks = sum(len(ev.rotation_plan(s, gk)) for s in steps)
+        alg.linear_transform_plain(ev, ct, diags, gk, hoisted=hoisted); ctx.backend.engine.sync()
+        reps = 3 if d >= 1000 else 10
+        eng = ctx.backend.engine
+        e0, e1 = eng.event(), eng.event()
+        t = time.perf_counter()
+        eng.event_record(e0)
+        for _ in range(reps):
+            r = alg.linear_transform_plain(ev, ct, diags, gk, hoisted=hoisted)
+        eng.event_record(e1)
+        eng.sync()
+        dt = (time.perf_counter() - t) / reps
+        busy = eng.event_elapsed_ms(e0, e1) / reps * 1e3
+        err = float(np.abs(encoder.decode(dec.decrypt(r))[:d].real - M @ v).max())
+        out["runs"].append({"d": d, "mode": mode, "key_switches_in_SEAL_order": ks, "gpu_us": dt * 1e6, "hip_event_us": busy,
+                            "max_abs_err": err, "direct_keygen_s": keygen_s if mode != "naf" else None})
+        print(out["runs"][-1], flush=True)
+    del gk_direct
 print(json.dumps(out))
