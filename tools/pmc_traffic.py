@@ -1,0 +1,42 @@
+#!/usr/bin/env python3
+"""Folds the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes)
+of the bench command into profiles/<round>_bench_pmc_traffic.json: HBM bytes per kernel and per op.
+usage: pmc_traffic.py <dir with FETCH_SIZE csv> <dir with WRITE_SIZE csv> <ops in the run> <out.json> [command text]
+FETCH_SIZE / WRITE_SIZE count kilobytes; on gfx950 FETCH_SIZE under-counts 128-byte streaming requests by 2x
+(MI355X_MICROARCH.md, HBM section), so both the raw and the doubled figure are kept."""
+import csv, glob, json, os, sys
+from collections import defaultdict
+
+
+def fold(d, counter):
+    per = defaultdict(lambda: [0, 0.0])
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for row in csv.DictReader(open(f)):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "").replace("hefx::", "")
+            per[name][0] += 1
+            per[name][1] += float(row["Counter_Value"])
+    return per
+
+
+def main():
+    fdir, wdir, ops, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    cmd = sys.argv[5] if len(sys.argv) > 5 else ""
+    fe, wr = fold(fdir, "FETCH_SIZE"), fold(wdir, "WRITE_SIZE")
+    rows, tf, tw = [], 0.0, 0.0
+    for k in sorted(set(fe) | set(wr)):
+        if not k.startswith(("ks_", "rs_")):
+            continue
+        rows.append({"kernel": k, "dispatches": fe.get(k, wr.get(k))[0], "FETCH_SIZE_KB": fe.get(k, [0, 0.0])[1],
+                     "WRITE_SIZE_KB": wr.get(k, [0, 0.0])[1]})
+        tf += fe.get(k, [0, 0.0])[1]
+        tw += wr.get(k, [0, 0.0])[1]
+    res = {"command": cmd, "ops": ops, "per_kernel": rows,
+           "per_op_bytes": {"fetch_raw": tf * 1024 / ops, "fetch_x2": 2 * tf * 1024 / ops, "write": tw * 1024 / ops}}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res["per_op_bytes"]))
+
+
+if __name__ == "__main__":
+    main()
