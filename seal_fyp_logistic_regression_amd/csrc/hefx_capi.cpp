@@ -1151,7 +1151,8 @@ extern "C" int hefx_encrypt(hefx_context *c, int L, const uint64_t *pk, const ui
     if (!pk || !key32 || !out) return fail(HEFX_ERR_INVALID, "bad encrypt arguments");
     if (stream_id >> 62) return fail(HEFX_ERR_INVALID, "stream id must be below 2^62");
     const size_t N = c->n, rowsz = (size_t)L * N;
-    if (int rc = ensure_scratch(c, 3 * rowsz)) return rc;
+    const bool split = c->logn == 15;  // the N = 32768 transform is out of place
+    if (int rc = ensure_scratch(c, (split ? 6 : 3) * rowsz)) return rc;
     u64 *u = c->scratch, *e = u + rowsz;
     hipStream_t s = (hipStream_t)stream;
     const SampleKey k = sample_key(key32);
@@ -1159,7 +1160,13 @@ extern "C" int hefx_encrypt(hefx_context *c, int L, const uint64_t *pk, const ui
     HIPCHK(launch_sample(c->T, SAMPLE_TERNARY, k, c->noise, 4 * stream_id + 0, 1, L, 0, u, s));
     HIPCHK(launch_sample(c->T, SAMPLE_NOISE, k, c->noise, 4 * stream_id + 1, 1, L, 0, e, s));
     HIPCHK(launch_sample(c->T, SAMPLE_NOISE, k, c->noise, 4 * stream_id + 2, 1, L, 0, e + rowsz, s));
-    HIPCHK(launch_ntt(c->T, false, u, 3, L, 0, s));
+    if (split) {
+        HIPCHK(launch_ntt_split15(c->T, false, u, u + 3 * rowsz, 3, L, 0, s));
+        u += 3 * rowsz;
+        e += 3 * rowsz;
+    } else {
+        HIPCHK(launch_ntt(c->T, false, u, 3, L, 0, s));
+    }
     HIPCHK(launch_encrypt_combine(c->T, L, (const u64 *)pk, u, e, (const u64 *)plain, (u64 *)out, s));
     return HEFX_OK;
 }

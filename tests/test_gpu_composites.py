@@ -274,3 +274,45 @@ def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
         alg.linear_transform_plain(e2["ev"], e2["enc"].encrypt(e2["encoder"].encode(v, scale)),
                                    [e2["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)], e2["gk"],
                                    hoisted=True)
+
+
+@pytest.mark.parametrize("N,bits_", [(16384, [60, 40, 40, 40, 40, 60]), (32768, [60, 40, 40, 40, 40, 60])])
+def test_full_size_properties(N, bits_):
+    """BASELINE configs 3 and 5 at full size, through size-independent properties (the oracle twin is not run here):
+    rotate(s) then rotate(-s) is the identity, rotation moves slots, a plain linear transform equals M.v, the
+    dot product of the LR step is right, and GPU encode/encrypt/decrypt/decode round-trips -- all to CKKS precision."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from seal_fyp_logistic_regression_amd import seal as S
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits_))
+    ctx = S.SEALContext.Create(parms)
+    kg = S.KeyGenerator(ctx, 21)
+    enc, dec = S.Encryptor(ctx, kg.public_key(), 22), S.Decryptor(ctx, kg.secret_key())
+    encoder, ev = S.CKKSEncoder(ctx), S.Evaluator(ctx)
+    d = 8
+    gk = kg.galois_keys([-d] + list(range(1, d)) + [-3, 1024, -1024])
+    rk = kg.relin_keys()
+    rng = np.random.default_rng(N)
+    v = rng.uniform(-1, 1, N // 2)
+    scale = 2.0 ** 40
+    ct = enc.encrypt(encoder.encode(v, scale))
+    assert np.abs(encoder.decode(dec.decrypt(ct)).real - v).max() < 1e-6
+    r = ev.rotate_vector(ct, 3, gk)
+    assert np.abs(encoder.decode(dec.decrypt(r)).real - np.roll(v, -3)).max() < 1e-5
+    back = ev.rotate_vector(r, -3, gk)
+    assert np.abs(encoder.decode(dec.decrypt(back)).real - v).max() < 1e-5
+    far = ev.rotate_vector(ev.rotate_vector(ct, 1024, gk), -1024, gk)
+    assert np.abs(encoder.decode(dec.decrypt(far)).real - v).max() < 1e-5
+    M, w = rng.standard_normal((d, d)), rng.standard_normal(d)
+    cw = enc.encrypt(encoder.encode(w, scale))
+    diags = encoder.encode_many(list(alg.get_all_diagonals(M)), scale)
+    for hoisted in (False, True):
+        out = alg.linear_transform_plain(ev, cw, diags, gk, hoisted=hoisted)
+        assert np.abs(encoder.decode(dec.decrypt(out))[:d].real - M @ w).max() < 1e-4
+    a, b = rng.uniform(-1, 1, d), rng.uniform(-1, 1, d)
+    ca, cb = enc.encrypt(encoder.encode(a, scale)), enc.encrypt(encoder.encode(b, scale))
+    prod = ev.multiply(ca, cb)
+    ev.relinearize_inplace(prod, rk)
+    ev.rescale_to_next_inplace(prod)
+    assert np.abs(encoder.decode(dec.decrypt(prod))[:d].real - a * b).max() < 1e-5

@@ -43,10 +43,10 @@ def test_uniform_rejection_path_bit_exact():
         assert (e.sample("uniform", KEY, s, 2, 4).download() == o.sample("uniform", KEY, s, 2, 4)).all()
 
 
-def test_encrypt_decrypt_bit_exact_and_round_trip():
+@pytest.mark.parametrize("N,bits", [(8192, [60, 40, 40, 60]), (32768, [60, 40, 60])])
+def test_encrypt_decrypt_bit_exact_and_round_trip(N, bits):
     from seal_fyp_logistic_regression_amd import seal as S
     from tests.oracle_backend import OracleBackend
-    N, bits = 8192, [60, 40, 40, 60]
     outs = {}
     for kind in ("gpu", "oracle"):
         parms = S.EncryptionParameters("ckks")
