@@ -29,6 +29,7 @@ SETS = {
                    0xffffffffffe8001]),
     "C4": (16384, [0xffffffffffd8001, 0xffff940001, 0xffffa78001, 0xffffaf8001, 0xffffb20001, 0xffffc40001,
                    0xffffca8001, 0xffffe80001, 0xffffffffffe8001]),
+    "C5": (32768, [0xfffffffff840001, 0xffff940001, 0xffffb20001, 0xffffc40001, 0xffffe80001, 0xffffffffffc0001]),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 
