@@ -556,6 +556,32 @@ extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint
     CTXCHK(c);
     if (int rc = check_level(c, L)) return rc;
     if (n < 1 || size < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad add_many arguments");
+    // wide sums: one launch reduces groups of 16 through a device pointer table (a ring slot of the key-switch
+    // descriptors doubles as the table), then the partials are summed below
+    constexpr int TABLE_GROUP = 16;
+    constexpr int TABLE_MAX = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *));
+    std::vector<const uint64_t *> partial_ptrs;
+    if (n > 2 * ADD_MANY_GROUP && n <= TABLE_MAX) {
+        for (int i = 0; i < n; ++i)
+            if (!in[i]) return fail(HEFX_ERR_INVALID, "null ciphertext in add_many");
+        const int groups = (n + TABLE_GROUP - 1) / TABLE_GROUP;
+        const size_t words = (size_t)size * L * c->n;
+        if (int rc = ensure_scratch(c, words * groups)) return rc;
+        const unsigned slot = c->ring_next++ % KS_RING;
+        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));
+        const uint64_t **hp = reinterpret_cast<const uint64_t **>(c->h_items + (size_t)slot * KS_MAX_CHUNK);
+        const u64 *const *dp = reinterpret_cast<const u64 *const *>(c->d_items + (size_t)slot * KS_MAX_CHUNK);
+        for (int i = 0; i < n; ++i) hp[i] = in[i];
+        hipStream_t s = (hipStream_t)stream;
+        HIPCHK(hipMemcpyAsync((void *)dp, hp, sizeof(void *) * n, hipMemcpyHostToDevice, s));
+        HIPCHK(launch_add_many_table(c->T, L, size, dp, n, TABLE_GROUP, c->scratch, s));
+        HIPCHK(hipEventRecord(c->ring_ev[slot], s));
+        c->ring_busy[slot] = true;
+        partial_ptrs.resize(groups);
+        for (int g = 0; g < groups; ++g) partial_ptrs[g] = reinterpret_cast<const uint64_t *>(c->scratch + (size_t)g * words);
+        in = partial_ptrs.data();
+        n = groups;
+    }
     for (int base = 0; base < n; base += ADD_MANY_GROUP) {
         PtrGroup g{};
         const int cnt = (n - base < ADD_MANY_GROUP) ? n - base : ADD_MANY_GROUP;

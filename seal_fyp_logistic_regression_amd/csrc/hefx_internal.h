@@ -74,6 +74,8 @@ hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int 
                               const u64 *b, u64 *out, int *flag, hipStream_t s);
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s);
+hipError_t launch_add_many_table(const DevTables &T, int L, int size, const u64 *const *d_ptrs, int n, int group,
+                                 u64 *partial, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
 // profiling: an event is recorded before every launch (tagged with its stage) and one after the last
 constexpr int KS_STAGES = 7;

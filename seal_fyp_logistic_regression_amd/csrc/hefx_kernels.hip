@@ -177,6 +177,43 @@ __global__ __launch_bounds__(256) void add_many_kernel(DevTables T, int L, size_
     }
 }
 
+// First level of a wide add_many: group gi sums inputs [gi*group, min(n, (gi+1)*group)) of a DEVICE pointer table
+// into partial[gi]; all groups run in one launch (a chain of 48-input launches over a 0.4 MB ciphertext keeps
+// under 100 workgroups in flight).
+__global__ __launch_bounds__(256) void add_many_table_kernel(DevTables T, int L, size_t total_pairs,
+                                                             const u64 *const *__restrict__ ptrs, int n, int group,
+                                                             ulonglong2 *__restrict__ partial)
+{
+    const int logn = T.logn;
+    const int gi = blockIdx.y;
+    const int first = gi * group, last = first + group < n ? first + group : n;
+    ulonglong2 *__restrict__ out = partial + (size_t)gi * total_pairs;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
+         w += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = w >> (logn - 1);
+        const u64 q = T.mods[(int)(row % (size_t)L)].q;
+        ulonglong2 acc = make_ulonglong2(0, 0);
+        for (int i = first; i < last; ++i) {
+            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(ptrs[i])[w];
+            acc.x = addmod(acc.x, x.x, q);
+            acc.y = addmod(acc.y, x.y, q);
+        }
+        out[w] = acc;
+    }
+}
+
+hipError_t launch_add_many_table(const DevTables &T, int L, int size, const u64 *const *d_ptrs, int n, int group,
+                                 u64 *partial, hipStream_t s)
+{
+    const size_t total_pairs = (size_t)size * L * ((size_t)1 << T.logn) / 2;
+    int blocks = (int)((total_pairs + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int groups = (n + group - 1) / group;
+    hipLaunchKernelGGL(add_many_table_kernel, dim3(blocks, groups), dim3(256), 0, s, T, L, total_pairs, d_ptrs, n, group,
+                       reinterpret_cast<ulonglong2 *>(partial));
+    return hipGetLastError();
+}
+
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s)
 {

@@ -117,6 +117,19 @@ def test_add_many(c2):
     got = e.add_many(L, 2, [e.to_device(c) for c in cts]).download()
     assert (got == want).all()
     assert (e.add_many(L, 2, [e.to_device(cts[0])]).download() == cts[0]).all()
+    # wide sums go through the device pointer table (two-level reduction): 150 inputs, and size-3 ciphertexts
+    dev = [e.to_device(c) for c in cts]
+    many = [dev[i % 53] for i in range(150)]
+    want = cts[0]
+    for i in range(1, 150):
+        want = o.add(want, cts[i % 53])
+    assert (e.add_many(L, 2, many).download() == want).all()
+    c3s = [o.multiply(cts[i], cts[i + 1]) for i in range(4)]
+    d3 = [e.to_device(c) for c in c3s]
+    want3 = c3s[0]
+    for i in range(1, 100):
+        want3 = o.add(want3, c3s[i % 4])
+    assert (e.add_many(L, 3, [d3[i % 4] for i in range(100)]).download() == want3).all()
 
 
 def _rand_key(o, seed):
