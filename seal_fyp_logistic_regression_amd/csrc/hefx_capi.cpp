@@ -272,6 +272,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
             f.ninv_r = (double)m.ninv / qd;
             f.ilw = (double)m.ilw;
             f.ilw_r = (double)m.ilw / qd;
+            f.c32 = (double)(((u64)1 << 32) % q);
             for (size_t i = 0; i < n; ++i) {
                 twf[(size_t)j * n + i] = (double)tw[(size_t)j * n + i].x;
                 itwf[(size_t)j * n + i] = (double)itw[(size_t)j * n + i].x;

@@ -158,17 +158,13 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
     u64 v[16];
     // [d_i]_m: the U64 policy needs it only when q_i > m; the FP64 policy takes any integer below 2^49 as input,
     // so a digit of a prime < 2^41 needs no reduction at all (the transform is linear and ends canonical)
-    const bool reduce = T.modsf[m].q != 0.0 ? T.modsf[i].q == 0.0 : qi > mc.q;
+    const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
     auto ld = [&](int r, u64 &x, u64 &y) {
         const int e = eo(C::idx_nat(t, r), SC::H);
         x = dd[e];
         y = dd[e + SC::H / 2];
-        if (reduce) {
-            x = barrett64(x, mc.q, mc.r1);
-            y = barrett64(y, mc.q, mc.r1);
-        }
     };
-    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+    split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
@@ -424,13 +420,15 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const u64 q = mc.q;
     const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
     const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
-    auto ld = [&](int r, u64 &x, u64 &y) {  // barrett64 is exact for any 64-bit input, also when P <= q
+    // u < P is reduced modulo q_j and (P/2 mod q_j) subtracted in the row's policy (exact for any 64-bit word)
+    const InMode mode = {true, true, true, half_j};
+    auto ld = [&](int r, u64 &x, u64 &y) {
         const int e = eo(C::idx_nat(t, r), SC::H);
-        x = submod(barrett64(ud[e], q, mc.r1), half_j, q);
-        y = submod(barrett64(ud[e + SC::H / 2], q, mc.r1), half_j, q);
+        x = ud[e];
+        y = ud[e + SC::H / 2];
     };
     typename A::V f[16];
-    split_fwd_raw<LOGN, A>(f, ld, lds, tw, cx, t, h);
+    split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
     // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (0) left in S.p0.
     // The operand loads of a group of 4 coefficients are issued before any of its stores.
     const size_t off = (size_t)h * SC::H;
@@ -626,17 +624,13 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     const ulonglong2 qinv = T.invmod[(size_t)(L - 1) * T.k + j];
     const u64 *__restrict__ dd = d + (size_t)poly * SC::N;
     u64 v[16];
-    const bool reduce = ql > q;
+    const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, false, 0};
     auto ld = [&](int r, u64 &x, u64 &y) {
         const int e = eo(C::idx_nat(t, r), SC::H);
         x = dd[e];
         y = dd[e + SC::H / 2];
-        if (reduce) {
-            x = barrett64(x, q, mc.r1);
-            y = barrett64(y, q, mc.r1);
-        }
     };
-    split_fwd<LOGN>(v, ld, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
     const size_t off = (size_t)h * SC::H;
     const u64 *__restrict__ src = in + ((size_t)poly * L + j) * SC::N + off;
     u64 *__restrict__ dst = out + ((size_t)poly * (L - 1) + j) * SC::N + off;
@@ -703,7 +697,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ntt_spl
             x = s[C::idx_nat(t, r)];
             y = s[C::idx_nat(t, r) + SC::H];
         };
-        split_fwd<LOGN>(v, ld, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+        const InMode mode = {false, false, false, 0};
+        split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[(size_t)h * SC::H + C::idx_out(t, r)] = v[r];
     } else {

@@ -25,7 +25,7 @@ struct ModConstF {
     double q, qinv;          // q and RN(1/q)
     double ninv, ninv_r;     // N^-1 mod q and RN(ninv/q)
     double ilw, ilw_r;       // (last inverse-stage twiddle * N^-1) mod q and RN(ilw/q)
-    double pad0, pad1;
+    double c32, pad1;        // 2^32 mod q (FP64 reduction of a 64-bit word: hi*c32 + lo)
 };
 
 // Twiddle tables of one modulus (integer and FP64 policies).

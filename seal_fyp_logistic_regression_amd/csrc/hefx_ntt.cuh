@@ -32,6 +32,15 @@
 
 namespace hefx {
 
+// How the raw 64-bit words a forward-split loader delivers become transform inputs: optional reduction modulo the
+// row's prime (the word comes from a wider prime) and optional subtraction of a constant (mod-down: - (P/2 mod q)).
+struct InMode {
+    bool red_int;  // integer policy: the word may exceed q
+    bool red_f64;  // FP64 policy: the word may exceed 2^52 (it comes from a prime that is not an FP64 prime)
+    bool has_sub;
+    u64 sub;       // canonical residue to subtract
+};
+
 template <int LOGN>
 struct NttCfg {
     static constexpr int N = 1 << LOGN;
@@ -111,6 +120,14 @@ struct ArithU64 {
     }
     __device__ static __forceinline__ void inv_pass_begin(V (&)[16], const Ctx &) {}
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
+    static constexpr bool IS_F64 = false;
+    template <bool RED>
+    __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &mc)
+    {
+        if (RED) x = barrett64(x, mc.q, mc.r1);
+        if (m.has_sub) x = submod(x, m.sub, c.q);
+        return x;
+    }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return csub(csub(x, c.two_q), c.q); }
     // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 4q):
     // ((acc - f) * P^-1 + sadd) [* pt] mod q, canonical
@@ -134,6 +151,7 @@ struct ArithF64 {
     struct Ctx {
         double q, qinv;
         double ninv, ilw;
+        double c32;
     };
     __device__ static __forceinline__ Ctx make(const ModConstF &mf)
     {
@@ -142,6 +160,7 @@ struct ArithF64 {
         c.qinv = mf.qinv;
         c.ninv = mf.ninv;
         c.ilw = mf.ilw;
+        c.c32 = mf.c32;
         return c;
     }
     // y*w mod q, exact, result in (-0.52q, 0.52q); y any integer with |y| < 2^45, w integer with |w| < 2^41:
@@ -200,6 +219,20 @@ struct ArithF64 {
     __device__ static __forceinline__ V from_u64(u64 x)
     {
         return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
+    }
+    // any 64-bit word -> an exact integer congruent to it mod q, in (-0.52q, 0.52q + 2^32): hi*(2^32 mod q) + lo with
+    // two u32 -> f64 conversions and one FP64 modmul (9 instructions against ~28 slow integer ones for Barrett)
+    __device__ static __forceinline__ V reduce_wide(u64 x, const Ctx &c)
+    {
+        return mm(__uint2double_rn((unsigned)(x >> 32)), c.c32, c) + __uint2double_rn((unsigned)x);
+    }
+    static constexpr bool IS_F64 = true;
+    template <bool RED>
+    __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &)
+    {
+        double v = RED ? reduce_wide(x, c) : from_u64(x);
+        if (m.has_sub) v -= from_u64(m.sub);
+        return v;
     }
     __device__ static __forceinline__ u64 to_u64(double r)
     {
@@ -435,45 +468,64 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 }
 
 // Forward split (transform size 2^LOGN, this workgroup = half h, sub-transform 2^(LOGN-1)):
-// ld(r, x, y) must deliver the canonical coefficients idx_nat(t,r) and idx_nat(t,r)+N/2; on return
+// ld(r, x, y) delivers the raw words of coefficients idx_nat(t,r) and idx_nat(t,r)+N/2, `mode` says how they become
+// inputs (reduction / constant subtraction in the row's arithmetic policy); on return
 // v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
 template <int LOGN, class A, class LD>
-__device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, u64 *lds,
-                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                              int h)
+__device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, const InMode &mode,
+                                              const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
+                                              const typename A::Ctx &cx, int t, int h)
 {
     const typename A::TW w1 = tw[1];
+    // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
+    // select per element (which would make every row pay for the reduction)
+    if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        u64 x[8], y[8];
+        for (int g = 0; g < 2; ++g) {
+            u64 x[8], y[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
+            for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) f[8 * g + r] = A::ct_half(A::from_u64(x[r]), A::from_u64(y[r]), w1, cx, h);
-        HEFX_STAGE_FENCE();
+            for (int r = 0; r < 8; ++r)
+                f[8 * g + r] = A::ct_half(A::template input<true>(x[r], mode, cx, mc),
+                                          A::template input<true>(y[r], mode, cx, mc), w1, cx, h);
+            HEFX_STAGE_FENCE();
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            u64 x[8], y[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
+#pragma unroll
+            for (int r = 0; r < 8; ++r)
+                f[8 * g + r] = A::ct_half(A::template input<false>(x[r], mode, cx, mc),
+                                          A::template input<false>(y[r], mode, cx, mc), w1, cx, h);
+            HEFX_STAGE_FENCE();
+        }
     }
     ntt_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
 }
 
 template <int LOGN, class A, class LD>
-__device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, u64 *lds,
-                                            const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                            int h)
+__device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const InMode &mode, const ModConst &mc,
+                                            u64 *lds, const typename A::TW *__restrict__ tw,
+                                            const typename A::Ctx &cx, int t, int h)
 {
     typename A::V f[16];
-    split_fwd_raw<LOGN, A>(f, ld, lds, tw, cx, t, h);
+    split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = A::fwd_finish(f[r], cx);
 }
 
 template <int LOGN, class LD>
-__device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, u64 *lds, const NttTables &nt,
-                                          const ModConst &mc, const ModConstF &mf, int t, int h)
+__device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMode &mode, u64 *lds,
+                                          const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
     if (mf.q != 0.0)
-        split_fwd_a<LOGN, ArithF64>(v, ld, lds, nt.twf, ArithF64::make(mf), t, h);
+        split_fwd_a<LOGN, ArithF64>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
     else
-        split_fwd_a<LOGN, ArithU64>(v, ld, lds, nt.tw, ArithU64::make(mc), t, h);
+        split_fwd_a<LOGN, ArithU64>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
 }
 
 // Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the
