@@ -221,6 +221,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "algorithmic_GB_per_step": B * bytes_op / 1e9,  # same basis as `traffic` (one step = one launch sequence)
                 "launch": "one step = the 6-kernel key-switch sequence over the whole batch "
                           f"({nchunks} chunks); achieved = {B} ops x {bytes_op} B / {step_ms:.3f} ms (HIP events)",
                 "dominant_kernel": dom,
