@@ -22,6 +22,9 @@
  *  - Level/scale/parms_id bookkeeping, NAF decomposition of rotation steps and SEAL's validity checks
  *    live ABOVE this ABI (in the shim); this layer is pure uint64 RNS arithmetic.
  *  - There is no CPU fallback: without a HIP device every call fails with HEFX_ERR_HIP.
+ *  - Threading: a context owns its scratch, descriptor ring and internal streams, so calls on ONE context must not
+ *    overlap in time on the host (the reference's drivers are single-threaded); different contexts -- e.g. one per
+ *    GPU / per rank -- are independent.  Work submitted through one context is ordered on the caller's stream.
  */
 #ifndef HEFX_H
 #define HEFX_H
