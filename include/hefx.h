@@ -189,6 +189,16 @@ int hefx_sample_ternary(hefx_context *ctx, const uint8_t *key32, uint64_t stream
                         int mod_first, uint64_t *d_out, void *stream);
 int hefx_sample_noise(hefx_context *ctx, const uint8_t *key32, uint64_t stream_id, int npoly, int nrows,
                       int mod_first, uint64_t *d_out, void *stream);
+/* KeyGenerator's key-switching keys (relin_keys, galois_keys; App. A.11) entirely on the device:
+ * out[k-1][2][k][N] (SEAL's layout) = for digit i: (-(a_i*sk + e_i) + [row i] (P mod q_i)*new_sk, a_i), a_i uniform from
+ * sub-stream 2*stream_id, e_i noise from 2*stream_id+1.  d_sk, d_new_sk: [k][N] NTT form (new_sk = sk^2 for the
+ * relinearisation key, hefx_galois_permute(sk) for a Galois key). */
+int hefx_keygen_kswitch(hefx_context *ctx, const uint64_t *d_sk, const uint64_t *d_new_sk, const uint8_t *key32,
+                        uint64_t stream_id, uint64_t *d_out, void *stream);
+/* out[r][w] = in[r][perm_g[w]] for `rows` rows of N words: the NTT-domain automorphism X -> X^g of plain
+ * polynomials (SEAL apply_galois_ntt); in != out */
+int hefx_galois_permute(hefx_context *ctx, uint32_t galois_elt, const uint64_t *d_in, int rows, uint64_t *d_out,
+                        void *stream);
 /* out[2][L][N] = (pk0*u + e0 + plain, pk1*u + e1), NTT form; d_pk = [2][k][N] (key-level public key), d_plain may be
  * NULL (encryption of zero); u ternary from sub-stream 4*stream_id, e0 / e1 noise from 4*stream_id+1 / +2. */
 int hefx_encrypt(hefx_context *ctx, int L, const uint64_t *d_pk, const uint64_t *d_plain, const uint8_t *key32,

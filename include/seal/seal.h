@@ -579,7 +579,7 @@ public:
         auto &e = ctx_->engine();
         auto s2 = shim::new_buf(e, (std::size_t)k * ctx_->n());
         shim::check(hefx_multiply_plain(e->ctx, k, 1, 1, sk_.buf->p, sk_.buf->p, s2->p, nullptr));
-        rk.keys[0] = kswitch_key(shim::download(s2));
+        rk.keys[0] = kswitch_key(s2);
         return rk;
     }
     void create_relin_keys(RelinKeys &rk) { rk = relin_keys(); }
@@ -610,24 +610,18 @@ private:
     GaloisKeys galois_keys_for(const std::vector<std::uint32_t> &elts)
     {
         GaloisKeys gk;
-        const std::size_t n = ctx_->n();
+        auto &e = ctx_->engine();
         const int k = ctx_->k();
-        int logn = 0;
-        while (((std::size_t)1 << logn) < n) ++logn;
         for (std::uint32_t g : elts) {
             if (gk.has_key(g)) continue;
-            std::vector<std::uint64_t> sp((std::size_t)k * n);
-            for (std::size_t i = 0; i < n; ++i) {
-                const std::uint32_t raw = (std::uint32_t)(((std::uint64_t)g * (2 * shim::bitrev((std::uint32_t)i, logn) + 1)) & (2 * n - 1));
-                const std::uint32_t src = shim::bitrev((raw - 1) >> 1, logn);
-                for (int j = 0; j < k; ++j) sp[(std::size_t)j * n + i] = sk_.host[(std::size_t)j * n + src];
-            }
+            auto sp = shim::new_buf(e, (std::size_t)k * ctx_->n());  // s(X^g), NTT domain, on the device
+            shim::check(hefx_galois_permute(e->ctx, g, sk_.buf->p, k, sp->p, nullptr));
             gk.keys[g] = kswitch_key(sp);
         }
         return gk;
     }
 
-    // npoly fresh symmetric encryptions of zero over the first `rows` primes: (device c0, host c1)
+    // npoly fresh symmetric encryptions of zero over the first `rows` primes: (device c0, host c1) -- public key
     std::pair<shim::BufPtr, std::vector<std::uint64_t>> encrypt_zero(int npoly, int rows)
     {
         auto &e = ctx_->engine();
@@ -645,30 +639,16 @@ private:
         return {t, a};
     }
 
-    shim::BufPtr kswitch_key(const std::vector<std::uint64_t> &new_sk)
+    // key-switching key for new_sk (device, [k][N] NTT form) under sk: sampling, NTT and assembly on the GPU
+    shim::BufPtr kswitch_key(const shim::BufPtr &new_sk)
     {
         auto &e = ctx_->engine();
-        const std::size_t n = ctx_->n();
         const int k = ctx_->k();
         if (k < 2) throw std::logic_error("keyswitching is not supported by the context");
-        auto z = encrypt_zero(k - 1, k);
-        std::vector<std::uint64_t> c0 = shim::download(z.first);
-        const std::uint64_t P = ctx_->primes()[k - 1];
-        std::vector<std::uint64_t> key((std::size_t)(k - 1) * 2 * k * n);
-        for (int i = 0; i < k - 1; ++i) {
-            const std::uint64_t q = ctx_->primes()[i], f = P % q;
-            std::uint64_t *row = &c0[((std::size_t)i * k + i) * n];
-            const std::uint64_t *ns = &new_sk[(std::size_t)i * n];
-            for (std::size_t a = 0; a < n; ++a) {
-                const std::uint64_t s = row[a] + shim::mulmod(ns[a], f, q);
-                row[a] = s >= q ? s - q : s;
-            }
-            std::copy(c0.begin() + (std::size_t)i * k * n, c0.begin() + (std::size_t)(i + 1) * k * n,
-                      key.begin() + ((std::size_t)i * 2) * k * n);
-            std::copy(z.second.begin() + (std::size_t)i * k * n, z.second.begin() + (std::size_t)(i + 1) * k * n,
-                      key.begin() + ((std::size_t)i * 2 + 1) * k * n);
-        }
-        return shim::upload(e, key);
+        auto key = shim::new_buf(e, (std::size_t)(k - 1) * 2 * k * ctx_->n());
+        shim::check(hefx_keygen_kswitch(e->ctx, sk_.buf->p, new_sk->p, rnd_.key.data(), 0x40000000ull + rnd_.stream(),
+                                        key->p, nullptr));
+        return key;
     }
 
     std::shared_ptr<SEALContext> ctx_;

@@ -73,6 +73,8 @@ _SIGS = {
     "hefx_sample_uniform": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_sample_ternary": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_sample_noise": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
+    "hefx_keygen_kswitch": (_i, [_vp, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
+    "hefx_galois_permute": (_i, [_vp, _u32, _vp, _i, _vp, _vp]),
     "hefx_encrypt": (_i, [_vp, _i, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
     "hefx_decrypt": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "hefx_event_create": (_i, [_vp, _pp]),

@@ -1207,3 +1207,40 @@ extern "C" int hefx_decrypt(hefx_context *c, int L, int size, const uint64_t *ct
     HIPCHK(launch_decrypt(c->T, L, size, (const u64 *)ct, (const u64 *)sk, (u64 *)out, (hipStream_t)stream));
     return HEFX_OK;
 }
+
+extern "C" int hefx_keygen_kswitch(hefx_context *c, const uint64_t *sk, const uint64_t *new_sk, const uint8_t *key32,
+                                   uint64_t stream_id, uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (c->k < 2) return fail(HEFX_ERR_UNSUPPORTED, "keyswitching is not supported by the context");
+    if (!sk || !new_sk || !key32 || !out) return fail(HEFX_ERR_INVALID, "bad key generation arguments");
+    if (stream_id >> 62) return fail(HEFX_ERR_INVALID, "stream id must be below 2^62");
+    const size_t N = c->n, words = (size_t)(c->k - 1) * c->k * N;
+    const bool split = c->logn == 15;
+    if (int rc = ensure_scratch(c, (split ? 3 : 2) * words)) return rc;
+    u64 *a = c->scratch, *e = a + words;
+    hipStream_t s = (hipStream_t)stream;
+    const SampleKey k = sample_key(key32);
+    // sub-streams 2*id: uniform a, 2*id+1: noise e
+    HIPCHK(launch_sample(c->T, SAMPLE_UNIFORM, k, c->noise, 2 * stream_id, c->k - 1, c->k, 0, a, s));
+    HIPCHK(launch_sample(c->T, SAMPLE_NOISE, k, c->noise, 2 * stream_id + 1, c->k - 1, c->k, 0, e, s));
+    if (split) {
+        HIPCHK(launch_ntt_split15(c->T, false, e, e + words, c->k - 1, c->k, 0, s));
+        e += words;
+    } else {
+        HIPCHK(launch_ntt(c->T, false, e, c->k - 1, c->k, 0, s));
+    }
+    HIPCHK(launch_keygen_combine(c->T, (const u64 *)sk, (const u64 *)new_sk, a, e, (u64 *)out, s));
+    return HEFX_OK;
+}
+
+extern "C" int hefx_galois_permute(hefx_context *c, uint32_t galois_elt, const uint64_t *in, int rows, uint64_t *out,
+                                   void *stream)
+{
+    CTXCHK(c);
+    if (!in || !out || rows < 1 || in == out) return fail(HEFX_ERR_INVALID, "bad permutation arguments");
+    const uint32_t *perm = nullptr;
+    if (int rc = get_perm(c, galois_elt, &perm)) return rc;
+    HIPCHK(launch_galois_permute(c->T, perm, (const u64 *)in, rows, (u64 *)out, (hipStream_t)stream));
+    return HEFX_OK;
+}

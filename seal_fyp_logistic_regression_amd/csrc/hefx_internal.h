@@ -111,6 +111,10 @@ hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, con
 hipError_t launch_encrypt_combine(const DevTables &T, int L, const u64 *pk, const u64 *u, const u64 *e,
                                   const u64 *plain, u64 *out, hipStream_t s);
 hipError_t launch_decrypt(const DevTables &T, int L, int size, const u64 *ct, const u64 *sk, u64 *out, hipStream_t s);
+hipError_t launch_keygen_combine(const DevTables &T, const u64 *sk, const u64 *new_sk, const u64 *a, const u64 *e,
+                                 u64 *out, hipStream_t s);
+hipError_t launch_galois_permute(const DevTables &T, const uint32_t *perm, const u64 *in, int rows, u64 *out,
+                                 hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

@@ -158,6 +158,63 @@ __global__ __launch_bounds__(256) void decrypt_kernel(DevTables T, int L, int si
     *reinterpret_cast<ulonglong2 *>(out + (size_t)j * n + w) = acc;
 }
 
+// Key-switching key for the secret new_sk under sk (App. A.11), digit i, key-level row m:
+//   out[i][1][m] = a_i[m] (uniform),  out[i][0][m] = -(a_i[m]*sk[m] + e_i[m]) + [m == i] (P mod q_i) * new_sk[i]
+// a: uniform [k-1][k][N]; e: noise [k-1][k][N] already in NTT form; everything NTT form, SEAL's key layout.
+__global__ __launch_bounds__(256) void keygen_combine_kernel(DevTables T, const u64 *__restrict__ sk,
+                                                             const u64 *__restrict__ new_sk,
+                                                             const u64 *__restrict__ a, const u64 *__restrict__ e,
+                                                             u64 *__restrict__ out)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int m = blockIdx.y, i = blockIdx.z, k = T.k;
+    const ModConst mc = T.mods[m];
+    const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(a + ((size_t)i * k + m) * n + w);
+    const ulonglong2 ev = *reinterpret_cast<const ulonglong2 *>(e + ((size_t)i * k + m) * n + w);
+    const ulonglong2 sv = *reinterpret_cast<const ulonglong2 *>(sk + (size_t)m * n + w);
+    ulonglong2 c0;
+    c0.x = negmod(addmod(mulmod(av.x, sv.x, mc), ev.x, mc.q), mc.q);
+    c0.y = negmod(addmod(mulmod(av.y, sv.y, mc), ev.y, mc.q), mc.q);
+    if (m == i) {
+        const u64 f = barrett64(T.mods[k - 1].q, mc.q, mc.r1);
+        const ulonglong2 ns = *reinterpret_cast<const ulonglong2 *>(new_sk + (size_t)m * n + w);
+        c0.x = addmod(c0.x, mulmod(ns.x, f, mc), mc.q);
+        c0.y = addmod(c0.y, mulmod(ns.y, f, mc), mc.q);
+    }
+    *reinterpret_cast<ulonglong2 *>(out + (((size_t)i * 2 + 0) * k + m) * n + w) = c0;
+    *reinterpret_cast<ulonglong2 *>(out + (((size_t)i * 2 + 1) * k + m) * n + w) = av;
+}
+
+// out[p][j][w] = in[p][j][perm[w]]: the NTT-domain automorphism of plain polynomials (s(X^g) for Galois keys)
+__global__ __launch_bounds__(256) void galois_permute_kernel(DevTables T, const uint32_t *__restrict__ perm,
+                                                             const u64 *__restrict__ in, u64 *__restrict__ out)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const size_t row = blockIdx.y;
+    const uint2 pi = *reinterpret_cast<const uint2 *>(perm + w);
+    const u64 *__restrict__ src = in + row * n;
+    *reinterpret_cast<ulonglong2 *>(out + row * n + w) = make_ulonglong2(src[pi.x], src[pi.y]);
+}
+
+hipError_t launch_keygen_combine(const DevTables &T, const u64 *sk, const u64 *new_sk, const u64 *a, const u64 *e,
+                                 u64 *out, hipStream_t s)
+{
+    const int n2 = (1 << T.logn) / 2;
+    hipLaunchKernelGGL(keygen_combine_kernel, dim3((n2 + 255) / 256, T.k, T.k - 1), dim3(256), 0, s, T, sk, new_sk, a,
+                       e, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_galois_permute(const DevTables &T, const uint32_t *perm, const u64 *in, int rows, u64 *out,
+                                 hipStream_t s)
+{
+    const int n2 = (1 << T.logn) / 2;
+    hipLaunchKernelGGL(galois_permute_kernel, dim3((n2 + 255) / 256, rows), dim3(256), 0, s, T, perm, in, out);
+    return hipGetLastError();
+}
+
 hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, const NoiseTable &tab, u64 stream,
                          int npoly, int nrows, int mod_first, u64 *out, hipStream_t s)
 {

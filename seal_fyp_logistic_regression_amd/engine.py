@@ -270,6 +270,19 @@ class Engine:
         capi.check(f(self._h, key32, stream_id, npoly, nrows, mod_first, out.ptr, stream))
         return out
 
+    def keygen_kswitch(self, sk, new_sk, key32: bytes, stream_id: int, out=None, stream=None):
+        """key-switching key [k-1][2][k][N] for new_sk under sk, sampled and assembled on the device"""
+        if len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        out = out if out is not None else DeviceArray(self, (self.k - 1, 2, self.k, self.N))
+        capi.check(capi.lib().hefx_keygen_kswitch(self._h, sk.ptr, new_sk.ptr, key32, stream_id, out.ptr, stream))
+        return out
+
+    def galois_permute(self, elt: int, a, rows: int, out=None, stream=None):
+        out = out if out is not None else DeviceArray(self, (rows, self.N))
+        capi.check(capi.lib().hefx_galois_permute(self._h, elt, a.ptr, rows, out.ptr, stream))
+        return out
+
     def encrypt(self, L, pk, plain, key32: bytes, stream_id: int, out=None, stream=None):
         if len(key32) != 32:
             raise ValueError("key32 must be 32 bytes")

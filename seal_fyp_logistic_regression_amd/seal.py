@@ -174,6 +174,12 @@ class GpuBackend:
     def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
         return self.engine.sample(kind, key32, stream_id, npoly, nrows, mod_first)
 
+    def keygen_kswitch(self, sk, new_sk, key32, stream_id):
+        return self.engine.keygen_kswitch(sk, new_sk, key32, stream_id)
+
+    def galois_permute(self, elt, a, rows):
+        return self.engine.galois_permute(elt, a, rows)
+
     def encrypt(self, L, pk, plain, key32, stream_id):
         return self.engine.encrypt(L, pk, plain, key32, stream_id)
 
@@ -355,7 +361,7 @@ class KeyGenerator:
         self.ctx = context
         self._key32, self._stream = _key32(seed), 0
         be, k = context.backend, context.k
-        h = be.sample("ternary", self._key32, self._next_stream(), 1, k)
+        h = be.sample("ternary", self._key32, 2 * self._next_stream(), 1, k)
         be.ntt_forward(h, 1, k, 0)
         self._sk = SecretKey(be.to_host(h).reshape(k, context.N), h)
 
@@ -366,11 +372,12 @@ class KeyGenerator:
     def secret_key(self) -> SecretKey:
         return self._sk
 
-    def _encrypt_zero(self, npoly: int, rows: int):
-        """npoly fresh symmetric encryptions of zero over the first `rows` primes: returns host (c0, c1)"""
+    def _encrypt_zero(self, npoly: int, rows: int, sid: int):
+        """npoly fresh symmetric encryptions of zero over the first `rows` primes: returns host (c0, c1);
+        a uniform from sampler stream 2*sid, e noise from 2*sid+1 (what hefx_keygen_kswitch draws)"""
         be, sk = self.ctx.backend, self._sk
-        a = be.sample("uniform", self._key32, self._next_stream(), npoly, rows)
-        e = be.sample("noise", self._key32, self._next_stream(), npoly, rows)
+        a = be.sample("uniform", self._key32, 2 * sid, npoly, rows)
+        e = be.sample("noise", self._key32, 2 * sid + 1, npoly, rows)
         be.ntt_forward(e, npoly, rows, 0)
         sk_rows = be.from_host(sk.host[:rows])
         as_ = be.multiply_plain(rows, npoly, a, sk_rows)
@@ -379,13 +386,24 @@ class KeyGenerator:
                 be.to_host(a).reshape(npoly, rows, self.ctx.N))
 
     def public_key(self):
-        c0, c1 = self._encrypt_zero(1, self.ctx.k)
+        c0, c1 = self._encrypt_zero(1, self.ctx.k, self._next_stream())
         return np.stack([c0[0], c1[0]])  # [2][k][N]
 
-    def _kswitch_key(self, new_sk_host: np.ndarray):
+    def _kswitch_key(self, new_sk_host, new_sk_dev=None):
+        """key-switching key for new_sk under sk.  On the HIP engine: one call (hefx_keygen_kswitch -- sampling, NTT and
+        assembly on the device); otherwise the same arithmetic composed from backend ops (the oracle twin in tests:
+        same sampler streams, same bits)."""
         ctx, be = self.ctx, self.ctx.backend
         k, N, q = ctx.k, ctx.N, ctx.primes
-        c0, c1 = self._encrypt_zero(k - 1, k)
+        sid = self._next_stream()
+        native = getattr(be, "keygen_kswitch", None)
+        if native is not None:
+            if new_sk_dev is None:
+                new_sk_dev = be.from_host(new_sk_host)
+            return native(self._sk.data, new_sk_dev, self._key32, sid)
+        if new_sk_host is None:
+            new_sk_host = be.to_host(new_sk_dev).reshape(k, N)
+        c0, c1 = self._encrypt_zero(k - 1, k, sid)
         P = q[k - 1]
         # c0[i][row i] += (P mod q_i) * new_sk[row i]
         factor = np.empty((k, N), dtype=np.uint64)
@@ -400,9 +418,9 @@ class KeyGenerator:
 
     def relin_keys(self) -> KSwitchKeys:
         be, sk = self.ctx.backend, self._sk
-        s2 = be.to_host(be.multiply_plain(self.ctx.k, 1, be.from_host(sk.host[None]), sk.data))[0]
+        s2 = be.multiply_plain(self.ctx.k, 1, be.from_host(sk.host[None]), sk.data)
         rk = KSwitchKeys()
-        rk.keys[0] = self._kswitch_key(s2)
+        rk.keys[0] = self._kswitch_key(None, s2)
         return rk
 
     def default_galois_elts(self) -> List[int]:
@@ -419,9 +437,13 @@ class KeyGenerator:
         N = self.ctx.N
         elts = self.default_galois_elts() if steps is None else [galois_elt_from_step(s, N) for s in steps]
         gk = KSwitchKeys()
+        permute = getattr(self.ctx.backend, "galois_permute", None)
         for g in elts:
-            tab = galois_tables.gather_table(N, g)
-            gk.keys[g] = self._kswitch_key(self._sk.host[:, tab])
+            if permute is not None:  # s(X^g) on the device
+                gk.keys[g] = self._kswitch_key(None, permute(g, self._sk.data, self.ctx.k))
+            else:
+                tab = galois_tables.gather_table(N, g)
+                gk.keys[g] = self._kswitch_key(self._sk.host[:, tab])
         return gk
 
 
