@@ -171,7 +171,7 @@ int hefx_linear_transform_plain_hoisted(hefx_context *ctx, int L, const uint64_t
  *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->
  *      `count` contiguous NTT-form plaintexts of L rows at d_out.  Canonical embedding with slot i <-> root
  *      zeta^(3^i), coefficients rounded half away from zero like std::round.  Floating point: matches any other
- *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit.  N <= 16384. */
+ *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit. */
 int hefx_ckks_encode(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
                      double scale, uint64_t *d_out, void *stream);
 

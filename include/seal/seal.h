@@ -841,7 +841,7 @@ private:
                           Plaintext &dest) const
     {
         const std::size_t n = ctx_->n();
-        if (n < 1024 || n > 16384 || values.empty()) return false;
+        if (n < 1024 || n > 32768 || values.empty()) return false;
         static const bool host_only = [] {
             const char *s = std::getenv("SEAL_SHIM_HOST_ENCODE");
             return s && *s && *s != '0';

@@ -926,7 +926,7 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
 {
     CTXCHK(c);
     if (int rc = check_level(c, L)) return rc;
-    if (c->logn < 10 || c->logn > 14) return fail(HEFX_ERR_UNSUPPORTED, "GPU encode is built for poly_degree in [1024, 16384]");
+    if (c->logn < 10 || c->logn > 15) return fail(HEFX_ERR_UNSUPPORTED, "GPU encode is built for poly_degree in [1024, 32768]");
     if (!h_re || !d_out || count < 1 || nvalues < 1 || (size_t)nvalues > c->n / 2)
         return fail(HEFX_ERR_INVALID, "values has invalid size");
     if (!(scale > 0)) return fail(HEFX_ERR_INVALID, "scale out of bounds");
@@ -944,6 +944,13 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
     HIPCHK(hipMemcpyAsync(c->d_vals, h_re, nv * sizeof(double), hipMemcpyHostToDevice, s));
     if (h_im) HIPCHK(hipMemcpyAsync(c->d_vals + nv, h_im, nv * sizeof(double), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));  // the host arrays may be transient
+    if (c->logn == 15) {  // the N = 32768 transform is out of place: coefficients into scratch, NTT into d_out
+        const size_t words = (size_t)count * L * c->n;
+        if (int rc = ensure_scratch(c, words)) return rc;
+        HIPCHK(launch_encode(c->T, c->E, c->d_vals, h_im ? c->d_vals + nv : nullptr, nvalues, count, scale, L, c->scratch, s));
+        HIPCHK(launch_ntt_split15(c->T, false, c->scratch, (u64 *)d_out, count, L, 0, s));
+        return HEFX_OK;
+    }
     HIPCHK(launch_encode(c->T, c->E, c->d_vals, h_im ? c->d_vals + nv : nullptr, nvalues, count, scale, L, (u64 *)d_out, s));
     HIPCHK(launch_ntt(c->T, false, (u64 *)d_out, count, L, 0, s));
     return HEFX_OK;

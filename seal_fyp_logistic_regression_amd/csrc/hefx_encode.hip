@@ -40,22 +40,23 @@ __device__ __forceinline__ void dif(double2 &u, double2 &v, const double2 *__res
     v = cmul(d, w[j * (M / (2 * gap))]);
 }
 
-template <int LM>
+// SPLIT (N = 32768: 16384 complex points do not fit LDS): the first DIF stage is applied while loading -- half h of
+// an FFT of FM = 2*M points keeps a0 + a1 (h = 0: even frequencies) or (a0 - a1) * w_FM^r (h = 1: odd frequencies) --
+// and the workgroup runs the remaining M-point transform; blockIdx.x = 2*kappa + h.
+template <int LM, bool SPLIT>
 __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T, EncodeTables E, const double *re,
                                                                    const double *im, int nvalues, double scale, int L,
                                                                    u64 *out /* [count][L][N] coefficient form */)
 {
     using C = FftCfg<LM>;
     extern __shared__ __align__(16) double2 fl[];
-    const int t = threadIdx.x, kappa = blockIdx.x, vec = blockIdx.y;
-    const int N = 2 * C::M;
+    const int t = threadIdx.x, vec = blockIdx.y;
+    const int kappa = SPLIT ? blockIdx.x >> 1 : blockIdx.x, hh = SPLIT ? blockIdx.x & 1 : 0;
+    constexpr int FM = SPLIT ? 2 * C::M : C::M;  // points of the whole FFT = N/2 = size the twiddle table is built for
+    const int N = 2 * FM;
     const double *vre = re + (size_t)vec * nvalues;
     const double *vim = im ? im + (size_t)vec * nvalues : nullptr;
-    double2 v[8];
-    // load A_r (natural order, r = t + T*e), pre-twist for kappa = 1
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int r = t + C::T * e;
+    auto load = [&](int r) {  // A_r, pre-twisted for kappa = 1
         const int s = E.slot[r];
         double2 a = make_double2(0.0, 0.0);
         if (s >= 0 && (s >> 1) < nvalues) {
@@ -63,7 +64,20 @@ __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T,
             a.y = vim ? vim[s >> 1] : 0.0;
             if (s & 1) a.y = -a.y;
         }
-        v[e] = kappa ? cmul(a, E.pre[r]) : a;
+        return kappa ? cmul(a, E.pre[r]) : a;
+    };
+    double2 v[8];
+    // natural order, r = t + T*e
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = t + C::T * e;
+        if (SPLIT) {
+            const double2 a0 = load(r), a1 = load(r + C::M);
+            v[e] = hh ? cmul(make_double2(a0.x - a1.x, a0.y - a1.y), E.wfft[r])
+                      : make_double2(a0.x + a1.x, a0.y + a1.y);
+        } else {
+            v[e] = load(r);
+        }
     }
     // radix-8 DIF passes: pass p works on stride S = M / 8^(p+1); gaps 4S, 2S, S
 #pragma unroll
@@ -82,7 +96,7 @@ __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T,
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e & half) continue;
-                dif(v[e], v[e | half], E.wfft, base + S * e, half * S, C::M);
+                dif(v[e], v[e | half], E.wfft, base + S * e, half * S, FM);
             }
         }
         if (p + 1 < C::FP || C::R > 0) {
@@ -106,7 +120,7 @@ __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T,
 #pragma unroll
                 for (int e = 0; e < G; ++e) {
                     if (e & half) continue;
-                    dif(v[c * G + e], v[c * G + (e | half)], E.wfft, (t + C::T * c) * G + e, half, C::M);
+                    dif(v[c * G + e], v[c * G + (e | half)], E.wfft, (t + C::T * c) * G + e, half, FM);
                 }
         }
     }
@@ -120,7 +134,8 @@ __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T,
             constexpr int G = 1 << C::R;
             pos = (t + C::T * (e / G)) * G + (e % G);
         }
-        const int kp = (int)(__brev((unsigned)pos) >> (32 - LM));
+        int kp = (int)(__brev((unsigned)pos) >> (32 - LM));
+        if (SPLIT) kp = 2 * kp + hh;
         const int k = 2 * kp + kappa;
         const double2 z = cmul(v[e], E.post[k]);
         const double co = __builtin_round(z.x * (2.0 / (double)N) * scale);
@@ -138,20 +153,21 @@ hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double
                          int count, double scale, int L, u64 *out, hipStream_t s)
 {
     const int lm = T.logn - 1;
-#define LAUNCH(LMV)                                                                                              \
+#define LAUNCH(LMV, SPL)                                                                                         \
     {                                                                                                            \
         const size_t lds = sizeof(double2) * (size_t)FftCfg<LMV>::M;                                             \
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ckks_encode_kernel<LMV>),                       \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(ckks_encode_kernel<LMV, SPL>),                  \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
-        hipLaunchKernelGGL((ckks_encode_kernel<LMV>), dim3(2, count), dim3(FftCfg<LMV>::T), lds, s, T, E, re, im, \
-                           nvalues, scale, L, out);                                                              \
+        hipLaunchKernelGGL((ckks_encode_kernel<LMV, SPL>), dim3(SPL ? 4 : 2, count), dim3(FftCfg<LMV>::T), lds, s, T, \
+                           E, re, im, nvalues, scale, L, out);                                                   \
     }
     switch (lm) {
-        case 9: LAUNCH(9) break;
-        case 10: LAUNCH(10) break;
-        case 11: LAUNCH(11) break;
-        case 12: LAUNCH(12) break;
-        case 13: LAUNCH(13) break;
+        case 9: LAUNCH(9, false) break;
+        case 10: LAUNCH(10, false) break;
+        case 11: LAUNCH(11, false) break;
+        case 12: LAUNCH(12, false) break;
+        case 13: LAUNCH(13, false) break;
+        case 14: LAUNCH(13, true) break;  // N = 32768: two half-size workgroups per (vector, kappa)
         default: return hipErrorInvalidValue;
     }
 #undef LAUNCH

@@ -188,7 +188,7 @@ class GpuBackend:
 
     def ckks_encode(self, L, values, scale):
         """[count][nvalues] slot values -> [count][L][N] NTT-form plaintexts, or None if N is outside the kernel's range"""
-        if not 1024 <= self.N <= 16384:
+        if not 1024 <= self.N <= 32768:
             return None
         return self.engine.ckks_encode(L, values, scale)
 
@@ -480,8 +480,8 @@ class Decryptor:
 
 class CKKSEncoder:
     """Canonical embedding with slot i <-> root zeta^(3^i) (App. A.12).  encode runs on the GPU
-    (hefx_ckks_encode: FFT + rounding + RNS + NTT in two launches) when the backend offers it; decode, scalars,
-    coefficients wider than 62 bits and N = 32768 use the host FFT + the backend NTT.  device_encode=False forces
+    (hefx_ckks_encode: FFT + rounding + RNS + NTT in two launches) when the backend offers it; decode, scalars and
+    coefficients wider than 62 bits use the host FFT + the backend NTT.  device_encode=False forces
     the host FFT (bit-identical across backends -- what the evaluator parity tests use)."""
 
     def __init__(self, context: SEALContext, device_encode: bool = True):
