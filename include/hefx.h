@@ -207,6 +207,15 @@ int hefx_encrypt(hefx_context *ctx, int L, const uint64_t *d_pk, const uint64_t 
 int hefx_decrypt(hefx_context *ctx, int L, int size, const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_out,
                  void *stream);
 
+/* ---- CKKSEncoder::decode(plain, vector<double>&) on the GPU (linear_transformation2.cpp:396-400,
+ *      logistic_regression_ckks.cpp:362-381 -- the decrypt/decode/encode/encrypt refresh of the LR loop):
+ *      `count` NTT-form plaintexts of L rows -> slot values, h_re/h_im[count][N/2] (h_im may be NULL).  Inverse NTT,
+ *      CRT composition (Garner, exact), centring against Q/2, division by the scale and the slot-root evaluation
+ *      (two N/2-point complex FFTs) all on the device.  Floating point: agrees with a host decode to ~1e-12 relative.
+ *      Blocks until the values are in the host arrays. */
+int hefx_ckks_decode(hefx_context *ctx, int L, const uint64_t *d_pt, int count, double scale, double *h_re,
+                     double *h_im, void *stream);
+
 /* ---- measurement helpers (no reference counterpart; the reference times with std::chrono around the L3
  *      call, e.g. linear_transformation2.cpp:363-365).  HIP events recorded on the stream the kernels use. */
 int hefx_event_create(hefx_context *ctx, void **event);

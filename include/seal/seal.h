@@ -710,7 +710,8 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------------
-// CKKSEncoder (App. A.12): canonical embedding, slot i <-> root zeta^(3^i); FFT on the host, NTT on the GPU
+// CKKSEncoder (App. A.12): canonical embedding, slot i <-> root zeta^(3^i); encode and decode run on the GPU
+// (hefx_ckks_encode / hefx_ckks_decode); the host FFT below remains for wide coefficients and SEAL_SHIM_HOST_ENCODE=1
 // ------------------------------------------------------------------------------------------------
 class CKKSEncoder {
 public:
@@ -784,6 +785,15 @@ public:
         auto &e = ctx_->engine();
         const std::size_t n = ctx_->n();
         const int L = plain.rows;
+        static const bool host_only = [] {
+            const char *s = std::getenv("SEAL_SHIM_HOST_ENCODE");
+            return s && *s && *s != '0';
+        }();
+        if (!host_only && L <= 16 && n >= 1024) {  // inverse NTT, CRT, centring and the slot-root FFT on the GPU
+            dest.resize(n / 2);
+            shim::check(hefx_ckks_decode(e->ctx, L, plain.buf->p, 1, plain.scale(), dest.data(), nullptr, nullptr));
+            return;
+        }
         auto tmp = shim::new_buf(e, (std::size_t)L * n);
         shim::check(hefx_copy(e->ctx, tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
         shim::check(hefx_ntt_inverse(e->ctx, tmp->p, 1, L, 0, nullptr));

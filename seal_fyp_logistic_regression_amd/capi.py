@@ -77,6 +77,7 @@ _SIGS = {
     "hefx_galois_permute": (_i, [_vp, _u32, _vp, _i, _vp, _vp]),
     "hefx_encrypt": (_i, [_vp, _i, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
     "hefx_decrypt": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
+    "hefx_ckks_decode": (_i, [_vp, _i, _vp, _i, C.c_double, _vp, _vp, _vp]),
     "hefx_event_create": (_i, [_vp, _pp]),
     "hefx_event_destroy": (_i, [_vp, _vp]),
     "hefx_event_record": (_i, [_vp, _vp, _vp]),

@@ -1251,3 +1251,74 @@ extern "C" int hefx_galois_permute(hefx_context *c, uint32_t galois_elt, const u
     HIPCHK(launch_galois_permute(c->T, perm, (const u64 *)in, rows, (u64 *)out, (hipStream_t)stream));
     return HEFX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------
+// CKKS decode on the GPU
+// ---------------------------------------------------------------------------------------------
+// mixed-radix digits of floor(Q/2) for Q = q_0 ... q_(L-1): little-endian big integer on the host
+static DecodeTables decode_tables(const hefx_context *c, int L)
+{
+    std::vector<u64> Q{1};
+    for (int j = 0; j < L; ++j) {  // Q *= q_j
+        u128 carry = 0;
+        for (auto &limb : Q) {
+            const u128 t = (u128)limb * c->primes[j] + carry;
+            limb = (u64)t;
+            carry = t >> 64;
+        }
+        if (carry) Q.push_back((u64)carry);
+    }
+    for (size_t i = 0; i < Q.size(); ++i)  // Q >>= 1 (Q is odd: floor)
+        Q[i] = (Q[i] >> 1) | (i + 1 < Q.size() ? Q[i + 1] << 63 : 0);
+    DecodeTables D{};
+    for (int j = 0; j < L; ++j) {  // digit j = Q mod q_j; Q /= q_j
+        u128 rem = 0;
+        for (size_t i = Q.size(); i-- > 0;) {
+            const u128 cur = (rem << 64) | Q[i];
+            Q[i] = (u64)(cur / c->primes[j]);
+            rem = cur % c->primes[j];
+        }
+        D.half[j] = (u64)rem;
+    }
+    return D;
+}
+
+extern "C" int hefx_ckks_decode(hefx_context *c, int L, const uint64_t *d_pt, int count, double scale, double *h_re,
+                                double *h_im, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (c->logn < 10 || c->logn > 15) return fail(HEFX_ERR_UNSUPPORTED, "GPU decode is built for poly_degree in [1024, 32768]");
+    if (L > 16) return fail(HEFX_ERR_UNSUPPORTED, "GPU decode handles at most 16 primes");
+    if (!d_pt || !h_re || count < 1) return fail(HEFX_ERR_INVALID, "plain is not valid for encryption parameters");
+    if (!(scale > 0)) return fail(HEFX_ERR_INVALID, "scale out of bounds");
+    if (int rc = ensure_encode_tables(c)) return rc;
+    const size_t N = c->n, words = (size_t)count * L * N;
+    const bool split = c->logn == 15;
+    if (int rc = ensure_scratch(c, (split ? 2 : 1) * words)) return rc;
+    const size_t ndbl = (size_t)count * N * 2;  // p [count][N] | re [count][N/2] | im [count][N/2]
+    if (c->vals_cap < ndbl) {
+        if (c->d_vals) {
+            HIPCHK(hipDeviceSynchronize());
+            HIPCHK(hipFree(c->d_vals));
+            c->d_vals = nullptr;
+            c->vals_cap = 0;
+        }
+        HIPCHK(hipMalloc((void **)&c->d_vals, ndbl * sizeof(double)));
+        c->vals_cap = ndbl;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    u64 *coef = c->scratch;
+    if (split) {
+        HIPCHK(launch_ntt_split15(c->T, true, (const u64 *)d_pt, coef, count, L, 0, s));
+    } else {
+        HIPCHK(hipMemcpyAsync(coef, d_pt, words * sizeof(u64), hipMemcpyDeviceToDevice, s));
+        HIPCHK(launch_ntt(c->T, true, coef, count, L, 0, s));
+    }
+    double *p = c->d_vals, *re = p + (size_t)count * N, *im = re + (size_t)count * (N / 2);
+    HIPCHK(launch_decode(c->T, c->E, decode_tables(c, L), L, coef, count, scale, p, re, h_im ? im : nullptr, s));
+    HIPCHK(hipMemcpyAsync(h_re, re, sizeof(double) * count * (N / 2), hipMemcpyDeviceToHost, s));
+    if (h_im) HIPCHK(hipMemcpyAsync(h_im, im, sizeof(double) * count * (N / 2), hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    return HEFX_OK;
+}

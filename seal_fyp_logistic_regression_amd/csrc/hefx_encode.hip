@@ -149,6 +149,183 @@ __global__ __launch_bounds__(FftCfg<LM>::T) void ckks_encode_kernel(DevTables T,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// CKKSEncoder::decode on the GPU: (1) CRT-compose every coefficient from its RNS residues (Garner mixed radix, exact
+// modular arithmetic), centre it against floor(Q/2) digit by digit, evaluate it in double (Horner over the mixed-radix
+// digits, ~L ulp) and divide by the scale; (2) evaluate p at the slot roots: with p real,
+//     A_r = sum_{k<N/2} (p_k + i (-1)^r p_{k+N/2}) zeta^{(2r+1) k},
+// i.e. for r = 2r' + par an N/2-point DFT (positive exponent) of c_k * zeta^{(2 par + 1) k}, c_k = p_k +- i p_{k+N/2};
+// slot i reads A_r at r = (3^i - 1)/2 or the conjugate of its mirror.  The positive-exponent DFT runs through the
+// same DIF passes as encode on conjugated data.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void decode_crt_kernel(DevTables T, DecodeTables D, int L, const u64 *__restrict__ coef,
+                                                         double inv_scale, double *__restrict__ p)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const size_t a = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t vec = blockIdx.y;
+    if (a >= n) return;
+    const u64 *__restrict__ c = coef + vec * L * n + a;
+    u64 d[16];
+    for (int j = 0; j < L; ++j) {  // Garner: d_j = ((r_j - d_0) q_0^-1 - d_1) q_1^-1 ... mod q_j
+        const ModConst mc = T.mods[j];
+        u64 t = c[(size_t)j * n];
+        for (int i = 0; i < j; ++i) {
+            const u64 di = barrett64(d[i], mc.q, mc.r1);
+            t = mulmod(submod(t, di, mc.q), T.invmod[(size_t)i * T.k + j].x, mc);
+        }
+        d[j] = t;
+    }
+    // x > floor(Q/2)?  compare the mixed-radix digits from the top
+    bool neg = false;
+    for (int j = L - 1; j >= 0; --j) {
+        if (d[j] != D.half[j]) {
+            neg = d[j] > D.half[j];
+            break;
+        }
+    }
+    if (neg) {  // y = Q - x, digit-wise with borrow (Q = (0, ..., 0 | 1))
+        u64 borrow = 0;
+        for (int j = 0; j < L; ++j) {
+            const u64 q = T.mods[j].q, sub = d[j] + borrow;  // < q + 1
+            if (sub == 0) {
+                d[j] = 0;
+                borrow = 0;
+            } else {
+                d[j] = q - sub;
+                borrow = 1;
+            }
+        }
+    }
+    double m = (double)d[L - 1];
+    for (int j = L - 2; j >= 0; --j) m = m * (double)T.mods[j].q + (double)d[j];
+    p[vec * n + a] = (neg ? -m : m) * inv_scale;
+}
+
+template <int LM, bool SPLIT>
+__global__ __launch_bounds__(FftCfg<LM>::T) void decode_fft_kernel(DevTables T, EncodeTables E,
+                                                                  const double *__restrict__ p, double *__restrict__ re,
+                                                                  double *__restrict__ im)
+{
+    using C = FftCfg<LM>;
+    extern __shared__ __align__(16) double2 fl[];
+    const int t = threadIdx.x, vec = blockIdx.y;
+    const int par = SPLIT ? blockIdx.x >> 1 : blockIdx.x, hh = SPLIT ? blockIdx.x & 1 : 0;
+    constexpr int FM = SPLIT ? 2 * C::M : C::M;  // N/2
+    const int N = 2 * FM;
+    const double *__restrict__ pv = p + (size_t)vec * N;
+    auto load = [&](int k) {  // conj(c_k * zeta^((2 par + 1) k)), zeta^j = conj(post[j]), zeta^N = -1
+        double2 c = make_double2(pv[k], par ? -pv[k + FM] : pv[k + FM]);
+        const int idx = par ? 3 * k : k;
+        double2 z = idx < N ? E.post[idx] : E.post[idx - N];  // conj(zeta^idx) up to sign
+        if (idx >= N) z = make_double2(-z.x, -z.y);
+        // c * conj(z) conjugated = conj(c) * z
+        return cmul(make_double2(c.x, -c.y), z);
+    };
+    double2 v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int k = t + C::T * e;
+        if (SPLIT) {
+            const double2 a0 = load(k), a1 = load(k + C::M);
+            v[e] = hh ? cmul(make_double2(a0.x - a1.x, a0.y - a1.y), E.wfft[k])
+                      : make_double2(a0.x + a1.x, a0.y + a1.y);
+        } else {
+            v[e] = load(k);
+        }
+    }
+#pragma unroll
+    for (int ps = 0; ps < C::FP; ++ps) {
+        const int LOGS = LM - 3 * (ps + 1);
+        const int S = 1 << LOGS;
+        const int b = t >> LOGS;
+        const int base = b * (8 * S) + (t & (S - 1));
+        if (ps > 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fl[base + S * e];
+        }
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int half = 4 >> u;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if (e & half) continue;
+                dif(v[e], v[e | half], E.wfft, base + S * e, half * S, FM);
+            }
+        }
+        if (ps + 1 < C::FP || C::R > 0) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fl[base + S * e] = v[e];
+            __syncthreads();
+        }
+    }
+    if (C::R > 0) {
+        constexpr int G = 1 << C::R, NG = 8 / G;
+#pragma unroll
+        for (int c = 0; c < NG; ++c)
+#pragma unroll
+            for (int e = 0; e < G; ++e) v[c * G + e] = fl[(t + C::T * c) * G + e];
+#pragma unroll
+        for (int u = 0; u < C::R; ++u) {
+            const int half = G >> (u + 1);
+#pragma unroll
+            for (int c = 0; c < NG; ++c)
+#pragma unroll
+                for (int e = 0; e < G; ++e) {
+                    if (e & half) continue;
+                    dif(v[c * G + e], v[c * G + (e | half)], E.wfft, (t + C::T * c) * G + e, half, FM);
+                }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int pos;
+        if (C::R == 0) {
+            pos = t * 8 + e;
+        } else {
+            constexpr int G = 1 << C::R;
+            pos = (t + C::T * (e / G)) * G + (e % G);
+        }
+        int rp = (int)(__brev((unsigned)pos) >> (32 - LM));
+        if (SPLIT) rp = 2 * rp + hh;
+        const int r = 2 * rp + par;
+        if (r >= FM) continue;  // A_(N-1-r) = conj(A_r): the upper half is redundant
+        const int sl = E.slot[r];
+        // A_r = conj(v) (the DFT ran on conjugated data); slot value = A_r, or conj(A_r) when r is the mirror root
+        const double2 A = make_double2(v[e].x, -v[e].y);
+        re[(size_t)vec * FM + (sl >> 1)] = A.x;
+        if (im) im[(size_t)vec * FM + (sl >> 1)] = (sl & 1) ? -A.y : A.y;
+    }
+}
+
+hipError_t launch_decode(const DevTables &T, const EncodeTables &E, const DecodeTables &D, int L, const u64 *coef,
+                         int count, double scale, double *p, double *re, double *im, hipStream_t s)
+{
+    const int n = 1 << T.logn;
+    hipLaunchKernelGGL(decode_crt_kernel, dim3((n + 255) / 256, count), dim3(256), 0, s, T, D, L, coef, 1.0 / scale, p);
+    const int lm = T.logn - 1;
+#define LAUNCHD(LMV, SPL)                                                                                        \
+    {                                                                                                            \
+        const size_t lds = sizeof(double2) * (size_t)FftCfg<LMV>::M;                                             \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(decode_fft_kernel<LMV, SPL>),                   \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                         \
+        hipLaunchKernelGGL((decode_fft_kernel<LMV, SPL>), dim3(SPL ? 4 : 2, count), dim3(FftCfg<LMV>::T), lds, s, T, \
+                           E, p, re, im);                                                                        \
+    }
+    switch (lm) {
+        case 9: LAUNCHD(9, false) break;
+        case 10: LAUNCHD(10, false) break;
+        case 11: LAUNCHD(11, false) break;
+        case 12: LAUNCHD(12, false) break;
+        case 13: LAUNCHD(13, false) break;
+        case 14: LAUNCHD(13, true) break;
+        default: return hipErrorInvalidValue;
+    }
+#undef LAUNCHD
+    return hipGetLastError();
+}
+
 hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double *re, const double *im, int nvalues,
                          int count, double scale, int L, u64 *out, hipStream_t s)
 {

@@ -96,6 +96,11 @@ struct EncodeTables {
     const double2 *pre;   // [N/2]  exp(-2 pi i r / N)
     const double2 *post;  // [N]    exp(-pi i k / N)
 };
+struct DecodeTables {
+    u64 half[16];  // mixed-radix digits of floor(Q_L / 2), Q_L = q_0 ... q_(L-1), radix (q_0, q_1, ...)
+};
+hipError_t launch_decode(const DevTables &T, const EncodeTables &E, const DecodeTables &D, int L, const u64 *coef,
+                         int count, double scale, double *p, double *re, double *im, hipStream_t s);
 hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double *re, const double *im, int nvalues,
                          int count, double scale, int L, u64 *out, hipStream_t s);
 // sampling + encrypt/decrypt arithmetic (hefx_sample.hip)

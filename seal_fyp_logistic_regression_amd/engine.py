@@ -308,6 +308,14 @@ class Engine:
                                                nvalues, count, float(scale), out.ptr, stream))
         return out
 
+    def ckks_decode(self, L, pt, scale, count=1, complex_out=True, stream=None):
+        """[count][L][N] NTT-form plaintexts -> [count][N/2] slot values (complex, or real if complex_out=False)"""
+        re = np.empty((count, self.N // 2), dtype=np.float64)
+        im = np.empty((count, self.N // 2), dtype=np.float64) if complex_out else None
+        capi.check(capi.lib().hefx_ckks_decode(self._h, L, pt.ptr, count, float(scale), re.ctypes.data,
+                                               im.ctypes.data if im is not None else None, stream))
+        return re + 1j * im if complex_out else re
+
     # ---- measurement
     def event(self):
         ev = C.c_void_p()

@@ -186,6 +186,9 @@ class GpuBackend:
     def decrypt(self, L, size, ct, sk):
         return self.engine.decrypt(L, size, ct, sk)
 
+    def ckks_decode(self, L, pt, scale):
+        return self.engine.ckks_decode(L, pt, scale)[0]
+
     def ckks_encode(self, L, values, scale):
         """[count][nvalues] slot values -> [count][L][N] NTT-form plaintexts, or None if N is outside the kernel's range"""
         if not 1024 <= self.N <= 32768:
@@ -588,6 +591,9 @@ class CKKSEncoder:
 
     def decode(self, plain: Plaintext) -> np.ndarray:
         ctx, be, N, L = self.ctx, self.ctx.backend, self.ctx.N, plain.parms_id()
+        dev = getattr(be, "ckks_decode", None) if self.device_encode else None
+        if dev is not None and L <= 16:  # inverse NTT, CRT, centring and the slot-root FFT on the GPU
+            return dev(L, plain.data, plain.scale)
         h = be.from_host(be.to_host(plain.data))
         rows = be.to_host(be.ntt_inverse(h, 1, L, 0))
         q = ctx.primes[:L]
