@@ -548,7 +548,8 @@ public:
     template <class Ctx>
     explicit KeyGenerator(const Ctx &context) : ctx_(shim::as_ptr(context))
     {
-        if (!ctx_->is_ckks()) return;  // BFV drivers only compile
+        // BFV drivers compile against the shim but stop here, with a message instead of a null payload later
+        if (!ctx_->is_ckks()) throw std::logic_error("BFV is not built in this shim (CKKS hot path only)");
         const int k = ctx_->k();
         auto &e = ctx_->engine();
         sk_.buf = shim::new_buf(e, (std::size_t)k * ctx_->n());
