@@ -153,6 +153,34 @@ int main()
               "hefx_linear_transform_plain: missing keys throw");
     }
 
+    // deferred rotations (shim::Engine::defer_*): every usage pattern must give the bits of immediate execution
+    {
+        auto run = [&](bool lazy) {
+            context->engine()->live();
+            context->engine()->lazy = lazy;
+            Ciphertext r1, r2, r3, m1, m2, t, chain, back;
+            evaluator.rotate_vector(ca, 1, gk, r1);    // kept AND multiplied: the product must not swallow it
+            evaluator.multiply_plain(r1, pb, m1);
+            evaluator.rotate_vector(ca, 1, gk, r2);    // same (source, element) as r1: computed once
+            evaluator.rotate_vector(ca, 3, gk, t);     // NAF chain, multiplied, then t is reassigned: fused
+            evaluator.multiply_plain(t, pb, m2);
+            evaluator.rotate_vector(m2, 2, gk, t);     // rotation of a recorded product
+            evaluator.rotate_vector(r1, 5, gk, chain); // rotation of a recorded rotation
+            evaluator.multiply(r2, cb, r3);            // tensor product with a recorded rotation
+            evaluator.rotate_vector_inplace(chain, -5, gk);
+            evaluator.multiply_plain_inplace(chain, pb);
+            std::vector<std::vector<uint64_t>> out;
+            for (const Ciphertext *c : {&r1, &r2, &m1, &m2, &t, &chain, &r3}) out.push_back(shim::download(c->buf));
+            context->engine()->lazy = true;
+            return out;
+        };
+        const auto a1 = run(true), a0 = run(false);
+        CHECK(a1 == a0, "deferred rotations / products == immediate execution, bit for bit (7 patterns)");
+        Ciphertext r;
+        evaluator.rotate_vector(ca, 2, gk, r);
+        CHECK(fabs(dec(r)[0] - 3.0) < 1e-5, "a recorded rotation is materialised by decrypt");
+    }
+
     // SEAL's error behaviour at the boundary
     Ciphertext low = ca;
     evaluator.mod_switch_to_next_inplace(low);

@@ -112,12 +112,51 @@ inline void check(int rc)
 // reference's habit of rebuilding SEALContext + Evaluator inside every Linear_Transform_Plain call
 // (helper.h:239-240) costs a map lookup.  Also owns a size-bucketed device-buffer pool: hipFree synchronises the
 // device, so freed payload buffers are recycled instead (all work is ordered on the default stream).
+struct Buf;
+using BufPtr = std::shared_ptr<Buf>;
+
 struct Engine {
-    hefx_context *ctx = nullptr;
+    hefx_context *ctx_raw = nullptr;
     std::uint32_t n = 0;
     std::vector<std::uint64_t> primes;
     std::mutex mu;
     std::map<std::size_t, std::vector<std::uint64_t *>> pool;
+
+    // ---- deferred rotations -------------------------------------------------------------------------------
+    // The reference issues its rotations one call at a time (helper.h:252-257: rotate_vector, multiply_plain, next
+    // diagonal ...), which would keep every launch at batch size 1.  rotate_vector and a multiply_plain of a rotation
+    // result are therefore RECORDED (their output buffers exist at once, only the contents are late) and run when
+    // anything else touches the engine (live()): all recorded key switches of one dependency depth go to the device
+    // as one batch, equal (source, Galois element) pairs are computed once, and a product whose rotated input
+    // nobody else holds is fused into the key switch.  Same bits as immediate execution: every key switch is a
+    // deterministic function of its inputs.  SEAL_SHIM_LAZY=0 turns the recording off.
+    struct KsNode {
+        BufPtr src, key, dst;
+        std::uint32_t elt;
+        int L, depth, ks_consumers, mul_consumers, mul_index;
+    };
+    struct MulNode {
+        int producer;
+        BufPtr pt, dst;  // pt: plaintext (multiply_plain) or the other ciphertext (multiply, ct = true)
+        bool ct;
+    };
+    std::vector<KsNode> pend_ks;
+    std::vector<MulNode> pend_mul;
+    std::map<std::pair<const std::uint64_t *, std::uint32_t>, int> pend_cse;  // (source, element) -> node
+    std::map<const std::uint64_t *, int> pend_dst;                           // output buffer -> node
+    std::map<const std::uint64_t *, int> pend_mul_dst;
+    bool lazy = true;
+
+    hefx_context *live()  // the context, with everything recorded so far submitted
+    {
+        if (!pend_ks.empty()) flush();
+        return ctx_raw;
+    }
+    BufPtr defer_rotation(const BufPtr &src, std::uint32_t elt, const BufPtr &key, int L, std::size_t words,
+                          const std::shared_ptr<Engine> &self);
+    BufPtr defer_multiply_plain(const BufPtr &a, const BufPtr &pt, std::size_t words, const std::shared_ptr<Engine> &self,
+                                bool ct = false);
+    inline void flush();
 
     std::uint64_t *alloc(std::size_t words)
     {
@@ -131,7 +170,7 @@ struct Engine {
             }
         }
         void *p = nullptr;
-        check(hefx_malloc(ctx, words * sizeof(std::uint64_t), &p));
+        check(hefx_malloc(ctx_raw, words * sizeof(std::uint64_t), &p));
         return static_cast<std::uint64_t *>(p);
     }
     void release(std::uint64_t *p, std::size_t words)
@@ -154,7 +193,8 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     e->primes = primes;
     int dev = 0;
     if (const char *d = std::getenv("HEFX_DEVICE")) dev = std::atoi(d);
-    check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx));
+    check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx_raw));
+    if (const char *l = std::getenv("SEAL_SHIM_LAZY")) e->lazy = std::atoi(l) != 0;
     (*registry)[key] = e;
     return e;
 }
@@ -172,18 +212,112 @@ struct Buf {
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
 };
-using BufPtr = std::shared_ptr<Buf>;
 inline BufPtr new_buf(const std::shared_ptr<Engine> &e, std::size_t words) { return std::make_shared<Buf>(e, words); }
+
+inline BufPtr Engine::defer_rotation(const BufPtr &src, std::uint32_t elt, const BufPtr &key, int L, std::size_t words,
+                                     const std::shared_ptr<Engine> &self)
+{
+    if (pend_mul_dst.count(src->p)) flush();  // a rotation of a recorded product: run what is recorded first
+    auto hit = pend_cse.find({src->p, elt});
+    if (hit != pend_cse.end() && pend_ks[hit->second].key == key && pend_ks[hit->second].L == L)
+        return pend_ks[hit->second].dst;
+    KsNode nd{src, key, new_buf(self, words), elt, L, 0, 0, 0, -1};
+    auto parent = pend_dst.find(src->p);
+    if (parent != pend_dst.end()) {
+        nd.depth = pend_ks[parent->second].depth + 1;
+        ++pend_ks[parent->second].ks_consumers;
+    }
+    pend_ks.push_back(nd);
+    const int idx = (int)pend_ks.size() - 1;
+    pend_cse[{src->p, elt}] = idx;
+    pend_dst[nd.dst->p] = idx;
+    return nd.dst;
+}
+
+// returns nullptr when `a` is not the output of a recorded rotation (the caller multiplies at once)
+inline BufPtr Engine::defer_multiply_plain(const BufPtr &a, const BufPtr &pt, std::size_t words,
+                                           const std::shared_ptr<Engine> &self, bool ct)
+{
+    auto it = pend_dst.find(a->p);
+    if (it == pend_dst.end()) return nullptr;
+    if (ct && (pend_dst.count(pt->p) || pend_mul_dst.count(pt->p))) return nullptr;  // other operand must be ready
+    MulNode m{it->second, pt, new_buf(self, words), ct};
+    KsNode &k = pend_ks[it->second];
+    if (ct)
+        ++k.ks_consumers;  // keeps the rotation from being fused away: the tensor product reads it
+    else
+        ++k.mul_consumers;
+    if (!ct) k.mul_index = (int)pend_mul.size();
+    pend_mul.push_back(m);
+    pend_mul_dst[m.dst->p] = (int)pend_mul.size() - 1;
+    return m.dst;
+}
+
+inline void Engine::flush()
+{
+    std::vector<KsNode> K;
+    std::vector<MulNode> M;
+    K.swap(pend_ks);
+    M.swap(pend_mul);
+    pend_cse.clear();
+    pend_dst.clear();
+    pend_mul_dst.clear();
+    int max_depth = 0;
+    for (const KsNode &k : K) max_depth = std::max(max_depth, k.depth);
+    std::vector<char> fused(K.size(), 0);
+    for (std::size_t i = 0; i < K.size(); ++i)  // the rotated input is held by this record only: never materialise it
+        fused[i] = K[i].mul_consumers == 1 && K[i].ks_consumers == 0 && K[i].dst.use_count() == 1;
+    std::vector<const std::uint64_t *> in, key, pts;
+    std::vector<std::uint64_t *> out;
+    std::vector<std::uint32_t> elts;
+    for (int depth = 0; depth <= max_depth; ++depth) {
+        std::map<int, std::vector<int>> by_level;
+        for (std::size_t i = 0; i < K.size(); ++i)
+            if (K[i].depth == depth) by_level[K[i].L].push_back((int)i);
+        for (auto &lv : by_level) {
+            for (int f = 0; f < 2; ++f) {
+                in.clear(), key.clear(), pts.clear(), out.clear(), elts.clear();
+                for (int i : lv.second) {
+                    if ((int)fused[i] != f) continue;
+                    in.push_back(K[i].src->p);
+                    key.push_back(K[i].key->p);
+                    elts.push_back(K[i].elt);
+                    if (f) {
+                        pts.push_back(M[K[i].mul_index].pt->p);
+                        out.push_back(M[K[i].mul_index].dst->p);
+                    } else {
+                        out.push_back(K[i].dst->p);
+                    }
+                }
+                if (in.empty()) continue;
+                if (f)
+                    check(hefx_rotate_multiply_plain_batch(ctx_raw, lv.first, (int)in.size(), in.data(), elts.data(),
+                                                           key.data(), pts.data(), out.data(), nullptr));
+                else
+                    check(hefx_apply_galois_batch(ctx_raw, lv.first, (int)in.size(), in.data(), elts.data(), key.data(),
+                                                  out.data(), nullptr));
+            }
+            for (const MulNode &m : M) {  // products whose rotated input stays visible: multiply separately
+                const KsNode &k = K[m.producer];
+                if (k.depth != depth || k.L != lv.first || fused[m.producer]) continue;
+                if (m.ct)
+                    check(hefx_multiply(ctx_raw, k.L, k.dst->p, m.pt->p, m.dst->p, nullptr));
+                else
+                    check(hefx_multiply_plain(ctx_raw, k.L, 2, 1, k.dst->p, m.pt->p, m.dst->p, nullptr));
+            }
+        }
+    }
+}
 inline BufPtr upload(const std::shared_ptr<Engine> &e, const std::vector<std::uint64_t> &h)
 {
     BufPtr b = new_buf(e, h.size());
-    check(hefx_upload(e->ctx, b->p, h.data(), h.size() * 8, nullptr));
+    check(hefx_upload(e->live(), b->p, h.data(), h.size() * 8, nullptr));
     return b;
 }
 inline std::vector<std::uint64_t> download(const BufPtr &b, std::size_t words = 0)
 {
     std::vector<std::uint64_t> h(words ? words : b->words);
-    check(hefx_download(b->eng->ctx, h.data(), b->p, h.size() * 8, nullptr));
+    check(hefx_download(b->eng->live(), h.data(), b->p, h.size() * 8, nullptr));
     return h;
 }
 
@@ -553,8 +687,8 @@ public:
         const int k = ctx_->k();
         auto &e = ctx_->engine();
         sk_.buf = shim::new_buf(e, (std::size_t)k * ctx_->n());
-        shim::check(hefx_sample_ternary(e->ctx, rnd_.key.data(), rnd_.stream(), 1, k, 0, sk_.buf->p, nullptr));
-        shim::check(hefx_ntt_forward(e->ctx, sk_.buf->p, 1, k, 0, nullptr));
+        shim::check(hefx_sample_ternary(e->live(), rnd_.key.data(), rnd_.stream(), 1, k, 0, sk_.buf->p, nullptr));
+        shim::check(hefx_ntt_forward(e->live(), sk_.buf->p, 1, k, 0, nullptr));
         sk_.host = shim::download(sk_.buf);
     }
 
@@ -579,7 +713,7 @@ public:
         const int k = ctx_->k();
         auto &e = ctx_->engine();
         auto s2 = shim::new_buf(e, (std::size_t)k * ctx_->n());
-        shim::check(hefx_multiply_plain(e->ctx, k, 1, 1, sk_.buf->p, sk_.buf->p, s2->p, nullptr));
+        shim::check(hefx_multiply_plain(e->live(), k, 1, 1, sk_.buf->p, sk_.buf->p, s2->p, nullptr));
         rk.keys[0] = kswitch_key(s2);
         return rk;
     }
@@ -616,7 +750,7 @@ private:
         for (std::uint32_t g : elts) {
             if (gk.has_key(g)) continue;
             auto sp = shim::new_buf(e, (std::size_t)k * ctx_->n());  // s(X^g), NTT domain, on the device
-            shim::check(hefx_galois_permute(e->ctx, g, sk_.buf->p, k, sp->p, nullptr));
+            shim::check(hefx_galois_permute(e->live(), g, sk_.buf->p, k, sp->p, nullptr));
             gk.keys[g] = kswitch_key(sp);
         }
         return gk;
@@ -629,14 +763,14 @@ private:
         const std::size_t n = ctx_->n();
         const std::size_t words = (std::size_t)npoly * rows * n;
         auto da = shim::new_buf(e, words), de = shim::new_buf(e, words);
-        shim::check(hefx_sample_uniform(e->ctx, rnd_.key.data(), rnd_.stream(), npoly, rows, 0, da->p, nullptr));
-        shim::check(hefx_sample_noise(e->ctx, rnd_.key.data(), rnd_.stream(), npoly, rows, 0, de->p, nullptr));
+        shim::check(hefx_sample_uniform(e->live(), rnd_.key.data(), rnd_.stream(), npoly, rows, 0, da->p, nullptr));
+        shim::check(hefx_sample_noise(e->live(), rnd_.key.data(), rnd_.stream(), npoly, rows, 0, de->p, nullptr));
         const std::vector<std::uint64_t> a = shim::download(da, words);
-        shim::check(hefx_ntt_forward(e->ctx, de->p, npoly, rows, 0, nullptr));
+        shim::check(hefx_ntt_forward(e->live(), de->p, npoly, rows, 0, nullptr));
         auto t = shim::new_buf(e, a.size());
-        shim::check(hefx_multiply_plain(e->ctx, rows, npoly, 1, da->p, sk_.buf->p, t->p, nullptr));
-        shim::check(hefx_add(e->ctx, rows, npoly, 1, t->p, de->p, t->p, nullptr));
-        shim::check(hefx_negate(e->ctx, rows, npoly, 1, t->p, t->p, nullptr));
+        shim::check(hefx_multiply_plain(e->live(), rows, npoly, 1, da->p, sk_.buf->p, t->p, nullptr));
+        shim::check(hefx_add(e->live(), rows, npoly, 1, t->p, de->p, t->p, nullptr));
+        shim::check(hefx_negate(e->live(), rows, npoly, 1, t->p, t->p, nullptr));
         return {t, a};
     }
 
@@ -647,7 +781,7 @@ private:
         const int k = ctx_->k();
         if (k < 2) throw std::logic_error("keyswitching is not supported by the context");
         auto key = shim::new_buf(e, (std::size_t)(k - 1) * 2 * k * ctx_->n());
-        shim::check(hefx_keygen_kswitch(e->ctx, sk_.buf->p, new_sk->p, rnd_.key.data(), 0x40000000ull + rnd_.stream(),
+        shim::check(hefx_keygen_kswitch(e->live(), sk_.buf->p, new_sk->p, rnd_.key.data(), 0x40000000ull + rnd_.stream(),
                                         key->p, nullptr));
         return key;
     }
@@ -674,7 +808,7 @@ public:
         const int L = plain.rows;
         auto c = shim::new_buf(e, (std::size_t)2 * L * ctx_->n());
         // sampling (u ternary, e0/e1 clipped normal), NTT and the dyadic arithmetic: one engine call
-        shim::check(hefx_encrypt(e->ctx, L, pk_.buf->p, plain.buf->p, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
+        shim::check(hefx_encrypt(e->live(), L, pk_.buf->p, plain.buf->p, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
         dest.set(c, 2, L, plain.parms_id(), plain.scale());
     }
 
@@ -696,7 +830,7 @@ public:
         auto &e = ctx_->engine();
         const int L = ct.rows;
         auto acc = shim::new_buf(e, (std::size_t)L * ctx_->n());
-        shim::check(hefx_decrypt(e->ctx, L, (int)ct.size(), ct.buf->p, sk_.buf->p, acc->p, nullptr));
+        shim::check(hefx_decrypt(e->live(), L, (int)ct.size(), ct.buf->p, sk_.buf->p, acc->p, nullptr));
         dest.buf = acc;
         dest.rows = L;
         dest.parms_id() = ct.parms_id();
@@ -758,7 +892,7 @@ public:
         }
         auto &e = ctx_->engine();
         dest.buf = shim::upload(e, rows);
-        shim::check(hefx_ntt_forward(e->ctx, dest.buf->p, 1, L, 0, nullptr));
+        shim::check(hefx_ntt_forward(e->live(), dest.buf->p, 1, L, 0, nullptr));
         finish(dest, L, id, scale, !any);
     }
     void encode(const std::vector<double> &values, double scale, Plaintext &dest) const
@@ -792,12 +926,12 @@ public:
         }();
         if (!host_only && L <= 16 && n >= 1024) {  // inverse NTT, CRT, centring and the slot-root FFT on the GPU
             dest.resize(n / 2);
-            shim::check(hefx_ckks_decode(e->ctx, L, plain.buf->p, 1, plain.scale(), dest.data(), nullptr, nullptr));
+            shim::check(hefx_ckks_decode(e->live(), L, plain.buf->p, 1, plain.scale(), dest.data(), nullptr, nullptr));
             return;
         }
         auto tmp = shim::new_buf(e, (std::size_t)L * n);
-        shim::check(hefx_copy(e->ctx, tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
-        shim::check(hefx_ntt_inverse(e->ctx, tmp->p, 1, L, 0, nullptr));
+        shim::check(hefx_copy(e->live(), tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
+        shim::check(hefx_ntt_inverse(e->live(), tmp->p, 1, L, 0, nullptr));
         const std::vector<std::uint64_t> co = shim::download(tmp);
         // CRT compose (Garner mixed radix -> little-endian limbs), centre, scale
         const auto &q = ctx_->primes();
@@ -869,7 +1003,7 @@ private:
         if (!zero && !nonzero) return false;
         auto &e = ctx_->engine();
         dest.buf = shim::new_buf(e, (std::size_t)L * n);
-        shim::check(hefx_ckks_encode(e->ctx, L, values.data(), nullptr, (int)values.size(), 1, scale, dest.buf->p, nullptr));
+        shim::check(hefx_ckks_encode(e->live(), L, values.data(), nullptr, (int)values.size(), 1, scale, dest.buf->p, nullptr));
         finish(dest, L, id, scale, zero);
         return true;
     }
@@ -1009,14 +1143,14 @@ public:
         std::vector<const std::uint64_t *> ptrs;
         for (auto &c : cts) ptrs.push_back(c.buf->p);
         auto out = shim::new_buf(e, words(cts[0].size(), L));
-        shim::check(hefx_add_many(e->ctx, L, (int)cts[0].size(), (int)cts.size(), ptrs.data(), out->p, nullptr));
+        shim::check(hefx_add_many(e->live(), L, (int)cts[0].size(), (int)cts.size(), ptrs.data(), out->p, nullptr));
         dest.set(out, cts[0].size(), L, cts[0].parms_id(), cts[0].scale());
     }
     void negate(const Ciphertext &a, Ciphertext &dest) const
     {
         check_ct(a);
         auto out = shim::new_buf(eng(), a.buf->words);
-        shim::check(hefx_negate(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
+        shim::check(hefx_negate(eng()->live(), a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
         dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
     }
     void negate_inplace(Ciphertext &a) const { negate(a, a); }
@@ -1026,7 +1160,7 @@ public:
         check_pt(a, p);
         if (!close(a.scale(), p.scale())) throw std::invalid_argument("scale mismatch");
         auto out = shim::new_buf(eng(), a.buf->words);
-        shim::check(hefx_add_plain(eng()->ctx, a.rows, (int)a.size(), a.buf->p, p.buf->p, out->p, nullptr));
+        shim::check(hefx_add_plain(eng()->live(), a.rows, (int)a.size(), a.buf->p, p.buf->p, out->p, nullptr));
         dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
     }
     void add_plain_inplace(Ciphertext &a, const Plaintext &p) const { add_plain(a, p, a); }
@@ -1038,8 +1172,14 @@ public:
         check_pt(a, p);
         const double ns = a.scale() * p.scale();
         check_scale(ns, a.parms_id());
+        if (eng()->lazy && a.size() == 2 && !p.is_zero()) {  // product of a recorded rotation: recorded with it
+            if (auto late = eng()->defer_multiply_plain(a.buf, p.buf, a.buf->words, eng())) {
+                dest.set(late, 2, a.rows, a.parms_id(), ns);
+                return;
+            }
+        }
         auto out = shim::new_buf(eng(), a.buf->words);
-        shim::check(hefx_multiply_plain(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, p.buf->p, out->p, nullptr));
+        shim::check(hefx_multiply_plain(eng()->live(), a.rows, (int)a.size(), 1, a.buf->p, p.buf->p, out->p, nullptr));
         // a valid ciphertext's c1 is uniformly random, so the product is transparent exactly when the plaintext
         // is zero -- known on the host since encode time; no device sync needed (why the reference adds 1e-8).
         if (p.is_zero()) throw std::logic_error("result ciphertext is transparent");
@@ -1055,11 +1195,17 @@ public:
             throw std::invalid_argument("multiply: only size-2 operands are built (every reference call site)");
         const double ns = a.scale() * b.scale();
         check_scale(ns, a.parms_id());
+        if (eng()->lazy && a.buf != b.buf) {  // tensor product with a recorded rotation (helper.h:227-228): recorded too
+            if (auto late = eng()->defer_multiply_plain(a.buf, b.buf, words(3, a.rows), eng(), true)) {
+                dest.set(late, 3, a.rows, a.parms_id(), ns);
+                return;
+            }
+        }
         auto out = shim::new_buf(eng(), words(3, a.rows));
         if (a.buf == b.buf)
-            shim::check(hefx_square(eng()->ctx, a.rows, a.buf->p, out->p, nullptr));
+            shim::check(hefx_square(eng()->live(), a.rows, a.buf->p, out->p, nullptr));
         else
-            shim::check(hefx_multiply(eng()->ctx, a.rows, a.buf->p, b.buf->p, out->p, nullptr));
+            shim::check(hefx_multiply(eng()->live(), a.rows, a.buf->p, b.buf->p, out->p, nullptr));
         dest.set(out, 3, a.rows, a.parms_id(), ns);
     }
     void multiply_inplace(Ciphertext &a, const Ciphertext &b) const { multiply(a, b, a); }
@@ -1074,7 +1220,7 @@ public:
         if (a.size() != 3) throw std::invalid_argument("encrypted size must be 2 or 3");
         if (!rk.has_key(0)) throw std::invalid_argument("not enough relinearization keys");
         auto out = shim::new_buf(eng(), words(2, a.rows));
-        shim::check(hefx_relinearize(eng()->ctx, a.rows, a.buf->p, rk.keys.at(0)->p, out->p, nullptr));
+        shim::check(hefx_relinearize(eng()->live(), a.rows, a.buf->p, rk.keys.at(0)->p, out->p, nullptr));
         a.set(out, 2, a.rows, a.parms_id(), a.scale());
     }
     void relinearize(const Ciphertext &a, const RelinKeys &rk, Ciphertext &dest) const
@@ -1087,7 +1233,7 @@ public:
         check_ct(a);
         if (a.rows <= 1) throw std::invalid_argument("end of modulus switching chain reached");
         auto out = shim::new_buf(eng(), words(a.size(), a.rows - 1));
-        shim::check(hefx_rescale_to_next(eng()->ctx, a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
+        shim::check(hefx_rescale_to_next(eng()->live(), a.rows, (int)a.size(), 1, a.buf->p, out->p, nullptr));
         dest.set(out, a.size(), a.rows - 1, ctx_->id_of_rows(a.rows - 1), a.scale() / (double)ctx_->primes()[a.rows - 1]);
     }
     void rescale_to_next_inplace(Ciphertext &a) const { rescale_to_next(a, a); }
@@ -1097,7 +1243,7 @@ public:
         const int L = target_rows(a.rows, id);
         if (L == a.rows) return;
         auto out = shim::new_buf(eng(), words(a.size(), L));
-        shim::check(hefx_mod_drop(eng()->ctx, a.rows, L, (int)a.size(), a.buf->p, out->p, nullptr));
+        shim::check(hefx_mod_drop(eng()->live(), a.rows, L, (int)a.size(), a.buf->p, out->p, nullptr));
         a.set(out, a.size(), L, id, a.scale());
     }
     void mod_switch_to_inplace(Plaintext &p, const parms_id_type &id) const
@@ -1106,7 +1252,7 @@ public:
         const int L = target_rows(p.rows, id);
         if (L == p.rows) return;
         auto out = shim::new_buf(eng(), words(1, L));
-        shim::check(hefx_mod_drop(eng()->ctx, p.rows, L, 1, p.buf->p, out->p, nullptr));
+        shim::check(hefx_mod_drop(eng()->live(), p.rows, L, 1, p.buf->p, out->p, nullptr));
         p.buf = out;
         p.rows = L;
         p.parms_id() = id;
@@ -1142,8 +1288,12 @@ public:
         rotation_plan(steps, gk, plan);
         shim::BufPtr cur = a.buf;
         for (std::uint32_t elt : plan) {
+            if (eng()->lazy) {  // recorded; runs batched with its siblings at the next non-rotation call
+                cur = eng()->defer_rotation(cur, elt, gk.keys.at(elt), a.rows, words(2, a.rows), eng());
+                continue;
+            }
             auto out = shim::new_buf(eng(), words(2, a.rows));
-            shim::check(hefx_apply_galois(eng()->ctx, a.rows, cur->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+            shim::check(hefx_apply_galois(eng()->live(), a.rows, cur->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
             cur = out;
         }
         dest.set(cur, 2, a.rows, a.parms_id(), a.scale());
@@ -1155,7 +1305,7 @@ public:
         const std::uint32_t elt = (std::uint32_t)(2 * ctx_->n() - 1);
         if (!gk.has_key(elt)) throw std::invalid_argument("Galois key not present");
         auto out = shim::new_buf(eng(), words(2, a.rows));
-        shim::check(hefx_apply_galois(eng()->ctx, a.rows, a.buf->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+        shim::check(hefx_apply_galois(eng()->live(), a.rows, a.buf->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
         dest.set(out, 2, a.rows, a.parms_id(), a.scale());
     }
     void complex_conjugate_inplace(Ciphertext &a, const GaloisKeys &gk) const { complex_conjugate(a, gk, a); }
@@ -1212,7 +1362,7 @@ public:
             keys.push_back(kv.second->p);
         }
         auto out = shim::new_buf(eng(), words(2, ct.rows));
-        shim::check(::hefx_linear_transform_plain(eng()->ctx, ct.rows, ct.buf->p, d, pts.data(), (int)keys.size(),
+        shim::check(::hefx_linear_transform_plain(eng()->live(), ct.rows, ct.buf->p, d, pts.data(), (int)keys.size(),
                                                   elts.data(), keys.data(), out->p, nullptr));
         dest.set(out, 2, ct.rows, ct.parms_id(), ns);
     }
@@ -1253,14 +1403,14 @@ private:
         const std::size_t mx = std::max(a.size(), b.size()), mn = std::min(a.size(), b.size());
         auto out = shim::new_buf(e, words(mx, L));
         auto f = sub ? hefx_sub : hefx_add;
-        shim::check(f(e->ctx, L, (int)mn, 1, a.buf->p, b.buf->p, out->p, nullptr));
+        shim::check(f(e->live(), L, (int)mn, 1, a.buf->p, b.buf->p, out->p, nullptr));
         if (mx > mn) {  // result size = max; extra polys are copied (negated when they come from b in a sub)
             const Ciphertext &big = a.size() > b.size() ? a : b;
             const std::size_t off = words(mn, L), cnt = words(mx - mn, L);
             if (sub && &big == &b)
-                shim::check(hefx_negate(e->ctx, L, (int)(mx - mn), 1, b.buf->p + off, out->p + off, nullptr));
+                shim::check(hefx_negate(e->live(), L, (int)(mx - mn), 1, b.buf->p + off, out->p + off, nullptr));
             else
-                shim::check(hefx_copy(e->ctx, out->p + off, big.buf->p + off, cnt * 8, nullptr));
+                shim::check(hefx_copy(e->live(), out->p + off, big.buf->p + off, cnt * 8, nullptr));
         }
         dest.set(out, mx, L, a.parms_id(), a.scale());
     }
