@@ -320,3 +320,38 @@ def test_full_size_properties(N, bits_):
     ev.relinearize_inplace(prod, rk)
     ev.rescale_to_next_inplace(prod)
     assert np.abs(encoder.decode(dec.decrypt(prod))[:d].real - a * b).max() < 1e-5
+
+
+def _vec(line):
+    import re
+    return [float(x) for x in re.findall(r"-?\d+\.\d+", line)]
+
+
+def test_reference_linear_transformation_benchmark_unchanged():
+    """The reference's benchmark driver behind its chart (linear_transformation.cpp: N=8192, d = 10/100/1000, plain
+    and cipher diagonals), compiled unchanged: every printed result row equals the expected row it prints next to it.
+    Runs through the shim's deferred rotations (batched submission of the loop's rotate/multiply calls)."""
+    import subprocess
+    r = subprocess.run([_driver("linear_transformation")], capture_output=True, text=True, timeout=900, cwd="/tmp")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    checked = 0
+    for i, ln in enumerate(lines):
+        if ln.startswith("Linear Transformation Set") and "Result" in ln:
+            got = _vec(lines[i + 1])
+            j = next(k for k in range(i + 1, i + 8) if lines[k].startswith("Expected output Set"))
+            want = _vec(lines[j + 1])
+            assert len(got) == len(want) == 6
+            assert np.allclose(got, want, rtol=1e-7, atol=2e-3), (ln, got, want)
+            checked += 1
+    assert checked == 6  # three sizes x (plain, cipher) diagonals
+
+
+def test_reference_polynomial_driver_unchanged():
+    import re
+    import subprocess
+    r = subprocess.run([_driver("polynomial")], input="3\n0.5\n1\n2\n0\n", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    act = [float(x) for x in re.findall(r"Actual : (-?[\d.]+)", r.stdout)]
+    exp = [float(x) for x in re.findall(r"Expected : (-?[\d.]+)", r.stdout)]
+    assert len(act) == len(exp) == 2 and np.allclose(act, exp, atol=1e-4)   # Horner and Tree, degree 3 at x = 0.5
