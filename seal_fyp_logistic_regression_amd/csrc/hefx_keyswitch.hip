@@ -427,10 +427,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         x = ud[e];
         y = ud[e + SC::H / 2];
     };
-    typename A::V f[16];
-    split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
     // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (0) left in S.p0.
-    // The operand loads of a group of 4 coefficients are issued before any of its stores.
     const size_t off = (size_t)h * SC::H;
     const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * SC::N + off;
     const u64 *__restrict__ addsrc =
@@ -438,20 +435,50 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const bool has_add = relin || c == 0;
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
+    typename A::V f[16];
+    if constexpr (KsWaves<LOGN>::FWD <= 2) {
+        // 256-VGPR builds (N <= 8192): the epilogue's operands are independent of the transform, so the first group's
+        // loads are issued BEFORE it (they land while the butterflies run) and the groups are software-pipelined --
+        // the loads of group g+1 are in flight while group g is computed and stored.  At the 128-VGPR cap of
+        // N = 16384 the extra buffers spill and cost more than they hide.
+        u64 a[2][4], sadd[2][4], pp[2][4];
+        auto fetch = [&](int hh, int bufi) {
 #pragma unroll
-    for (int hh = 0; hh < 4; ++hh) {
-        u64 a[4], sadd[4], pp[4];
+            for (int r = 0; r < 4; ++r) {
+                const int idx = C::idx_out(t, 4 * hh + r);
+                a[bufi][r] = acc[idx];
+                sadd[bufi][r] = has_add ? addsrc[idx] : 0;
+                pp[bufi][r] = pt ? pt[idx] : 0;
+            }
+        };
+        fetch(0, 0);
+        split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int idx = C::idx_out(t, 4 * hh + r);
-            a[r] = acc[idx];
-            sadd[r] = has_add ? addsrc[idx] : 0;
-            pp[r] = pt ? pt[idx] : 0;
+        for (int hh = 0; hh < 4; ++hh) {
+            const int cur = hh & 1;
+            if (hh + 1 < 4) fetch(hh + 1, cur ^ 1);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[C::idx_out(t, 4 * hh + r)] = md_epilogue(A{}, f[4 * hh + r], a[cur][r], sadd[cur][r], pp[cur][r],
+                                                             pt != nullptr, cx, T, sp, j, mc);
         }
+    } else {
+        split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-            dst[C::idx_out(t, 4 * hh + r)] =
-                md_epilogue(A{}, f[4 * hh + r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+        for (int hh = 0; hh < 4; ++hh) {
+            u64 a[4], sadd[4], pp[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int idx = C::idx_out(t, 4 * hh + r);
+                a[r] = acc[idx];
+                sadd[r] = has_add ? addsrc[idx] : 0;
+                pp[r] = pt ? pt[idx] : 0;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                dst[C::idx_out(t, 4 * hh + r)] =
+                    md_epilogue(A{}, f[4 * hh + r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+        }
     }
 }
 
