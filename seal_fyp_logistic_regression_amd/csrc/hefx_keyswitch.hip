@@ -39,6 +39,9 @@ struct KsWaves {
     static constexpr int INV = LOGN <= 14 ? 2 : 4;  // ks_intt_digits, ks_moddown_intt, rs_intt
     static constexpr int FWD = LOGN <= 13 ? 2 : 4;  // ks_ntt_digits, ks_moddown_finish, rs_finish
 #endif
+    // load batches of the first (split) stage: all sixteen coefficient pairs are fetched at once in the 256-VGPR
+    // builds of N <= 8192 (a few percent there; at N = 16384 the inverse kernels lose 5-15 % with one batch)
+    static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = FWD <= 2 ? 1 : 2;
 };
 
 namespace hefx {
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
     const ulonglong2 *__restrict__ src =
         reinterpret_cast<const ulonglong2 *>(S.xd + ((size_t)b * L + i) * SC::N);
     u64 v[16];
-    split_inv<LOGN>(v, src, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
+    split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
-    split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
     const ulonglong2 *__restrict__ src =
         reinterpret_cast<const ulonglong2 *>(S.acc + ((size_t)p * (L + 1) + L) * SC::N);  // p = b*2 + c
     u64 v[16];
-    split_inv<LOGN>(v, src, lds, ntt_tables(T, sp), mc, T.modsf[sp], t, h);
+    split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, sp), mc, T.modsf[sp], t, h);
     const u64 half = mc.q >> 1;
     u64 *__restrict__ ud = S.u + (size_t)p * SC::N + (size_t)h * SC::H;
 #pragma unroll
@@ -452,7 +455,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             }
         };
         fetch(0, 0);
-        split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
             const int cur = hh & 1;
@@ -463,7 +466,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                                                              pt != nullptr, cx, T, sp, j, mc);
         }
     } else {
-        split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
         for (int hh = 0; hh < 4; ++hh) {
             u64 a[4], sadd[4], pp[4];
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt
     const ulonglong2 *__restrict__ src =
         reinterpret_cast<const ulonglong2 *>(in + ((size_t)p * L + (L - 1)) * SC::N);
     u64 v[16];
-    split_inv<LOGN>(v, src, lds, ntt_tables(T, L - 1), T.mods[L - 1], T.modsf[L - 1], t, h);
+    split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, L - 1), T.mods[L - 1], T.modsf[L - 1], t, h);
     u64 *__restrict__ dd = d + (size_t)p * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
-    split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
     const size_t off = (size_t)h * SC::H;
     const u64 *__restrict__ src = in + ((size_t)poly * L + j) * SC::N + off;
     u64 *__restrict__ dst = out + ((size_t)poly * (L - 1) + j) * SC::N + off;

@@ -471,7 +471,9 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 // ld(r, x, y) delivers the raw words of coefficients idx_nat(t,r) and idx_nat(t,r)+N/2, `mode` says how they become
 // inputs (reduction / constant subtraction in the row's arithmetic policy); on return
 // v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
-template <int LOGN, class A, class LD>
+// NB = number of load batches of the first stage: 2 (eight pairs each) under the 128-VGPR cap, 1 (all sixteen pairs in
+// flight at once, one exposed memory latency instead of two) in the 256-VGPR builds.
+template <int LOGN, class A, class LD, int NB = 2>
 __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, const InMode &mode,
                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
                                               const typename A::Ctx &cx, int t, int h)
@@ -479,53 +481,54 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
     const typename A::TW w1 = tw[1];
     // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
     // select per element (which would make every row pay for the reduction)
+    constexpr int BS = 16 / NB;
     if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            u64 x[8], y[8];
+        for (int g = 0; g < NB; ++g) {
+            u64 x[BS], y[BS];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
+            for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                f[8 * g + r] = A::ct_half(A::template input<true>(x[r], mode, cx, mc),
-                                          A::template input<true>(y[r], mode, cx, mc), w1, cx, h);
+            for (int r = 0; r < BS; ++r)
+                f[BS * g + r] = A::ct_half(A::template input<true>(x[r], mode, cx, mc),
+                                           A::template input<true>(y[r], mode, cx, mc), w1, cx, h);
             HEFX_STAGE_FENCE();
         }
     } else {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            u64 x[8], y[8];
+        for (int g = 0; g < NB; ++g) {
+            u64 x[BS], y[BS];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) ld(8 * g + r, x[r], y[r]);
+            for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                f[8 * g + r] = A::ct_half(A::template input<false>(x[r], mode, cx, mc),
-                                          A::template input<false>(y[r], mode, cx, mc), w1, cx, h);
+            for (int r = 0; r < BS; ++r)
+                f[BS * g + r] = A::ct_half(A::template input<false>(x[r], mode, cx, mc),
+                                           A::template input<false>(y[r], mode, cx, mc), w1, cx, h);
             HEFX_STAGE_FENCE();
         }
     }
     ntt_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
 }
 
-template <int LOGN, class A, class LD>
+template <int LOGN, class A, class LD, int NB = 2>
 __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const InMode &mode, const ModConst &mc,
                                             u64 *lds, const typename A::TW *__restrict__ tw,
                                             const typename A::Ctx &cx, int t, int h)
 {
     typename A::V f[16];
-    split_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, h);
+    split_fwd_raw<LOGN, A, LD, NB>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = A::fwd_finish(f[r], cx);
 }
 
-template <int LOGN, class LD>
+template <int LOGN, int NB = 2, class LD>
 __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMode &mode, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
     if (mf.q != 0.0)
-        split_fwd_a<LOGN, ArithF64>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
+        split_fwd_a<LOGN, ArithF64, LD, NB>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
     else
-        split_fwd_a<LOGN, ArithU64>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
+        split_fwd_a<LOGN, ArithU64, LD, NB>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
 }
 
 // Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the
@@ -533,28 +536,30 @@ __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMo
 // `pairs` points at the row viewed as (value[2j], value[2j+1]) records.  The first stage is done in two batches
 // of eight pairs (+ eight twiddles for the odd half) with a scheduling fence between them: issuing all 16 pair
 // loads and 16 twiddle loads at once needs ~250 VGPRs in the FP64 policy and spilled heavily at the 128 cap.
-template <int LOGN, class A>
+template <int LOGN, class A, int NB = 2>
 __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
                                             const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t,
                                             int h)
 {
     using C = NttCfg<LOGN - 1>;
+    constexpr int BS = 16 / NB;
     typename A::V f[16];
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        ulonglong2 pr[8];
+    for (int g = 0; g < NB; ++g) {
+        ulonglong2 pr[BS];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) pr[r] = pairs[C::idx_out(t, 8 * g + r)];
+        for (int r = 0; r < BS; ++r) pr[r] = pairs[C::idx_out(t, BS * g + r)];
         if (h == 0) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) f[8 * g + r] = A::gs_half_sum(A::from_u64(pr[r].x), A::from_u64(pr[r].y), cx);
+            for (int r = 0; r < BS; ++r)
+                f[BS * g + r] = A::gs_half_sum(A::from_u64(pr[r].x), A::from_u64(pr[r].y), cx);
         } else {
-            typename A::TW w[8];
+            typename A::TW w[BS];
 #pragma unroll
-            for (int r = 0; r < 8; ++r) w[r] = itw[C::N + C::idx_out(t, 8 * g + r)];  // itw[N/2 + j]
+            for (int r = 0; r < BS; ++r) w[r] = itw[C::N + C::idx_out(t, BS * g + r)];  // itw[N/2 + j]
 #pragma unroll
-            for (int r = 0; r < 8; ++r)
-                f[8 * g + r] = A::gs_half_diff(A::from_u64(pr[r].x), A::from_u64(pr[r].y), w[r], cx);
+            for (int r = 0; r < BS; ++r)
+                f[BS * g + r] = A::gs_half_diff(A::from_u64(pr[r].x), A::from_u64(pr[r].y), w[r], cx);
         }
         HEFX_STAGE_FENCE();
     }
@@ -563,14 +568,14 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__re
     for (int r = 0; r < 16; ++r) v[r] = A::inv_finish(f[r], cx);
 }
 
-template <int LOGN>
+template <int LOGN, int NB = 2>
 __device__ __forceinline__ void split_inv(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
     if (mf.q != 0.0)
-        split_inv_a<LOGN, ArithF64>(v, pairs, lds, nt.itwf, ArithF64::make(mf), t, h);
+        split_inv_a<LOGN, ArithF64, NB>(v, pairs, lds, nt.itwf, ArithF64::make(mf), t, h);
     else
-        split_inv_a<LOGN, ArithU64>(v, pairs, lds, nt.itw, ArithU64::make(mc), t, h);
+        split_inv_a<LOGN, ArithU64, NB>(v, pairs, lds, nt.itw, ArithU64::make(mc), t, h);
 }
 
 }  // namespace hefx
