@@ -112,10 +112,18 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the engine has no CPU fallback")
+    # one rank per GPU.  HEFX_BENCH_BACKEND=gloo (development only) lets several ranks share the GPUs that exist, to
+    # exercise the multi-rank code path on a one-GPU box; the driver's runs use RCCL ("nccl").
+    backend = os.environ.get("HEFX_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from seal_fyp_logistic_regression_amd import Engine
 
@@ -162,7 +170,7 @@ def main():
     dt = time.perf_counter() - t0
     gpu_ms = e.event_elapsed_ms(ev0, ev1)  # HIP events on the stream the launches are issued on
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
