@@ -166,6 +166,16 @@ int hefx_linear_transform_plain_hoisted(hefx_context *ctx, int L, const uint64_t
                                         const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                         const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
 
+/* DOUBLE hoisting: besides the shared decomposition, the d-1 products diag_l * rot_l(ct_new) are accumulated in the
+ * extended basis (data primes + special prime) and modded down ONCE: per rotation only a gathered key MAC remains.
+ * d_diag_pts_keylevel[l] are KEY-LEVEL plaintexts ([k][N]: encode with parms_id = key level); L must be the top data
+ * level (k-1); direct Galois keys for 1..d-1.  One rounding instead of d-1: not the bits of the rotation-by-rotation
+ * sum (nor SEAL's); bit-exact against the oracle's statement of this algorithm (orc_lt_double_hoisted). */
+int hefx_linear_transform_plain_hoisted2(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
+                                         const uint64_t *const *d_diag_pts_keylevel, int nkeys,
+                                         const uint32_t *key_elts, const uint64_t *const *d_keys, uint64_t *d_out,
+                                         void *stream);
+
 /* ---- CKKSEncoder::encode(vector<double>, scale, plain) on the GPU (call sites
  *      matrix_mult_benchmark.cpp:291-323, logistic_regression_ckks.cpp:222-225,302-305, helper.h:333-343):
  *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->

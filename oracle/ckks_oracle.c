@@ -493,6 +493,38 @@ int orc_is_transparent(const orc_ctx *c, int L, int size, const uint64_t *ct)
 /* ------------------------------------------------------------------------------------------------
  * key switching (App. A.8): RNS digits, one special prime P = primes[k-1], rounded division by P.
  * ---------------------------------------------------------------------------------------------- */
+/* the mod-down of App. A.8 on CANONICAL accumulators S[2][L+1][N] (rows q_0..q_(L-1), P), added into ct[2][L][N]:
+ * ct[c][j] += (S[c][j] - NTT_j(((INTT_P(S[c][P]) + P/2) mod P) mod q_j - P/2 mod q_j)) * P^-1 mod q_j */
+static void moddown_into(const orc_ctx *c, int L, const uint64_t *S, uint64_t *ct)
+{
+    const uint64_t n = c->N;
+    const int sp = c->k - 1, nm = L + 1;
+    const mod_t *mp = &c->t[sp].m;
+    const uint64_t half = mp->q >> 1;
+    uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    for (int cc = 0; cc < 2; cc++) {
+        memcpy(d, S + ((size_t)cc * nm + L) * n, sizeof(uint64_t) * n);
+        orc_ntt_inv(c, sp, d);
+        for (uint64_t a = 0; a < n; a++) d[a] = barrett64(d[a] + half, mp);
+        for (int j = 0; j < L; j++) {
+            const mod_t *m = &c->t[j].m;
+            uint64_t half_j = barrett64(half, m);
+            uint64_t pinv = orc_invmod(mp->q % m->q, m->q);
+            for (uint64_t a = 0; a < n; a++) x[a] = submod(barrett64(d[a], m), half_j, m->q);
+            orc_ntt_fwd(c, j, x);
+            const uint64_t *aj = S + ((size_t)cc * nm + j) * n;
+            uint64_t *dst = ct + ((size_t)cc * L + j) * n;
+            for (uint64_t a = 0; a < n; a++) {
+                uint64_t v = submod(aj[a], x[a], m->q);
+                dst[a] = addmod(dst[a], mulmod_m(v, pinv, m), m->q);
+            }
+        }
+    }
+    free(d);
+    free(x);
+}
+
 /* tab == NULL: SEAL's key switch of `target` (App. A.8).
  * tab != NULL: the HOISTED variant (csrc/hefx_keyswitch.hip, ks_mac_hoisted_kernel): `target` is
  * the UNROTATED c1; its digits are extended to every modulus once and each extended row is read through the Galois
@@ -599,6 +631,80 @@ void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, ui
     memcpy(ct_out, res, sizeof(uint64_t) * (size_t)2 * L * n);
     free(tab);
     free(res);
+}
+
+/* DOUBLE-HOISTED linear transform, core (csrc/hefx_keyswitch.hip lt2_mac_kernel), top data level
+ * L = k-1: given ct_new [2][L][N], key-level diagonals diag[d][k][N] (NTT), Galois elements elt[1..d-1] and their
+ * keys key[l] ([k-1][2][k][N], l = 1..d-1 stored at index l-1):
+ *   S[c][m]  = sum_l diag_l[m] * (sum_i x_i[m][tab_l] * key_l[i][c][m])   over all k moduli (x_i = digit i of c1 extended)
+ *   out      = (diag_0*c0 + sum_l diag_l * c0[tab_l], diag_0*c1) + moddown(S)
+ * Every operation is exact modulo its prime, so the reduction points do not matter; the single mod-down rounds once. */
+void orc_lt_double_hoisted_core(const orc_ctx *c, int L, const uint64_t *ct_new, int d, const uint64_t *diag,
+                                const uint64_t *elts, const uint64_t *keys, uint64_t *out)
+{
+    const uint64_t n = c->N;
+    const int k = c->k, sp = k - 1, nm = L + 1;
+    uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)L * nm * n); /* x[i][jj] */
+    uint64_t *dg = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t *S = (uint64_t *)calloc((size_t)2 * nm * n, sizeof(uint64_t));
+    const uint64_t *c0 = ct_new, *c1 = ct_new + (size_t)L * n;
+    for (int i = 0; i < L; i++) {
+        memcpy(dg, c1 + (size_t)i * n, sizeof(uint64_t) * n);
+        orc_ntt_inv(c, i, dg);
+        for (int jj = 0; jj < nm; jj++) {
+            const int mi = jj < L ? jj : sp;
+            uint64_t *xr = x + ((size_t)i * nm + jj) * n;
+            if (mi == i) {
+                memcpy(xr, c1 + (size_t)i * n, sizeof(uint64_t) * n);
+            } else {
+                const uint64_t q = c->t[mi].m.q;
+                for (uint64_t a = 0; a < n; a++) xr[a] = dg[a] % q;
+                orc_ntt_fwd(c, mi, xr);
+            }
+        }
+    }
+    /* out = diag_0 * ct_new (both polys, data primes) */
+    for (int cc = 0; cc < 2; cc++)
+        for (int j = 0; j < L; j++) {
+            const uint64_t q = c->t[j].m.q;
+            const uint64_t *src = ct_new + ((size_t)cc * L + j) * n, *d0 = diag + (size_t)j * n;
+            uint64_t *o = out + ((size_t)cc * L + j) * n;
+            for (uint64_t a = 0; a < n; a++) o[a] = (uint64_t)((u128)src[a] * d0[a] % q);
+        }
+    for (int l = 1; l < d; l++) {
+        const uint64_t *dl = diag + (size_t)l * k * n;
+        const uint64_t *key = keys + (size_t)(l - 1) * (k - 1) * 2 * k * n;
+        orc_galois_table(n, elts[l], tab);
+        for (int jj = 0; jj < nm; jj++) {
+            const int mi = jj < L ? jj : sp;
+            const uint64_t q = c->t[mi].m.q;
+            for (int cc = 0; cc < 2; cc++) {
+                uint64_t *Sr = S + ((size_t)cc * nm + jj) * n;
+                for (uint64_t a = 0; a < n; a++) {
+                    u128 acc = 0;
+                    for (int i = 0; i < L; i++) {
+                        const uint64_t xv = x[((size_t)i * nm + jj) * n + tab[a]];
+                        const uint64_t kv = key[((((size_t)i * 2 + cc) * k) + mi) * n + a];
+                        acc += (u128)xv * kv % q;
+                    }
+                    const uint64_t inner = (uint64_t)(acc % q);
+                    Sr[a] = (uint64_t)(((u128)Sr[a] + (u128)inner * dl[(size_t)mi * n + a] % q) % q);
+                }
+            }
+        }
+        for (int j = 0; j < L; j++) { /* C0 += diag_l * c0[tab_l] */
+            const uint64_t q = c->t[j].m.q;
+            uint64_t *o = out + (size_t)j * n;
+            for (uint64_t a = 0; a < n; a++)
+                o[a] = (uint64_t)(((u128)o[a] + (u128)c0[(size_t)j * n + tab[a]] * dl[(size_t)j * n + a] % q) % q);
+        }
+    }
+    moddown_into(c, L, S, out);
+    free(tab);
+    free(x);
+    free(dg);
+    free(S);
 }
 
 /* apply_galois_inplace, CKKS size-2 (App. A.7): c0' = perm(c0) + ks0, c1' = ks1 */

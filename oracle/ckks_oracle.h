@@ -110,6 +110,11 @@ void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, doubl
 void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
                               uint64_t *ct_out);
 
+/* double-hoisted linear transform, core on ct_new (second fast mode; see ckks_oracle.c); elts[l], l = 1..d-1;
+ * keys = [d-1][k-1][2][k][N]; diag = [d][k][N] key-level plaintexts; L must be k-1 */
+void orc_lt_double_hoisted_core(const orc_ctx *c, int L, const uint64_t *ct_new, int d, const uint64_t *diag,
+                                const uint64_t *elts, const uint64_t *keys, uint64_t *out);
+
 /* ---- counter-mode sampling: CPU statement of csrc/hefx_sample.hip (see ckks_oracle.c for the specification) */
 void orc_chacha20_block(const uint32_t key[8], uint64_t counter, uint64_t nonce, uint32_t out[16]);
 void orc_noise_thresholds(uint64_t t[39]);

@@ -69,6 +69,7 @@ def lib():
     sig("orc_switch_key", None, vp, i, u64p, u64p, u64p)
     sig("orc_apply_galois", None, vp, i, u64p, u64, u64p, u64p)
     sig("orc_apply_galois_hoisted", None, vp, i, u64p, u64, u64p, u64p)
+    sig("orc_lt_double_hoisted_core", None, vp, i, u64p, i, u64p, u64p, u64p, u64p)
     sig("orc_relinearize", None, vp, i, u64p, u64p, u64p)
     sig("orc_rescale", None, vp, i, i, u64p, u64p, i)
     sig("orc_mod_drop", None, vp, i, i, i, u64p, u64p)
@@ -221,6 +222,17 @@ class Oracle:
         """hoisted-rotation fast mode (decompose, then permute): NOT SEAL's bits, see ckks_oracle.c"""
         out = np.zeros_like(ct)
         lib().orc_apply_galois_hoisted(self._h, ct.shape[1], np.ascontiguousarray(ct), elt, key, out)
+        return out
+
+    def lt_double_hoisted_core(self, ct_new, diags_keylevel, elts, keys):
+        """second fast mode: ct_new [2][L][N], diags [d][k][N], elts[1..d-1] (index 0 ignored), keys list for l>=1"""
+        d = len(diags_keylevel)
+        L = ct_new.shape[1]
+        diag = np.ascontiguousarray(np.stack(diags_keylevel), dtype=np.uint64)
+        kk = np.ascontiguousarray(np.stack(keys), dtype=np.uint64) if keys else np.zeros(1, dtype=np.uint64)
+        e = np.ascontiguousarray(np.asarray([0] + list(elts), dtype=np.uint64))
+        out = np.zeros_like(ct_new)
+        lib().orc_lt_double_hoisted_core(self._h, L, np.ascontiguousarray(ct_new), d, diag, e, kk, out)
         return out
 
     def switch_key(self, ct, target, key):

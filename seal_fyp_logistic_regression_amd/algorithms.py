@@ -85,11 +85,17 @@ def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[
                            gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
     """Linear_Transform_Plain, helper.h:237-262 (= linear_transformation2.cpp:149-174).
 
+    hoisted=2 is the double-hoisted fast mode: U_diagonals must be KEY-LEVEL plaintexts (encoder.encode(..., parms_id =
+    context.key_parms_id())), ct at the top data level; the products are accumulated over the extended basis and modded
+    down once (hefx_linear_transform_plain_hoisted2) -- per rotation only a gathered key MAC remains.
+
     hoisted=True is the fast mode of SURVEY 8f rank 3: the d-1 rotations of ct_new share one digit decomposition
     (hefx_rotate_hoisted_batch).  It needs a direct Galois key per step (keygen.galois_keys(steps)) and is NOT
     bit-identical to the reference's sequence (signed instead of positive digit lifts where the automorphism
     negates a coefficient); it decrypts to the same values with the same noise bound."""
     d = len(U_diagonals)
+    if hoisted == 2:
+        return _linear_transform_plain_hoisted2(ev, ct, U_diagonals, gal_keys)
     if hoisted:
         return _linear_transform_plain_hoisted(ev, ct, U_diagonals, gal_keys)
     native = getattr(ev.be, "linear_transform_plain", None)
@@ -102,15 +108,49 @@ def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[
     return ev.add_many(res)                                          # :259
 
 
+def _linear_transform_plain_hoisted2(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
+                                     gal_keys: KSwitchKeys) -> Ciphertext:
+    ctx, be = ev.ctx, ev.be
+    d, L = len(U_diagonals), ct.parms_id()
+    if ct.size() != 2:
+        raise ValueError("encrypted size must be 2")
+    if L != ctx.first_parms_id():
+        raise ValueError("double hoisting is built for the top data level")
+    scale = None
+    for p in U_diagonals:
+        if p.parms_id() != ctx.k:
+            raise ValueError("double hoisting needs key-level plaintexts (encode with parms_id = key level)")
+        s = ct.scale * p.scale
+        ev._check_scale(s, L)
+        if scale is not None and not ev._close(scale, s):
+            raise ValueError("scale mismatch")
+        scale = s if scale is None else scale
+        if p.is_zero:
+            raise RuntimeError("result ciphertext is transparent")
+    native = getattr(be, "linear_transform_plain", None)
+    if native is not None:  # plans, key checks and everything else behind one C-ABI call (errors come back as ValueError)
+        elts = sorted(gal_keys.keys)
+        data = native(L, ct.data, [p.data for p in U_diagonals], elts, [gal_keys.key(e) for e in elts], hoisted=2)
+    else:  # the oracle twin: regular -d rotation, then the oracle's statement of the double-hoisted core
+        plans = [ev.rotation_plan(l, gal_keys) for l in range(1, d)]
+        if any(len(p) != 1 for p in plans):
+            raise ValueError("hoisted linear transform needs a direct Galois key for every step 1..d-1")
+        ct_new = ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))
+        elts = [p[0] for p in plans]
+        data = be.lt_double_hoisted_core(ct_new.data, [p.data for p in U_diagonals], elts,
+                                         [gal_keys.key(e) for e in elts])
+    return Ciphertext()._set(data, 2, L, scale)
+
+
 def _linear_transform_plain_hoisted(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
                                     gal_keys: KSwitchKeys) -> Ciphertext:
     d, L = len(U_diagonals), ct.parms_id()
+    native = getattr(ev.be, "linear_transform_plain", None)
+    if native is not None:  # one C-ABI call (hefx_linear_transform_plain_hoisted), which also checks the keys
+        return _linear_transform_plain_native(ev, native, ct, U_diagonals, gal_keys, hoisted=True)
     plans = [ev.rotation_plan(l, gal_keys) for l in range(1, d)]
     if any(len(p) != 1 for p in plans):
         raise ValueError("hoisted linear transform needs a direct Galois key for every step 1..d-1")
-    native = getattr(ev.be, "linear_transform_plain", None)
-    if native is not None:  # one C-ABI call (hefx_linear_transform_plain_hoisted)
-        return _linear_transform_plain_native(ev, native, ct, U_diagonals, gal_keys, hoisted=True)
     ct_new = ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))          # helper.h:244-247, regular rotation
     res = [ev.multiply_plain(ct_new, U_diagonals[0])]                # :250
     for p in U_diagonals[1:]:

@@ -1126,6 +1126,90 @@ extern "C" int hefx_linear_transform_plain_hoisted(hefx_context *c, int L, const
 {
     return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, true);
 }
+// Double-hoisted Linear_Transform_Plain (see lt2_mac_kernel): top data level, direct keys for 1..d-1, diagonals
+// encoded at the KEY level ([k][N]: data primes then the special prime).
+extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, const uint64_t *ct, int d,
+                                                    const uint64_t *const *diag_pts_keylevel, int nkeys,
+                                                    const uint32_t *key_elts, const uint64_t *const *keys,
+                                                    uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (L != c->k - 1) return fail(HEFX_ERR_UNSUPPORTED, "double hoisting is built for the top data level");
+    if (!ct || !out || d < 1 || !diag_pts_keylevel || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+        return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    for (int i = 0; i < d; ++i)
+        if (!diag_pts_keylevel[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    LtKeys K;
+    for (int i = 0; i < nkeys; ++i) {
+        if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
+        K.m[key_elts[i]] = keys[i];
+    }
+    const size_t N = c->n, ctw = 2 * (size_t)L * N;
+    const int k = c->k, nrot = d - 1, chunks = nrot > 0 ? (nrot + lt2_chunk() - 1) / lt2_chunk() : 0;
+    std::vector<uint32_t> first, plan;
+    if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
+    std::vector<KsItem> items((size_t)d + 1);  // [0]: source (ct_new); [1..d-1]: rotations; [d]: the mod-down
+    // ---- workspace
+    const size_t ws_words = 4 * ctw + (size_t)chunks * (2 * (size_t)k + L) * N + (items.size() * sizeof(KsItem) + 7) / 8;
+    if (c->lt_cap < ws_words) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
+        c->lt_ws = nullptr;
+        c->lt_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->lt_ws, ws_words * sizeof(u64)));
+        c->lt_cap = ws_words;
+    }
+    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw, *cbuf = ct_new + ctw;
+    u64 *partial_s = reinterpret_cast<u64 *>(cbuf + ctw), *partial_c0 = partial_s + (size_t)chunks * 2 * k * N;
+    KsItem *d_items = reinterpret_cast<KsItem *>(partial_c0 + (size_t)chunks * L * N);
+    for (int l = 1; l < d; ++l) {
+        plan.clear();
+        if (const char *err = lt_plan(l, N, K, plan)) return fail(HEFX_ERR_INVALID, err);
+        if (plan.size() != 1)
+            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
+        KsItem &it = items[l];
+        it.c_in = nullptr;
+        it.c_out = nullptr;
+        it.key = (const u64 *)K.m[plan[0]];
+        it.pt = (const u64 *)diag_pts_keylevel[l];
+        if (int rc = get_perm(c, plan[0], &it.perm)) return rc;
+    }
+    items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr};
+    items[d] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out};
+    // ---- ct_new = ct + rotate(ct, -d); cbuf = ct_new * diag_0
+    const uint64_t *src = ct;
+    for (size_t t = 0; t < first.size(); ++t) {
+        uint64_t *dst = (t & 1) ? pong : ping;
+        const uint64_t *key = K.m[first[t]];
+        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
+        src = dst;
+    }
+    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
+    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts_keylevel[0], cbuf, stream)) return rc;
+    if (nrot == 0) {
+        HIPCHK(hipMemcpyAsync(out, cbuf, ctw * sizeof(u64), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return HEFX_OK;
+    }
+    // ---- decomposition of ct_new (once), gathered MACs of all rotations, one mod-down
+    const size_t per = ks_words_per_item(c, L) + ks_x_words(c, L, 1);
+    if (int rc = ensure_scratch(c, per)) return rc;
+    KsScratch S;
+    S.d = c->scratch;
+    S.xd = S.d + (size_t)L * N;
+    S.acc = S.xd + (size_t)L * N;
+    S.u = S.acc + (size_t)2 * (L + 1) * N;
+    S.p0 = S.u + (size_t)2 * N;
+    S.x = S.p0 + (size_t)L * N;
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(hipMemcpyAsync(d_items, items.data(), sizeof(KsItem) * items.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // `items` is a local
+    HIPCHK(launch_lt2_decompose(c->T, L, d_items, d_items + 1, nrot, S, (const u64 *)ct_new, partial_s, partial_c0,
+                                (u64 *)cbuf, s));
+    HIPCHK(launch_lt2_moddown(c->T, L, d_items + d, S, s));
+    return HEFX_OK;
+}
+
 extern "C" int hefx_rotate_hoisted_batch(hefx_context *c, int L, const uint64_t *ct_in, int n, const uint32_t *elts,
                                          const uint64_t *const *keys, const uint64_t *const *pts,
                                          uint64_t *const *ct_out, void *stream)

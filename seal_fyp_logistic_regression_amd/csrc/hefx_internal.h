@@ -86,6 +86,12 @@ struct KsProf {
 };
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof);
+// double-hoisted linear transform (hefx_keyswitch.hip): see lt2_mac_kernel
+hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,
+                                const KsScratch &scr, const u64 *ct_new, u64 *partial_s, u64 *partial_c0, u64 *cbuf,
+                                hipStream_t s);
+hipError_t launch_lt2_moddown(const DevTables &T, int L, const KsItem *item, const KsScratch &scr, hipStream_t s);
+int lt2_chunk();
 // out-of-place split NTT for N = 32768 (rows do not fit one workgroup's LDS)
 hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, u64 *dst, int npoly, int nrows,
                               int mod_first, hipStream_t s);

@@ -280,6 +280,81 @@ __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const 
 }
 
 // ------------------------------------------------------------------------------------------------
+// DOUBLE HOISTING (second fast mode of the linear transform): besides sharing the digit
+// decomposition, the d-1 products diag_l * rot_l(ct_new) are SUMMED IN THE EXTENDED BASIS (q_0..q_(L-1), P) and modded
+// down once -- per rotation only a gathered MAC remains, no transform at all:
+//   S[c][jj]  = sum_l diag_l[jj] * ( sum_i x[i][jj][perm_l] * key_l[i][c][jj] )        (all L+1 moduli)
+//   C0[j]     = sum_l diag_l[j]  * c0[j][perm_l]                                        (data primes)
+//   out       = (diag_0*c0 + C0, diag_0*c1) + moddown(S)
+// mod-down rounds once instead of d-1 times, so the result differs from the rotation-by-rotation sum in the last
+// bits of noise (like any BSGS / double-hoisted evaluation); it is bit-exact against the oracle's statement of this
+// algorithm.  The diagonals must be encoded over the special prime too (key-level plaintexts); top data level only.
+// Workgroups own a chunk of LT2_CHUNK rotations and write partial sums that a wide add_many reduces.
+// ------------------------------------------------------------------------------------------------
+constexpr int LT2_CHUNK = 8;
+
+__global__ __launch_bounds__(256) void lt2_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int nrot,
+                                                      KsScratch S, u64 *__restrict__ partial /* [chunks][2][L+1][N] */)
+{
+    const int logn = T.logn;
+    const size_t n = (size_t)1 << logn;
+    const int jj = blockIdx.y, ch = blockIdx.z;
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    MacAcc tot;
+    const int l0 = ch * LT2_CHUNK, l1 = l0 + LT2_CHUNK < nrot ? l0 + LT2_CHUNK : nrot;
+    for (int l = l0; l < l1; ++l) {
+        const KsItem it = items[l];
+        const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
+        MacAcc A;
+        for (int i = 0; i < L; ++i) {
+            const u64 *__restrict__ xrow = i == jj ? S.xd + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
+            ulonglong2 x;
+            x.x = xrow[pi.x];
+            x.y = xrow[pi.y];
+            const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
+            A.mac(x, reinterpret_cast<const ulonglong2 *>(kbase)[w],
+                  reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w]);
+        }
+        ulonglong2 r0, r1;
+        r0.x = barrett128(A.a0xl, A.a0xh, mc);
+        r0.y = barrett128(A.a0yl, A.a0yh, mc);
+        r1.x = barrett128(A.a1xl, A.a1xh, mc);
+        r1.y = barrett128(A.a1yl, A.a1yh, mc);
+        const ulonglong2 dg = reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)m * n)[w];  // key-level plaintext row m
+        mac128(tot.a0xl, tot.a0xh, r0.x, dg.x);
+        mac128(tot.a0yl, tot.a0yh, r0.y, dg.y);
+        mac128(tot.a1xl, tot.a1xh, r1.x, dg.x);
+        mac128(tot.a1yl, tot.a1yh, r1.y, dg.y);
+    }
+    u64 *base = partial + (size_t)ch * 2 * (L + 1) * n;
+    tot.store(base + (size_t)jj * n, base + ((size_t)(L + 1) + jj) * n, w, mc);
+}
+
+// partial C0[ch][j] = sum_{l in chunk} diag_l[j] * c0[j][perm_l]
+__global__ __launch_bounds__(256) void lt2_c0_kernel(DevTables T, const KsItem *__restrict__ items, int L, int nrot,
+                                                     const u64 *__restrict__ c0, u64 *__restrict__ partial /* [chunks][L][N] */)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const int j = blockIdx.y, ch = blockIdx.z;
+    const ModConst mc = T.mods[j];
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    u64 xl = 0, xh = 0, yl = 0, yh = 0;
+    const int l0 = ch * LT2_CHUNK, l1 = l0 + LT2_CHUNK < nrot ? l0 + LT2_CHUNK : nrot;
+    const u64 *__restrict__ row = c0 + (size_t)j * n;
+    for (int l = l0; l < l1; ++l) {
+        const KsItem it = items[l];
+        const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
+        const ulonglong2 dg = reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)j * n)[w];
+        mac128(xl, xh, row[pi.x], dg.x);
+        mac128(yl, yh, row[pi.y], dg.y);
+    }
+    reinterpret_cast<ulonglong2 *>(partial + ((size_t)ch * L + j) * n)[w] =
+        make_ulonglong2(barrett128(xl, xh, mc), barrett128(yl, yh, mc));
+}
+
+// ------------------------------------------------------------------------------------------------
 // (2+3 fused) acc[b][c][jj] = sum_i NTT_m([d[b][i]]_m) * key[i][c][m] for one half h of one target modulus jj:
 // the workgroup walks the L digits, transforms each one (8 coefficients per thread, hefx_ntt8.cuh) and multiplies
 // the result straight into two 128-bit accumulators per coefficient that live in registers for the whole loop.
@@ -596,6 +671,69 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     return hipGetLastError();
 }
 
+// out[r] = (addin ? addin[r] : 0) + sum_ch partial[ch][r] for `rows` rows of N words; the modulus of row r is
+// q_(r % period) for r % period < L, the special prime otherwise (period = L+1 for S, L for C0)
+__global__ __launch_bounds__(256) void lt2_reduce_kernel(DevTables T, int L, int period, int rows, int chunks,
+                                                         const u64 *__restrict__ partial, const u64 *addin, u64 *out)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const int r = blockIdx.y;
+    const int jj = r % period;
+    const u64 q = T.mods[jj < L ? jj : T.k - 1].q;
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    ulonglong2 acc = addin ? reinterpret_cast<const ulonglong2 *>(addin + (size_t)r * n)[w] : make_ulonglong2(0, 0);
+    for (int ch = 0; ch < chunks; ++ch) {
+        const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(partial + ((size_t)ch * rows + r) * n)[w];
+        acc.x = addmod(acc.x, v.x, q);
+        acc.y = addmod(acc.y, v.y, q);
+    }
+    reinterpret_cast<ulonglong2 *>(out + (size_t)r * n)[w] = acc;
+}
+
+// double hoisting, device side: decompose ct_new once (item 0 of `src_item`: c_in = ct_new, no permutation), partial
+// sums of the rotations, then -- after the caller has reduced the partials into scr.acc / cbuf -- the single mod-down
+template <int LOGN>
+static hipError_t launch_lt2_decompose_t(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items,
+                                         int nrot, const KsScratch &scr, const u64 *ct_new, u64 *partial_s,
+                                         u64 *partial_c0, u64 *cbuf, hipStream_t s)
+{
+    using SC = SplitCfg<LOGN>;
+    const size_t lds = SC::LDS_BYTES;
+    static bool attr_done = false;
+    if (!attr_done) {
+        set_lds(ks_intt_digits_kernel<LOGN>, lds);
+        set_lds(ks_ntt_digits_kernel<LOGN>, lds);
+        set_lds(ks_moddown_intt_kernel<LOGN>, lds);
+        set_lds(ks_moddown_finish_kernel<LOGN>, lds);
+        attr_done = true;
+    }
+    const int chunks = (nrot + LT2_CHUNK - 1) / LT2_CHUNK;
+    hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, src_item, L, 0, 0, 1, scr);
+    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
+    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, scr);
+    hipLaunchKernelGGL(lt2_mac_kernel, dim3(SC::N / 2 / 256, L + 1, chunks), dim3(256), 0, s, T, rot_items, L, nrot, scr,
+                       partial_s);
+    hipLaunchKernelGGL(lt2_c0_kernel, dim3(SC::N / 2 / 256, L, chunks), dim3(256), 0, s, T, rot_items, L, nrot, ct_new,
+                       partial_c0);
+    // S -> scr.acc [2][L+1][N];  C0 += partials, in place on poly 0 of cbuf
+    hipLaunchKernelGGL(lt2_reduce_kernel, dim3(SC::N / 2 / 256, 2 * (L + 1)), dim3(256), 0, s, T, L, L + 1, 2 * (L + 1),
+                       chunks, partial_s, (const u64 *)nullptr, scr.acc);
+    hipLaunchKernelGGL(lt2_reduce_kernel, dim3(SC::N / 2 / 256, L), dim3(256), 0, s, T, L, L, L, chunks, partial_c0,
+                       (const u64 *)cbuf, cbuf);
+    return hipGetLastError();
+}
+// single mod-down of scr.acc ([2][L+1][N]) with add-in item->c_in ([2][L][N]) into item->c_out (relin-style epilogue)
+template <int LOGN>
+static hipError_t launch_lt2_moddown_t(const DevTables &T, int L, const KsItem *item, const KsScratch &scr, hipStream_t s)
+{
+    using SC = SplitCfg<LOGN>;
+    const size_t lds = SC::LDS_BYTES;
+    hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(2)), dim3(SC::T), lds, s, T, L, 2, scr);
+    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(2, L)), dim3(SC::T), lds, s, T, item, L, 1, 2,
+                       scr);
+    return hipGetLastError();
+}
+
 #define HEFX_DISPATCH_SPLIT(logn, CALL)       \
     switch (logn) {                           \
         case 11: return CALL(11);             \
@@ -605,6 +743,22 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         case 15: return CALL(15);             \
         default: return hipErrorInvalidValue; \
     }
+
+hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,
+                                const KsScratch &scr, const u64 *ct_new, u64 *partial_s, u64 *partial_c0, u64 *cbuf,
+                                hipStream_t s)
+{
+#define CALL(LN) launch_lt2_decompose_t<LN>(T, L, src_item, rot_items, nrot, scr, ct_new, partial_s, partial_c0, cbuf, s)
+    HEFX_DISPATCH_SPLIT(T.logn, CALL)
+#undef CALL
+}
+hipError_t launch_lt2_moddown(const DevTables &T, int L, const KsItem *item, const KsScratch &scr, hipStream_t s)
+{
+#define CALL(LN) launch_lt2_moddown_t<LN>(T, L, item, scr, s)
+    HEFX_DISPATCH_SPLIT(T.logn, CALL)
+#undef CALL
+}
+int lt2_chunk() { return LT2_CHUNK; }
 
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof)

@@ -252,7 +252,8 @@ class Engine:
     def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, out=None, stream=None, hoisted=False):
         """Linear_Transform_Plain in one native call (hefx_linear_transform_plain[_hoisted])"""
         out = out if out is not None else DeviceArray(self, (2, L, self.N))
-        f = capi.lib().hefx_linear_transform_plain_hoisted if hoisted else capi.lib().hefx_linear_transform_plain
+        f = {False: capi.lib().hefx_linear_transform_plain, True: capi.lib().hefx_linear_transform_plain_hoisted,
+             2: capi.lib().hefx_linear_transform_plain_hoisted2}[hoisted]
         capi.check(f(
             self._h, L, ct.ptr, len(diag_pts), capi.ptr_array([p.ptr for p in diag_pts]), len(keys),
             capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))

@@ -104,6 +104,12 @@ class OracleBackend:
             outs = [self.o.multiply_plain(r, np.ascontiguousarray(p).reshape(L, self.N)) for r, p in zip(outs, pts)]
         return outs
 
+    def lt_double_hoisted_core(self, ct_new, diags_keylevel, elts, keys):
+        L = len(self.primes) - 1
+        return self.o.lt_double_hoisted_core(self._ct(ct_new, 2, L),
+                                             [np.ascontiguousarray(p).reshape(self.k, self.N) for p in diags_keylevel],
+                                             elts, keys)
+
     def relinearize(self, L, ct3, key):
         return self.o.relinearize(self._ct(ct3, 3, L), key)
 

@@ -355,3 +355,31 @@ def test_reference_polynomial_driver_unchanged():
     act = [float(x) for x in re.findall(r"Actual : (-?[\d.]+)", r.stdout)]
     exp = [float(x) for x in re.findall(r"Expected : (-?[\d.]+)", r.stdout)]
     assert len(act) == len(exp) == 2 and np.allclose(act, exp, atol=1e-4)   # Horner and Tree, degree 3 at x = 0.5
+
+
+@pytest.mark.parametrize("N,bits_,d", [(8192, [60, 40, 40, 60], 12), (4096, [50, 30, 30, 50], 21), (16384, [60, 40, 40, 40, 40, 60], 9)])
+def test_double_hoisted_linear_transform_bit_exact_against_its_oracle(N, bits_, d):
+    """hefx_linear_transform_plain_hoisted2: shared decomposition AND one mod-down for the whole transform (key-level
+    diagonals).  Not the bits of the rotation-by-rotation sum; bit-exact against the oracle's statement of this
+    algorithm (orc_lt_double_hoisted_core), same decrypted values to CKKS precision.  d > 8 spans several chunks."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    rng = np.random.default_rng(d)
+    M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
+    steps = [-d] + list(range(1, d))
+
+    def run(e):
+        scale = 2.0 ** 30
+        ctx = e["ctx"]
+        dk = [e["encoder"].encode(x, scale, parms_id=ctx.k) for x in alg.get_all_diagonals(M)]
+        dd = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+        ct = e["enc"].encrypt(e["encoder"].encode(v, scale))
+        return (alg.linear_transform_plain(e["ev"], ct, dk, e["gk"], hoisted=2),
+                alg.linear_transform_plain(e["ev"], ct, dd, e["gk"]))
+
+    r = both(N, bits_, run, galois_steps=steps)
+    (eg, (hg, cg)), (eo, (ho, co)) = r["gpu"], r["oracle"]
+    assert (bits(eg, hg) == bits(eo, ho)).all()
+    assert (bits(eg, cg) == bits(eo, co)).all()
+    assert (bits(eg, hg) != bits(eg, cg)).any()
+    assert np.allclose(decode(eg, hg, d), M @ v, atol=1e-2)
+    assert np.abs(decode(eg, hg, d) - decode(eg, cg, d)).max() < 1e-2  # 30-bit primes at scale 2^30: noise ~1e-3

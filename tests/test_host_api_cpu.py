@@ -210,3 +210,24 @@ def test_hoisted_rotation_is_a_valid_key_switch_but_not_seals_bits(env):
     assert np.abs(dec(e, a, d).real - M @ w).max() < 1e-2 and np.abs(dec(e, h, d).real - M @ w).max() < 1e-2
     with pytest.raises(ValueError, match="direct Galois key"):
         alg.linear_transform_plain(ev, cw, diags, e["gk"], hoisted=True)
+
+
+def test_double_hoisted_linear_transform_decrypts_to_the_matrix_product(env):
+    """second fast mode on the oracle twin: key-level diagonals, one mod-down for the whole transform"""
+    e = env
+    ctx, ev, kg = e["ctx"], e["ev"], e["kg"]
+    d = 6
+    gk = kg.galois_keys([-d] + list(range(1, d)))
+    rng = np.random.default_rng(2)
+    M, w = rng.standard_normal((d, d)), rng.standard_normal(d)
+    scale = 2.0 ** 30
+    diags_key = [e["encoder"].encode(x, scale, parms_id=ctx.k) for x in alg.get_all_diagonals(M)]
+    diags = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+    cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+    h2 = alg.linear_transform_plain(ev, cw, diags_key, gk, hoisted=2)
+    ref = alg.linear_transform_plain(ev, cw, diags, gk)
+    assert h2.parms_id() == ref.parms_id() and h2.scale == ref.scale
+    assert np.abs(dec(e, h2, d).real - M @ w).max() < 1e-2
+    assert np.abs(dec(e, h2, d).real - dec(e, ref, d).real).max() < 1e-3
+    with pytest.raises(ValueError, match="key-level"):
+        alg.linear_transform_plain(ev, cw, diags, gk, hoisted=2)
