@@ -103,9 +103,26 @@ inline bool is_prime(std::uint64_t n)
     if (rc == HEFX_ERR_TRANSPARENT) throw std::logic_error(msg);
     throw std::runtime_error("hefx: " + msg);
 }
+// SEAL_SHIM_SYNC=1: wait for the device after every engine call, so that a caller's own wall-clock timers (the
+// reference brackets its calls with chrono) measure completed work, as they would with SEAL's synchronous CPU code.
+// Default off: calls return as soon as their launches are queued.
+inline hefx_context *&sync_target()
+{
+    static thread_local hefx_context *ctx = nullptr;
+    return ctx;
+}
+inline bool sync_mode()
+{
+    static const bool on = [] {
+        const char *s = std::getenv("SEAL_SHIM_SYNC");
+        return s && *s && *s != '0';
+    }();
+    return on;
+}
 inline void check(int rc)
 {
     if (rc != HEFX_OK) raise(rc);
+    if (sync_mode() && sync_target()) (void)hefx_stream_sync(sync_target(), nullptr);
 }
 
 // One engine context per distinct (N, primes); created on first use and kept for the life of the process, so the
@@ -150,6 +167,7 @@ struct Engine {
     hefx_context *live()  // the context, with everything recorded so far submitted
     {
         if (!pend_ks.empty()) flush();
+        sync_target() = ctx_raw;
         return ctx_raw;
     }
     BufPtr defer_rotation(const BufPtr &src, std::uint32_t elt, const BufPtr &key, int L, std::size_t words,

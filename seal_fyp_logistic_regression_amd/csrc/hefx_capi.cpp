@@ -332,6 +332,13 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         delete c;
         return hipfail(e, "context table upload");
     }
+    // load every code object now (first-launch cost), not inside the caller's first timed operation
+    if (warm_kernels(nullptr) != hipSuccess || warm_keyswitch(nullptr) != hipSuccess || warm_encode(nullptr) != hipSuccess ||
+        warm_sample(nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+        (void)hipFree(c->d_tables);
+        delete c;
+        return fail(HEFX_ERR_HIP, "kernel code objects failed to load");
+    }
     unsigned char *base = static_cast<unsigned char *>(c->d_tables);
     c->T.tw = reinterpret_cast<const ulonglong2 *>(base);
     c->T.itw = reinterpret_cast<const ulonglong2 *>(base + tw_bytes);

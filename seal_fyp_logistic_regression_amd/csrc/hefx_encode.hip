@@ -351,4 +351,13 @@ hipError_t launch_encode(const DevTables &T, const EncodeTables &E, const double
     return hipGetLastError();
 }
 
+// HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
+// that once, up front, instead of the first encode / rotation / encryption of a program.
+__global__ void warm_encode_kernel() {}
+hipError_t warm_encode(hipStream_t s)
+{
+    hipLaunchKernelGGL(warm_encode_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace hefx

@@ -126,6 +126,10 @@ hipError_t launch_keygen_combine(const DevTables &T, const u64 *sk, const u64 *n
                                  u64 *out, hipStream_t s);
 hipError_t launch_galois_permute(const DevTables &T, const uint32_t *perm, const u64 *in, int rows, u64 *out,
                                  hipStream_t s);
+hipError_t warm_kernels(hipStream_t s);
+hipError_t warm_keyswitch(hipStream_t s);
+hipError_t warm_encode(hipStream_t s);
+hipError_t warm_sample(hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
                           hipStream_t s);
 

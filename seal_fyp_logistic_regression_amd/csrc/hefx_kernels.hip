@@ -269,4 +269,13 @@ hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b
 }
 
 
+// HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
+// that once, up front, instead of the first encode / rotation / encryption of a program.
+__global__ void warm_kernels_kernel() {}
+hipError_t warm_kernels(hipStream_t s)
+{
+    hipLaunchKernelGGL(warm_kernels_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace hefx

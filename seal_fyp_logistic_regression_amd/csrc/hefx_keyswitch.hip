@@ -912,4 +912,13 @@ hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, 
     return hipGetLastError();
 }
 
+// HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
+// that once, up front, instead of the first encode / rotation / encryption of a program.
+__global__ void warm_keyswitch_kernel() {}
+hipError_t warm_keyswitch(hipStream_t s)
+{
+    hipLaunchKernelGGL(warm_keyswitch_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace hefx

@@ -248,4 +248,13 @@ hipError_t launch_decrypt(const DevTables &T, int L, int size, const u64 *ct, co
     return hipGetLastError();
 }
 
+// HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
+// that once, up front, instead of the first encode / rotation / encryption of a program.
+__global__ void warm_sample_kernel() {}
+hipError_t warm_sample(hipStream_t s)
+{
+    hipLaunchKernelGGL(warm_sample_kernel, dim3(1), dim3(64), 0, s);
+    return hipGetLastError();
+}
+
 }  // namespace hefx
