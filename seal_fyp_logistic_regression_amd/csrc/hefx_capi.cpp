@@ -130,6 +130,13 @@ struct hefx_context {
     EncodeTables E{};
     double *d_vals = nullptr;
     size_t vals_cap = 0;
+    // pinned staging ring for small encodes (one vector): the caller's array is copied here and the call returns
+    // without waiting for the H2D copy
+    static constexpr int STAGE_SLOTS = 8;
+    double *h_stage = nullptr;
+    hipEvent_t stage_ev[STAGE_SLOTS] = {};
+    bool stage_busy[STAGE_SLOTS] = {};
+    unsigned stage_next = 0;
     NoiseTable noise{};  // inverse-CDF thresholds of the clipped normal (sigma 3.2, bound 19.2, truncated)
     // linear-transform workspace (rotated copies and products of one hefx_linear_transform_plain call)
     u64 *lt_ws = nullptr;
@@ -377,6 +384,9 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_enc_tables) (void)hipFree(c->d_enc_tables);
     if (c->d_vals) (void)hipFree(c->d_vals);
+    if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (auto &ev : c->stage_ev)
+        if (ev) (void)hipEventDestroy(ev);
     if (c->lt_ws) (void)hipFree(c->lt_ws);
     delete c;
 }
@@ -948,9 +958,26 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
         c->vals_cap = need;
     }
     hipStream_t s = (hipStream_t)stream;
-    HIPCHK(hipMemcpyAsync(c->d_vals, h_re, nv * sizeof(double), hipMemcpyHostToDevice, s));
-    if (h_im) HIPCHK(hipMemcpyAsync(c->d_vals + nv, h_im, nv * sizeof(double), hipMemcpyHostToDevice, s));
-    HIPCHK(hipStreamSynchronize(s));  // the host arrays may be transient
+    const size_t slot_doubles = c->n;  // one vector of N/2 complex values
+    if (need <= slot_doubles) {  // small: through the pinned ring, no wait for the copy
+        if (!c->h_stage) {
+            HIPCHK(hipHostMalloc((void **)&c->h_stage, sizeof(double) * slot_doubles * hefx_context::STAGE_SLOTS,
+                                 hipHostMallocDefault));
+            for (auto &ev : c->stage_ev) HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        }
+        const unsigned slot = c->stage_next++ % hefx_context::STAGE_SLOTS;
+        if (c->stage_busy[slot]) HIPCHK(hipEventSynchronize(c->stage_ev[slot]));
+        double *h = c->h_stage + (size_t)slot * slot_doubles;
+        memcpy(h, h_re, nv * sizeof(double));
+        if (h_im) memcpy(h + nv, h_im, nv * sizeof(double));
+        HIPCHK(hipMemcpyAsync(c->d_vals, h, need * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(c->stage_ev[slot], s));
+        c->stage_busy[slot] = true;
+    } else {
+        HIPCHK(hipMemcpyAsync(c->d_vals, h_re, nv * sizeof(double), hipMemcpyHostToDevice, s));
+        if (h_im) HIPCHK(hipMemcpyAsync(c->d_vals + nv, h_im, nv * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));  // the host arrays may be transient
+    }
     if (c->logn == 15) {  // the N = 32768 transform is out of place: coefficients into scratch, NTT into d_out
         const size_t words = (size_t)count * L * c->n;
         if (int rc = ensure_scratch(c, words)) return rc;
