@@ -73,3 +73,17 @@ def test_product_never_imports_oracle():
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
                 assert "ckks_oracle" not in text, f
+
+
+def test_header_is_plain_c():
+    """include/hefx.h is the C-ABI: it must compile as C99 on its own (no C++-isms, no HIP or torch types)."""
+    import subprocess
+    import tempfile
+    src = '#include "hefx.h"\nint main(void) { return hefx_device_count() < 0; }\n'
+    with tempfile.NamedTemporaryFile("w", suffix=".c", delete=False) as f:
+        f.write(src)
+        path = f.name
+    r = subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-fsyntax-only", "-I",
+                        os.path.join(ROOT, "include"), path], capture_output=True, text=True)
+    os.unlink(path)
+    assert r.returncode == 0, r.stderr
