@@ -713,7 +713,8 @@ public:
     const SecretKey &secret_key() const { return sk_; }
     PublicKey public_key()
     {
-        PublicKey pk;
+        if (pk_.buf) return pk_;  // generated once, like SEAL's KeyGenerator
+        PublicKey &pk = pk_;
         auto z = encrypt_zero(1, ctx_->k());
         const std::size_t w = (std::size_t)ctx_->k() * ctx_->n();
         std::vector<std::uint64_t> h(2 * w);
@@ -806,6 +807,7 @@ private:
 
     std::shared_ptr<SEALContext> ctx_;
     SecretKey sk_;
+    PublicKey pk_;
     shim::SamplerState rnd_;
 };
 

@@ -71,3 +71,70 @@ def linear_transform_plain_sharded(ev: Evaluator, ct: Ciphertext, U_diagonals: S
         z = ev.multiply_plain(ct_new, U_diagonals[0])
         partial = ev.sub(z, z)
     return allreduce_ciphertext(ev, partial, group)
+
+
+def _zero_like(ev: Evaluator, ct: Ciphertext) -> Ciphertext:
+    """the zero ciphertext at ct's size / level / scale (a rank's contribution when it owns no unit)"""
+    return ev.sub(ct, ct)
+
+
+def cc_matrix_multiplication_sharded(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int,
+                                     U_sigma: Sequence[Plaintext], U_tau: Sequence[Plaintext],
+                                     V_diagonals: Sequence[Sequence[Plaintext]],
+                                     W_diagonals: Sequence[Sequence[Plaintext]], gal_keys: KSwitchKeys,
+                                     group=None) -> Ciphertext:
+    """CC_Matrix_Multiplication (/root/reference/matrix_multiplication.cpp:11-132) with Step 2 sharded:
+    the two n^2-diagonal transforms of Step 1 are diagonal-sharded (one all-reduce each), the 2(n-1) transforms of
+    Step 2 and the products A_k (.) B_k are split by k, and the size-3 partial sums meet in one all-reduce.  Modular
+    addition is associative and commutative, so the bits equal the serial order of :123-129."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ctA0 = linear_transform_plain_sharded(ev, ctA, U_sigma, gal_keys, group)      # :22
+    ctB0 = linear_transform_plain_sharded(ev, ctB, U_tau, gal_keys, group)        # :25
+    mine = list(shard(dimension - 1, rank, world))
+    ctAk = [alg.linear_transform_plain(ev, ctA0, V_diagonals[k], gal_keys) for k in mine]   # :42
+    ctBk = [alg.linear_transform_plain(ev, ctB0, W_diagonals[k], gal_keys) for k in mine]   # :43
+    for c in ctAk + ctBk:
+        ev.rescale_to_next_inplace(c)                                              # :69-73
+    ctAB = ev.multiply(ctA0, ctB0)                                                 # :104
+    ev.mod_switch_to_next_inplace(ctAB)                                            # :112
+    for c in ctAk + ctBk:
+        c.scale = 2.0 ** int(np.log2(c.scale))                                     # :117-121
+    partial = ctAB if rank == 0 else _zero_like(ev, ctAB)                          # A_0 (.) B_0 is counted once
+    for a, b in zip(ctAk, ctBk):
+        ev.add_inplace(partial, ev.multiply(a, b))                                 # :123-129
+    return allreduce_ciphertext(ev, partial, group)
+
+
+def predict_cipher_weights_sharded(ev: Evaluator, encoder, encryptor, features: Sequence[Ciphertext],
+                                   weights: Ciphertext, num_weights: int, scale: float, gal_keys: KSwitchKeys,
+                                   relin_keys: KSwitchKeys, degree: int = 3, group=None) -> Ciphertext:
+    """predict_cipher_weights (/root/reference/logistic_regression_ckks.cpp:208-266) with the observation rows split
+    over the ranks: every rank computes and masks the dot products of its rows; the masked partial sums
+    meet in one all-reduce; the sigmoid polynomial runs replicated."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    num_rows = len(features)
+    mine = list(shard(num_rows, rank, world))
+    results = alg.cipher_dot_product_many(ev, [features[i] for i in mine], [weights] * len(mine), num_weights,
+                                          relin_keys, gal_keys)                     # :220
+    for r, i in zip(results, mine):
+        mask = np.zeros(num_rows)
+        mask[i] = 1
+        mask_pt = encoder.encode(mask, scale)                                       # :222-225
+        ev.mod_switch_to_next_inplace(mask_pt)                                      # :227
+        ev.multiply_plain_inplace(r, mask_pt)                                       # :229
+    if results:
+        partial = ev.add_many(results)                                              # :233 (this rank's share)
+    else:  # more ranks than rows: the zero ciphertext at the level / scale a masked dot product has
+        one = alg.cipher_dot_product_many(ev, features[:1], [weights], num_weights, relin_keys, gal_keys)[0]
+        mask_pt = encoder.encode(np.ones(1), scale)
+        ev.mod_switch_to_next_inplace(mask_pt)
+        ev.multiply_plain_inplace(one, mask_pt)
+        partial = _zero_like(ev, one)
+    lin = allreduce_ciphertext(ev, partial, group)
+    ev.relinearize_inplace(lin, relin_keys)                                         # :237 (no-op)
+    ev.rescale_to_next_inplace(lin)                                                 # :239
+    lin.scale = 2.0 ** int(np.log2(lin.scale))                                      # :242
+    coeffs = alg.SIGMOID_COEFFS[degree]                                             # :245-262
+    return alg.horner_cipher(ev, encoder, encryptor, lin, len(coeffs) - 1, coeffs, scale, relin_keys)   # :264

@@ -389,8 +389,11 @@ class KeyGenerator:
                 be.to_host(a).reshape(npoly, rows, self.ctx.N))
 
     def public_key(self):
-        c0, c1 = self._encrypt_zero(1, self.ctx.k, self._next_stream())
-        return np.stack([c0[0], c1[0]])  # [2][k][N]
+        # generated once, like SEAL's KeyGenerator (public_key() returns the same key on every call)
+        if getattr(self, "_pk", None) is None:
+            c0, c1 = self._encrypt_zero(1, self.ctx.k, self._next_stream())
+            self._pk = np.stack([c0[0], c1[0]])  # [2][k][N]
+        return self._pk
 
     def _kswitch_key(self, new_sk_host, new_sk_dev=None):
         """key-switching key for new_sk under sk.  On the HIP engine: one call (hefx_keygen_kswitch -- sampling, NTT and

@@ -67,3 +67,81 @@ def test_shard_partition():
             parts = [list(shard(n, r, w)) for r in range(w)]
             assert sum(parts, []) == list(range(n))
             assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _worker_matmul_lr(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import seal_fyp_logistic_regression_amd.seal as S
+        from seal_fyp_logistic_regression_amd import algorithms as alg
+        from seal_fyp_logistic_regression_amd import parallel as par
+        from tests.test_host_api_cpu import make
+        # ---- matrix product n = 3 (Step 2 sharded by k)
+        n = 3
+        e = make(2048, [60, 40, 40, 40, 40, 60], seed=6)  # config 3's chain: the product ends at scale 2^160
+        A = np.arange(1, n * n + 1, dtype=float).reshape(n, n) / 4
+        d = n * n
+        Us, Ut = np.zeros((d, d)), np.zeros((d, d))
+        for i in range(n):
+            for j in range(n):
+                Us[n * i + j, n * i + (i + j) % n] = 1
+                Ut[n * i + j, n * ((i + j) % n) + j] = 1
+        V, W = [], []
+        for k in range(1, n):
+            Vk, Wk = np.zeros((d, d)), np.zeros((d, d))
+            for i in range(n):
+                for j in range(n):
+                    Vk[n * i + j, n * i + (j + k) % n] = 1
+                    Wk[n * i + j, n * ((i + k) % n) + j] = 1
+            V.append(Vk)
+            W.append(Wk)
+        scale = 2.0 ** 40
+        enc = lambda U: [e["encoder"].encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)]
+        ctA = S.Encryptor(e["ctx"], e["kg"].public_key(), seed=7).encrypt(e["encoder"].encode(A.reshape(-1), scale))
+        args = (ctA, ctA, n, enc(Us), enc(Ut), [enc(v) for v in V], [enc(w) for w in W], e["gk"])
+        serial = alg.cc_matrix_multiplication(e["ev"], *args)
+        sharded = par.cc_matrix_multiplication_sharded(e["ev"], *args)
+        mm_same = bool((np.asarray(serial.data) == np.asarray(sharded.data)).all()) and sharded.size() == 3
+        got = e["encoder"].decode(e["dec"].decrypt(sharded))[:d].real.reshape(n, n)
+        mm_val = bool(np.allclose(got, A @ A, atol=5e-2))
+        # ---- LR predict, rows sharded; same Encryptor state on both paths
+        e = make(2048, [60, 40, 40, 40, 40, 40, 40, 40, 60], seed=4)
+        scale = 2.0 ** 40
+        X = np.array([[0.5, -1.0, 0.2, 0.1], [1.5, 0.25, -0.3, 0.4], [-0.75, 0.5, 0.6, -0.2]])
+        w = np.array([0.3, -0.6, 0.5, 0.25])
+        feats = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in X]
+        cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+        enc_a = S.Encryptor(e["ctx"], e["kg"].public_key(), seed=9)
+        enc_b = S.Encryptor(e["ctx"], e["kg"].public_key(), seed=9)
+        p_serial = alg.predict_cipher_weights(e["ev"], e["encoder"], enc_a, feats, cw, 4, scale, e["gk"], e["rk"])
+        p_shard = par.predict_cipher_weights_sharded(e["ev"], e["encoder"], enc_b, feats, cw, 4, scale, e["gk"], e["rk"])
+        lr_same = bool((np.asarray(p_serial.data) == np.asarray(p_shard.data)).all())
+        q.put((rank, mm_same, mm_val, lr_same))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_matrix_product_and_lr_predict_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_matmul_lr, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = []
+    for _ in procs:
+        try:
+            out.append(q.get(timeout=240))
+        except Exception:
+            break
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
+    for rank, mm_same, mm_val, lr_same in sorted(out):
+        assert mm_same, f"rank {rank}: sharded matrix product differs from the serial one"
+        assert mm_val
+        assert lr_same, f"rank {rank}: row-sharded LR predict differs from the serial one"
