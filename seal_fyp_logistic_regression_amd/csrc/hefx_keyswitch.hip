@@ -142,7 +142,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
-                                                                             int item0, KsScratch S)
+                                                                             int item0, int stream_x, KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -169,8 +169,15 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
     };
     split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
+    // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
+    // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
+    if (stream_x) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], xd + C::idx_out(t, r));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -189,6 +196,7 @@ struct MacAcc {
         mac128(a1xl, a1xh, x.x, k1.x);
         mac128(a1yl, a1yh, x.y, k1.y);
     }
+    template <bool STREAM = false>
     __device__ __forceinline__ void store(u64 *acc0, u64 *acc1, size_t w, const ModConst &mc) const
     {
         ulonglong2 r0, r1;
@@ -196,13 +204,20 @@ struct MacAcc {
         r0.y = barrett128(a0yl, a0yh, mc);
         r1.x = barrett128(a1xl, a1xh, mc);
         r1.y = barrett128(a1yl, a1yh, mc);
-        reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
-        reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
+        if (STREAM) {
+            __builtin_nontemporal_store(r0.x, acc0 + 2 * w);
+            __builtin_nontemporal_store(r0.y, acc0 + 2 * w + 1);
+            __builtin_nontemporal_store(r1.x, acc1 + 2 * w);
+            __builtin_nontemporal_store(r1.y, acc1 + 2 * w + 1);
+        } else {
+            reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
+            reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
+        }
     }
 };
 
 // NI consecutive items (bl .. bl+NI-1) that share `key`
-template <int NI, class XR, class AR>
+template <int NI, bool STREAM, class XR, class AR>
 __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, int L, int m, size_t n, size_t w, int bl,
                                           const ModConst &mc, const XR &xrow, const AR &accrow)
 {
@@ -211,16 +226,25 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
         const u64 *kbase = key + ((size_t)i * 2 * T.k + m) * n;
         ulonglong2 x[NI];
 #pragma unroll
-        for (int e = 0; e < NI; ++e) x[e] = xrow(bl + e, i)[w];
+        for (int e = 0; e < NI; ++e) {
+            const ulonglong2 *xp = xrow(bl + e, i) + w;
+            if (STREAM) {  // read exactly once
+                x[e].x = __builtin_nontemporal_load(&xp->x);
+                x[e].y = __builtin_nontemporal_load(&xp->y);
+            } else {
+                x[e] = *xp;
+            }
+        }
         const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
         const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
 #pragma unroll
         for (int e = 0; e < NI; ++e) A[e].mac(x[e], k0, k1);
     }
 #pragma unroll
-    for (int e = 0; e < NI; ++e) A[e].store(accrow(bl + e, 0), accrow(bl + e, 1), w, mc);
+    for (int e = 0; e < NI; ++e) A[e].template store<STREAM>(accrow(bl + e, 0), accrow(bl + e, 1), w, mc);
 }
 
+template <bool STREAM>
 __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int item0,
                                                      int count, KsScratch S)
 {
@@ -238,10 +262,10 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
     const u64 *k0 = items[item0 + bl0].key;
     const u64 *k1 = bl0 + 1 < count ? items[item0 + bl0 + 1].key : nullptr;
     if (k1 == k0) {
-        mac_items<2>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
+        mac_items<2, STREAM>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
     } else {
-        mac_items<1>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
-        if (k1) mac_items<1>(T, k1, L, m, n, w, bl0 + 1, mc, xrow, accrow);
+        mac_items<1, STREAM>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
+        if (k1) mac_items<1, STREAM>(T, k1, L, m, n, w, bl0 + 1, mc, xrow, accrow);
     }
 }
 
@@ -623,7 +647,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(1);
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
         mark(2);
-        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, scr);
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, 0, scr);
         mark(3);
         hipLaunchKernelGGL(ks_mac_hoisted_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
         mark(4);
@@ -656,11 +680,18 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     for (int item0 = 0; item0 < n; item0 += sub) {
         const int m = n - item0 < sub ? n - item0 : sub;
         mark(2);
+        // x of this (sub-)chunk against the 256 MB Infinity Cache: beyond it, stream x (HEFX_STREAM_X=0/1 overrides)
+        static const int force = getenv("HEFX_STREAM_X") ? atoi(getenv("HEFX_STREAM_X")) : -1;
+        const int stream_x = force >= 0 ? force : ((size_t)m * L * (L + 1) * SC::N * 8 > ((size_t)256 << 20) ? 1 : 0);
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds, s, T, L, m * L,
-                           item0, scr);
+                           item0, stream_x, scr);
         mark(3);
-        hipLaunchKernelGGL(ks_mac_kernel, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch, L, item0,
-                           m, scr);
+        if (stream_x)
+            hipLaunchKernelGGL(ks_mac_kernel<true>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
+                               L, item0, m, scr);
+        else
+            hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
+                               L, item0, m, scr);
     }
     mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
@@ -710,7 +741,7 @@ static hipError_t launch_lt2_decompose_t(const DevTables &T, int L, const KsItem
     const int chunks = (nrot + LT2_CHUNK - 1) / LT2_CHUNK;
     hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, src_item, L, 0, 0, 1, scr);
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
-    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, scr);
+    hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, 0, scr);
     hipLaunchKernelGGL(lt2_mac_kernel, dim3(SC::N / 2 / 256, L + 1, chunks), dim3(256), 0, s, T, rot_items, L, nrot, scr,
                        partial_s);
     hipLaunchKernelGGL(lt2_c0_kernel, dim3(SC::N / 2 / 256, L, chunks), dim3(256), 0, s, T, rot_items, L, nrot, ct_new,
