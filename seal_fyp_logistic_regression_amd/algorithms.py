@@ -374,10 +374,11 @@ def predict_cipher_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, featu
     """predict_cipher_weights, /root/reference/logistic_regression_ckks.cpp:208-266."""
     num_rows = len(features)
     results = cipher_dot_product_many(ev, features, [weights] * num_rows, num_weights, relin_keys, gal_keys)  # :220
+    # the reference encodes one one-hot mask per row inside the loop (:222-225, 2000 CPU FFTs per iteration); here all
+    # masks go through one batched encode (one GPU launch on the HIP engine) -- same plaintexts, same order of use
+    masks = encoder.encode_many(list(np.eye(num_rows)), scale)
     for i in range(num_rows):
-        mask = np.zeros(num_rows)
-        mask[i] = 1
-        mask_pt = encoder.encode(mask, scale)                                                              # :222-225
+        mask_pt = masks[i]
         ev.mod_switch_to_next_inplace(mask_pt)                                                             # :227
         ev.multiply_plain_inplace(results[i], mask_pt)                                                     # :229
     lin = ev.add_many(results)                                                                             # :233
@@ -405,10 +406,9 @@ def update_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, features: Seq
     for f in fT:
         ev.mod_switch_to_inplace(f, pred_labels.parms_id())                                                # :298
     grads = cipher_dot_product_many(ev, fT, [pred_labels] * num_weights, num_obs, relin_keys, gal_keys)    # :299
+    masks = encoder.encode_many(list(np.eye(num_weights)), scale)                                          # :302-305, batched
     for i in range(num_weights):
-        mask = np.zeros(num_weights)
-        mask[i] = 1
-        mask_pt = encoder.encode(mask, scale)                                                              # :302-305
+        mask_pt = masks[i]
         ev.mod_switch_to_inplace(mask_pt, grads[i].parms_id())                                             # :308
         ev.multiply_plain_inplace(grads[i], mask_pt)                                                       # :310
     gradient = ev.add_many(grads)                                                                          # :316
