@@ -153,6 +153,55 @@ int main()
               "hefx_linear_transform_plain: missing keys throw");
     }
 
+    // extensions: product sum (Linear_Transform_CipherMatrix_PlainVector in one pass) and the baby-step / giant-step
+    // form of Linear_Transform_Plain
+    {
+        const int d = 13, n1 = 4, n2 = 4;
+        vector<vector<double>> M(d, vector<double>(d));
+        vector<double> v(d), want(d, 0.0);
+        for (int i = 0; i < d; i++) {
+            v[i] = 0.1 * (i + 1);
+            for (int j = 0; j < d; j++) M[i][j] = 0.01 * ((7 * i + 3 * j) % 11) - 0.05;
+        }
+        for (int i = 0; i < d; i++)
+            for (int j = 0; j < d; j++) want[i] += M[i][j] * v[j];
+        vector<Plaintext> plain(d), shifted(d);
+        for (int l = 0; l < d; l++) {
+            vector<double> dv(d), sv((l / n1) * n1 + d, 0.0);
+            for (int i = 0; i < d; i++) dv[i] = sv[(l / n1) * n1 + i] = M[i][(i + l) % d];
+            encoder.encode(dv, scale, plain[l]);
+            encoder.encode(sv, scale, shifted[l]);
+        }
+        vector<int> steps{-d};
+        for (int i = 1; i < n1; i++) steps.push_back(i);
+        for (int j = 1; j < n2; j++) steps.push_back(j * n1);
+        GaloisKeys gb = keygen.galois_keys(steps);
+        Plaintext pv;
+        encoder.encode(v, scale, pv);
+        Ciphertext cv, res;
+        encryptor.encrypt(pv, cv);
+        for (int hoisted = 0; hoisted < 2; hoisted++) {
+            evaluator.hefx_linear_transform_plain_bsgs(cv, shifted, gb, n1, res, hoisted != 0);
+            auto r = dec(res);
+            double err = 0;
+            for (int i = 0; i < d; i++) err = max(err, fabs(r[i] - want[i]));
+            CHECK(err < 1e-4 && res.scale() == scale * scale, "hefx_linear_transform_plain_bsgs decrypts to M.v");
+        }
+        CHECK(throws_invalid([&] { Ciphertext t; evaluator.hefx_linear_transform_plain_bsgs(cv, shifted, gk, n1, t); },
+                             "direct Galois key"),
+              "hefx_linear_transform_plain_bsgs: power-of-two keys alone are refused");
+        // product sum against the op-by-op body of helper.h:265-278
+        vector<Ciphertext> cts(5);
+        for (int i = 0; i < 5; i++) evaluator.rotate_vector(cv, i == 0 ? 0 : 1 << (i - 1), gk, cts[i]);
+        vector<Ciphertext> prods(5);
+        for (int i = 0; i < 5; i++) evaluator.multiply_plain(cts[i], plain[i], prods[i]);
+        Ciphertext ref, fast;
+        evaluator.add_many(prods, ref);
+        evaluator.hefx_multiply_plain_sum(cts, plain, fast);
+        CHECK(fast.scale() == ref.scale() && shim::download(fast.buf) == shim::download(ref.buf),
+              "hefx_multiply_plain_sum == add_many(multiply_plain), bit for bit");
+    }
+
     // deferred rotations (shim::Engine::defer_*): every usage pattern must give the bits of immediate execution
     {
         auto run = [&](bool lazy) {

@@ -97,6 +97,15 @@ int hefx_add_many(hefx_context *ctx, int L, int size, int n, const uint64_t *con
 int hefx_multiply_plain(hefx_context *ctx, int L, int size, int count, const uint64_t *d_ct,
                         const uint64_t *d_pt, uint64_t *d_out, void *stream);
 int hefx_check_transparent(hefx_context *ctx, void *stream);
+/* Linear_Transform_CipherMatrix_PlainVector (helper.h:265-278: add_many of multiply_plain results, :271,:275) and the
+ * inner sums of a baby-step/giant-step transform, in one pass: for g in [0, ceil(n/group)):
+ *   d_outs[g] = sum_{i in [g*group, min(n,(g+1)*group))} d_cts[i] (.) d_pts[i]   (mod q_j per row)
+ * d_cts[i]: [size][L][N], d_pts[i]: [L][N], d_outs[g]: [size][L][N], none of a group's inputs aliasing its output.
+ * The canonical residues of the sums, i.e. the bits of n multiply_plain calls followed by add_many.  The pointer
+ * arrays are host arrays of device pointers.  Transparency is the caller's check (the plaintexts' zero flags). */
+int hefx_multiply_plain_sum(hefx_context *ctx, int L, int size, int n, int group, const uint64_t *const *d_cts,
+                            const uint64_t *const *d_pts, uint64_t *const *d_outs, void *stream);
+
 /* size 2 x size 2 -> size 3 */
 int hefx_multiply(hefx_context *ctx, int L, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out3,
                   void *stream);
@@ -175,6 +184,17 @@ int hefx_linear_transform_plain_hoisted2(hefx_context *ctx, int L, const uint64_
                                          const uint64_t *const *d_diag_pts_keylevel, int nkeys,
                                          const uint32_t *key_elts, const uint64_t *const *d_keys, uint64_t *d_out,
                                          void *stream);
+
+/* Baby-step / giant-step form of Linear_Transform_Plain (helper.h:237-262).  With n2 = ceil(d/n1)
+ * and l = j*n1 + i:  sum_l diag_l (.) rot_l(ct_new) = sum_j rot_(j*n1)( sum_i diag'_l (.) rot_i(ct_new) ), where
+ * d_shifted_diag_pts[l] encodes diag_l shifted RIGHT by j*n1 slots (done in the clear before encoding).  Needs direct
+ * Galois keys for the steps 1..n1-1 and n1, 2*n1, .., (n2-1)*n1 (n1+n2-2 key switches instead of d-1); rotate(-d) may
+ * use a NAF chain.  d + n1*n2 <= N/2.  hoisted_baby != 0 shares the digit decomposition of ct_new over the baby
+ * rotations (hefx_rotate_hoisted_batch's algorithm).  A different operation sequence than the reference's loop: the
+ * same plaintext result with different noise bits; the checker is the same composition over the oracle. */
+int hefx_linear_transform_plain_bsgs(hefx_context *ctx, int L, const uint64_t *d_ct, int d, int n1,
+                                     const uint64_t *const *d_shifted_diag_pts, int nkeys, const uint32_t *key_elts,
+                                     const uint64_t *const *d_keys, int hoisted_baby, uint64_t *d_out, void *stream);
 
 /* ---- CKKSEncoder::encode(vector<double>, scale, plain) on the GPU (call sites
  *      matrix_mult_benchmark.cpp:291-323, logistic_regression_ckks.cpp:222-225,302-305, helper.h:333-343):

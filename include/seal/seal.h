@@ -1387,6 +1387,71 @@ public:
         dest.set(out, 2, ct.rows, ct.parms_id(), ns);
     }
 
+    // ---- EXTENSION: add_many(multiply_plain(cts[i], pts[i])) in one pass over the operands
+    // (hefx_multiply_plain_sum) -- the body of Linear_Transform_CipherMatrix_PlainVector (helper.h:265-278) with the
+    // checks, exceptions and result bits of its op-by-op form.
+    void hefx_multiply_plain_sum(const std::vector<Ciphertext> &cts, const std::vector<Plaintext> &pts,
+                                 Ciphertext &dest) const
+    {
+        if (cts.empty() || cts.size() > pts.size()) throw std::invalid_argument("encrypteds cannot be empty");
+        const Ciphertext &c0 = cts[0];
+        double ns = 0;
+        std::vector<const std::uint64_t *> cp, pp;
+        for (std::size_t i = 0; i < cts.size(); ++i) {
+            check_ct(cts[i]);
+            if (cts[i].parms_id() != c0.parms_id() || cts[i].size() != c0.size())
+                throw std::invalid_argument("encrypteds parameter mismatch");
+            check_pt(cts[i], pts[i]);
+            const double s = cts[i].scale() * pts[i].scale();
+            check_scale(s, c0.parms_id());
+            if (i && !close(ns, s)) throw std::invalid_argument("scale mismatch");
+            if (!i) ns = s;
+            if (pts[i].is_zero()) throw std::logic_error("result ciphertext is transparent");
+            cp.push_back(cts[i].buf->p);
+            pp.push_back(pts[i].buf->p);
+        }
+        auto out = shim::new_buf(eng(), words(c0.size(), c0.rows));
+        std::uint64_t *op = out->p;
+        shim::check(::hefx_multiply_plain_sum(eng()->live(), c0.rows, (int)c0.size(), (int)cp.size(), (int)cp.size(),
+                                              cp.data(), pp.data(), &op, nullptr));
+        dest.set(out, c0.size(), c0.rows, c0.parms_id(), ns);
+    }
+
+    // ---- EXTENSION: Linear_Transform_Plain in baby-step / giant-step form (hefx_linear_transform_plain_bsgs):
+    // `shifted_diags[l]` encodes diagonal l shifted right by (l / n1) * n1 slots; gk holds direct keys for -d (or its
+    // NAF terms), 1..n1-1 and n1, 2*n1, ...  n1 + ceil(d/n1) - 2 key switches instead of d - 1; a fast mode like the
+    // hoisted ones: the plaintext result of helper.h:237-262, not its noise bits.
+    void hefx_linear_transform_plain_bsgs(const Ciphertext &ct, const std::vector<Plaintext> &shifted_diags,
+                                          const GaloisKeys &gk, int n1, Ciphertext &dest, bool hoisted_baby = true) const
+    {
+        check_ct(ct);
+        if (ct.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+        if (shifted_diags.empty()) throw std::invalid_argument("encrypteds cannot be empty");
+        const int d = (int)shifted_diags.size();
+        double ns = 0;
+        std::vector<const std::uint64_t *> pts;
+        for (const Plaintext &p : shifted_diags) {
+            check_pt(ct, p);
+            const double s = ct.scale() * p.scale();
+            check_scale(s, ct.parms_id());
+            if (!pts.empty() && !close(ns, s)) throw std::invalid_argument("scale mismatch");
+            if (pts.empty()) ns = s;
+            if (p.is_zero()) throw std::logic_error("result ciphertext is transparent");
+            pts.push_back(p.buf->p);
+        }
+        std::vector<std::uint32_t> elts;
+        std::vector<const std::uint64_t *> keys;
+        for (const auto &kv : gk.keys) {
+            elts.push_back(kv.first);
+            keys.push_back(kv.second->p);
+        }
+        auto out = shim::new_buf(eng(), words(2, ct.rows));
+        shim::check(::hefx_linear_transform_plain_bsgs(eng()->live(), ct.rows, ct.buf->p, d, n1, pts.data(),
+                                                       (int)keys.size(), elts.data(), keys.data(), hoisted_baby ? 1 : 0,
+                                                       out->p, nullptr));
+        dest.set(out, 2, ct.rows, ct.parms_id(), ns);
+    }
+
 private:
     const std::shared_ptr<shim::Engine> &eng() const { return ctx_->engine(); }
     std::size_t words(std::size_t size, int rows) const { return size * (std::size_t)rows * ctx_->n(); }

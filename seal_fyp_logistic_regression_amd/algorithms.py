@@ -81,6 +81,30 @@ def _rotations_batched(ev: Evaluator, ct: Ciphertext, steps: Sequence[int], gal_
     return out
 
 
+def _plain_product_scale(ev: Evaluator, ct: Ciphertext, pts: Sequence[Plaintext]) -> float:
+    """The checks multiply_plain + add_many would make over ct (.) pts[i], and the common product scale.  One set
+    comprehension when everything is in order (a 1000-diagonal transform is otherwise host-bound in this loop); the
+    element-by-element walk only runs to raise the exception of the FIRST offending plaintext, like the op-by-op
+    sequence."""
+    L = ct.parms_id()
+    if {(p._parms_id, p._scale, p.is_zero) for p in pts} == {(L, pts[0]._scale, False)}:
+        scale = ct.scale * pts[0]._scale
+        ev._check_scale(scale, L)
+        return scale
+    scale = None
+    for p in pts:
+        if p.parms_id() != L:
+            raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
+        s = ct.scale * p.scale
+        ev._check_scale(s, L)
+        if scale is not None and not ev._close(scale, s):
+            raise ValueError("scale mismatch")
+        scale = s if scale is None else scale
+        if p.is_zero:
+            raise RuntimeError("result ciphertext is transparent")
+    return scale
+
+
 def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Plaintext],
                            gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
     """Linear_Transform_Plain, helper.h:237-262 (= linear_transformation2.cpp:149-174).
@@ -172,22 +196,85 @@ def _linear_transform_plain_native(ev: Evaluator, native, ct: Ciphertext, U_diag
     L = ct.parms_id()
     if ct.size() != 2:
         raise ValueError("encrypted size must be 2")
-    scale = None
-    for p in U_diagonals:
-        if p.parms_id() != L:
-            raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
-        s = ct.scale * p.scale
-        ev._check_scale(s, L)
-        if scale is not None and not ev._close(scale, s):
-            raise ValueError("scale mismatch")
-        scale = s if scale is None else scale
-        if p.is_zero:
-            raise RuntimeError("result ciphertext is transparent")
+    scale = _plain_product_scale(ev, ct, U_diagonals)
     # missing keys / too large steps come back from the engine with SEAL's messages (ValueError)
     elts = sorted(gal_keys.keys)
     data = native(L, ct.data, [p.data for p in U_diagonals], elts, [gal_keys.key(e) for e in elts],
                   **({"hoisted": True} if hoisted else {}))
     return Ciphertext()._set(data, 2, L, scale)
+
+
+# ---- baby-step / giant-step form of Linear_Transform_Plain -----------------------------------
+# With l = j*n1 + i (i < n1 baby, j < n2 giant):
+#   sum_l diag_l (.) rot_l(v)  =  sum_j rot_(j*n1)( sum_i rot_(-j*n1)(diag_l) (.) rot_i(v) )
+# so a d x d transform needs n1-1 (hoisted) + n2-1 key switches instead of d-1, and n1+n2-1 Galois keys instead of d
+# (d = 1000: 63 and 64 against 999 and 1000), at the price of diagonals that are rotated in the clear before they
+# are encoded.  A different operation sequence than helper.h:237-262, so NOT its noise bits: same decryption, checked
+# bit-for-bit against the same composition on the oracle-backed twin.
+def bsgs_split(d: int, n1: int = None):
+    """(n1, n2) with n1*n2 >= d; default n1 = ceil(sqrt(d))"""
+    if n1 is None:
+        n1 = max(1, int(np.ceil(np.sqrt(d))))
+    return n1, (d + n1 - 1) // n1
+
+
+def bsgs_steps(d: int, n1: int = None) -> List[int]:
+    """rotation steps the transform needs direct Galois keys for (keygen.galois_keys(bsgs_steps(d)))"""
+    n1, n2 = bsgs_split(d, n1)
+    return [-d] + list(range(1, n1)) + [j * n1 for j in range(1, n2)]
+
+
+def bsgs_diagonals(diagonals: np.ndarray, n1: int = None) -> List[np.ndarray]:
+    """diagonals[l] (length d, helper.h:198-209) shifted right by (l // n1) * n1 slots -- what
+    linear_transform_plain_bsgs expects, still in the clear; encode each with the ciphertext's scale and level."""
+    d = len(diagonals)
+    n1, _ = bsgs_split(d, n1)
+    out = []
+    for l in range(d):
+        shift = (l // n1) * n1
+        v = np.zeros(shift + d, dtype=np.asarray(diagonals[l]).dtype)
+        v[shift:] = diagonals[l]
+        out.append(v)
+    return out
+
+
+def linear_transform_plain_bsgs(ev: Evaluator, ct: Ciphertext, shifted_diagonals: Sequence[Plaintext],
+                                gal_keys: KSwitchKeys, n1: int = None, hoisted: bool = True) -> Ciphertext:
+    """Linear_Transform_Plain (helper.h:237-262) in baby-step / giant-step form; `shifted_diagonals` are the
+    encodings of bsgs_diagonals(...), gal_keys must hold direct keys for bsgs_steps(d, n1).  hoisted=True shares the
+    digit decomposition of ct_new over the baby rotations (hefx_rotate_hoisted_batch)."""
+    be, L = ev.be, ct.parms_id()
+    d = len(shifted_diagonals)
+    n1, n2 = bsgs_split(d, n1)
+    if d + n1 * n2 > ev.ctx.N // 2:  # the shifted diagonals and the rotated duplicate must not wrap around
+        raise ValueError("baby-step/giant-step transform: dimension too large for the slot count")
+    native = getattr(be, "linear_transform_plain_bsgs", None)
+    if native is not None:  # the HIP engine: the whole composition behind one C-ABI call, same bits as the lines below
+        if ct.size() != 2:
+            raise ValueError("encrypted size must be 2")
+        scale = _plain_product_scale(ev, ct, shifted_diagonals)
+        elts = sorted(gal_keys.keys)
+        data = native(L, ct.data, [p.data for p in shifted_diagonals], n1, elts, [gal_keys.key(e) for e in elts],
+                      hoisted)
+        return Ciphertext()._set(data, 2, L, scale)
+    baby = list(range(1, n1))
+    plans = [ev.rotation_plan(s, gal_keys) for s in baby + [j * n1 for j in range(1, n2)]]
+    if any(len(p) != 1 for p in plans):
+        raise ValueError("baby-step/giant-step transform needs a direct Galois key for every step of bsgs_steps(d)")
+    ct_new = ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))          # helper.h:244-247
+    elts = [p[0] for p in plans]
+    if hoisted and baby:
+        data = be.rotate_hoisted_batch(L, ct_new.data, elts[:n1 - 1], [gal_keys.key(e) for e in elts[:n1 - 1]])
+        rots = [ct_new] + [Ciphertext()._set(x, 2, L, ct_new.scale) for x in data]
+    else:
+        rots = [ct_new] + _rotations_batched(ev, ct_new, baby, gal_keys)
+    # inner sums: group j = sum_i rots[i] (.) diag'[j*n1 + i], all groups in one pass
+    inner = ev.multiply_plain_sum([rots[l % n1] for l in range(d)], list(shifted_diagonals), group=n1)
+    if n2 > 1:
+        outs = be.apply_galois_batch(L, [c.data for c in inner[1:]], elts[n1 - 1:],
+                                     [gal_keys.key(e) for e in elts[n1 - 1:]])
+        inner = inner[:1] + [Ciphertext()._set(x, 2, L, inner[0].scale) for x in outs]
+    return ev.add_many(inner)
 
 
 def linear_transform_cipher(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[Ciphertext],
@@ -204,7 +291,8 @@ def linear_transform_cipher(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence
 def linear_transform_ciphermatrix_plainvector(ev: Evaluator, pt_rotations: Sequence[Plaintext],
                                               U_diagonals: Sequence[Ciphertext]) -> Ciphertext:
     """Linear_Transform_CipherMatrix_PlainVector, helper.h:265-278."""
-    return ev.add_many([ev.multiply_plain(U_diagonals[i], pt_rotations[i]) for i in range(len(pt_rotations))])
+    n = len(pt_rotations)                                            # :271 multiply_plain, :275 add_many -- one pass
+    return ev.multiply_plain_sum(list(U_diagonals[:n]), list(pt_rotations))[0]
 
 
 def c_matrix_encode(ev: Evaluator, matrix: Sequence[Ciphertext], gal_keys: KSwitchKeys) -> Ciphertext:

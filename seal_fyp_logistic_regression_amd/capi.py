@@ -56,6 +56,7 @@ _SIGS = {
     "hefx_add_many": (_i, [_vp, _i, _i, _i, _pp, _vp, _vp]),
     "hefx_multiply_plain": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "hefx_check_transparent": (_i, [_vp, _vp]),
+    "hefx_multiply_plain_sum": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _pp, _vp]),
     "hefx_multiply": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "hefx_square": (_i, [_vp, _i, _vp, _vp, _vp]),
     "hefx_apply_galois": (_i, [_vp, _i, _vp, _u32, _vp, _vp, _vp]),
@@ -70,6 +71,7 @@ _SIGS = {
     "hefx_rotate_hoisted_batch": (_i, [_vp, _i, _vp, _i, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_linear_transform_plain_hoisted": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_linear_transform_plain_hoisted2": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
+    "hefx_linear_transform_plain_bsgs": (_i, [_vp, _i, _vp, _i, _i, _pp, _i, C.POINTER(_u32), _pp, _i, _vp, _vp]),
     "hefx_ckks_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp]),
     "hefx_sample_uniform": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_sample_ternary": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),

@@ -612,6 +612,48 @@ extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint
     return HEFX_OK;
 }
 
+extern "C" int hefx_multiply_plain_sum(hefx_context *c, int L, int size, int n, int group,
+                                       const uint64_t *const *cts, const uint64_t *const *pts, uint64_t *const *outs,
+                                       void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (n < 1 || size < 1 || group < 1 || !cts || !pts || !outs)
+        return fail(HEFX_ERR_INVALID, "bad multiply_plain_sum arguments");
+    if (group > n) group = n;
+    const int groups = (n + group - 1) / group;
+    for (int i = 0; i < n; ++i)
+        if (!cts[i] || !pts[i]) return fail(HEFX_ERR_INVALID, "null operand in multiply_plain_sum");
+    for (int g = 0; g < groups; ++g) {
+        if (!outs[g]) return fail(HEFX_ERR_INVALID, "null output in multiply_plain_sum");
+        for (int i = g * group; i < n && i < (g + 1) * group; ++i)
+            if (cts[i] == outs[g]) return fail(HEFX_ERR_INVALID, "multiply_plain_sum output aliases an input");
+    }
+    // the pointer table travels through a ring slot of the key-switch descriptors; whole groups per slice
+    constexpr int TABLE_MAX = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *));
+    if (2 * group + 1 > TABLE_MAX) return fail(HEFX_ERR_INVALID, "multiply_plain_sum group too large");
+    const int gps = TABLE_MAX / (2 * group + 1);  // groups per slice
+    hipStream_t s = (hipStream_t)stream;
+    for (int g0 = 0; g0 < groups; g0 += gps) {
+        const int ng = groups - g0 < gps ? groups - g0 : gps;
+        const int i0 = g0 * group, cnt = (n - i0 < ng * group) ? n - i0 : ng * group;
+        const unsigned slot = c->ring_next++ % KS_RING;
+        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));
+        const uint64_t **hp = reinterpret_cast<const uint64_t **>(c->h_items + (size_t)slot * KS_MAX_CHUNK);
+        const u64 *const *dp = reinterpret_cast<const u64 *const *>(c->d_items + (size_t)slot * KS_MAX_CHUNK);
+        for (int i = 0; i < cnt; ++i) {
+            hp[i] = cts[i0 + i];
+            hp[cnt + i] = pts[i0 + i];
+        }
+        for (int g = 0; g < ng; ++g) hp[2 * cnt + g] = outs[g0 + g];
+        HIPCHK(hipMemcpyAsync((void *)dp, hp, sizeof(void *) * (2 * (size_t)cnt + ng), hipMemcpyHostToDevice, s));
+        HIPCHK(launch_mulplain_sum(c->T, L, size, dp, cnt, group, s));
+        HIPCHK(hipEventRecord(c->ring_ev[slot], s));
+        c->ring_busy[slot] = true;
+    }
+    return HEFX_OK;
+}
+
 extern "C" int hefx_multiply(hefx_context *c, int L, const uint64_t *a, const uint64_t *b, uint64_t *out3,
                              void *stream)
 {
@@ -1160,6 +1202,99 @@ extern "C" int hefx_linear_transform_plain_hoisted(hefx_context *c, int L, const
 {
     return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, true);
 }
+// Baby-step / giant-step Linear_Transform_Plain: with l = j*n1 + i,
+//   sum_l diag_l (.) rot_l(ct_new) = sum_j rot_(j*n1)( sum_i diag'_l (.) rot_i(ct_new) ),  diag'_l = diag_l shifted
+// right by j*n1 slots in the clear (the caller encodes them that way).  n1-1 baby rotations of ct_new (one hoisted
+// batch, or regular key switches), the inner sums in one pass (hefx_multiply_plain_sum), n2-1 giant rotations (one
+// regular batch), one add_many.  Direct Galois keys for 1..n1-1 and n1, 2*n1, ..; rotate(-d) may use a NAF chain.
+extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const uint64_t *ct, int d, int n1,
+                                                const uint64_t *const *shifted_diag_pts, int nkeys,
+                                                const uint32_t *key_elts, const uint64_t *const *keys, int hoisted_baby,
+                                                uint64_t *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (!ct || !out || d < 1 || n1 < 1 || n1 > d || !shifted_diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+        return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    const int n2 = (d + n1 - 1) / n1;
+    if ((size_t)d + (size_t)n1 * n2 > c->n / 2)
+        return fail(HEFX_ERR_INVALID, "baby-step/giant-step transform: dimension too large for the slot count");
+    for (int i = 0; i < d; ++i)
+        if (!shifted_diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    LtKeys K;
+    for (int i = 0; i < nkeys; ++i) {
+        if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
+        K.m[key_elts[i]] = keys[i];
+    }
+    const size_t N = c->n, ctw = 2 * (size_t)L * N;
+    std::vector<uint32_t> first, plan, belt, gelt;
+    if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
+    for (int t = 1; t < n1 + n2 - 1; ++t) {  // baby steps 1..n1-1, then giant steps n1, 2*n1, ...
+        const int step = t < n1 ? t : (t - n1 + 1) * n1;
+        plan.clear();
+        if (const char *err = lt_plan(step, N, K, plan)) return fail(HEFX_ERR_INVALID, err);
+        if (plan.size() != 1)
+            return fail(HEFX_ERR_INVALID,
+                        "baby-step/giant-step transform needs a direct Galois key for every baby and giant step");
+        (t < n1 ? belt : gelt).push_back(plan[0]);
+    }
+    // ---- workspace: ping / pong / ct_new, n1-1 baby rotations, n2 inner sums, n2-1 rotated inner sums
+    const size_t need = ctw * (size_t)(3 + (n1 - 1) + n2 + (n2 - 1));
+    if (c->lt_cap < need) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
+        c->lt_ws = nullptr;
+        c->lt_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->lt_ws, need * sizeof(u64)));
+        c->lt_cap = need;
+    }
+    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw,
+             *rots = ct_new + ctw, *inner = rots + (size_t)(n1 - 1) * ctw, *grot = inner + (size_t)n2 * ctw;
+    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247)
+    const uint64_t *src = ct;
+    for (size_t t = 0; t < first.size(); ++t) {
+        uint64_t *dst = (t & 1) ? pong : ping;
+        const uint64_t *key = K.m[first[t]];
+        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
+        src = dst;
+    }
+    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
+    std::vector<const uint64_t *> in, kk;
+    std::vector<uint64_t *> oo;
+    // ---- baby steps: rots[i-1] = rotate(ct_new, i)
+    if (n1 > 1) {
+        for (int i = 1; i < n1; ++i) {
+            in.push_back(ct_new);
+            kk.push_back(K.m[belt[i - 1]]);
+            oo.push_back(rots + (size_t)(i - 1) * ctw);
+        }
+        if (int rc = ks_run(c, L, n1 - 1, false, in.data(), belt.data(), kk.data(), nullptr, nullptr, oo.data(), stream,
+                            hoisted_baby != 0))
+            return rc;
+    }
+    // ---- inner[j] = sum_i rotate(ct_new, i) (.) diag'[j*n1 + i]
+    std::vector<const uint64_t *> cc(d);
+    std::vector<uint64_t *> io(n2);
+    for (int l = 0; l < d; ++l) cc[l] = (l % n1) ? rots + (size_t)(l % n1 - 1) * ctw : ct_new;
+    for (int j = 0; j < n2; ++j) io[j] = inner + (size_t)j * ctw;
+    if (int rc = hefx_multiply_plain_sum(c, L, 2, d, n1, cc.data(), shifted_diag_pts, io.data(), stream)) return rc;
+    // ---- giant steps and the final sum
+    std::vector<const uint64_t *> res(n2);
+    res[0] = inner;
+    if (n2 > 1) {
+        in.clear(), kk.clear(), oo.clear();
+        for (int j = 1; j < n2; ++j) {
+            in.push_back(inner + (size_t)j * ctw);
+            kk.push_back(K.m[gelt[j - 1]]);
+            oo.push_back(grot + (size_t)(j - 1) * ctw);
+            res[j] = oo.back();
+        }
+        if (int rc = ks_run(c, L, n2 - 1, false, in.data(), gelt.data(), kk.data(), nullptr, nullptr, oo.data(), stream))
+            return rc;
+    }
+    return hefx_add_many(c, L, 2, n2, res.data(), out, stream);
+}
+
 // Double-hoisted Linear_Transform_Plain (see lt2_mac_kernel): top data level, direct keys for 1..d-1, diagonals
 // encoded at the KEY level ([k][N]: data primes then the special prime).
 extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, const uint64_t *ct, int d,

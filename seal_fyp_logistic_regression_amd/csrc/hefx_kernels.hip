@@ -214,6 +214,68 @@ hipError_t launch_add_many_table(const DevTables &T, int L, int size, const u64 
     return hipGetLastError();
 }
 
+// Grouped sum of plaintext products: group gi forms  out[gi] = sum_i ct[i] (.) pt[i]  over its slice [gi*group,
+// min(n,(gi+1)*group)) of a DEVICE pointer table laid out as  n ciphertexts | n plaintexts | groups outputs.
+// One pass: every operand word is read once and only the sums are written (n multiply_plain + add_many would write
+// and re-read 2n ciphertexts).  128-bit lazy accumulation, folded every 32 terms (products < 2^122), one Barrett at
+// the end -- the canonical residue of the sum, i.e. the bits of the op-by-op sequence.
+__global__ __launch_bounds__(256) void mulplain_sum_kernel(DevTables T, int L, int size, const u64 *const *__restrict__ tab,
+                                                           int n, int group)
+{
+    const int logn = T.logn;
+    const size_t row_pairs = (size_t)1 << (logn - 1), poly_pairs = row_pairs * (size_t)L;
+    const size_t total_pairs = poly_pairs * (size_t)size;
+    const int gi = blockIdx.y;
+    const int first = gi * group, last = first + group < n ? first + group : n;
+    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + gi]));
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
+         w += (size_t)gridDim.x * blockDim.x) {
+        const size_t wp = w % poly_pairs;  // the plaintext word every poly of the ciphertext meets
+        const ModConst mc = T.mods[(int)(wp >> (logn - 1))];
+        u64 xl = 0, xh = 0, yl = 0, yh = 0;
+        int i = first;
+        for (; i + 4 <= last; i += 4) {  // eight independent loads in flight per lane
+            ulonglong2 c[4], p[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                c[u] = reinterpret_cast<const ulonglong2 *>(tab[i + u])[w];
+                p[u] = reinterpret_cast<const ulonglong2 *>(tab[n + i + u])[wp];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                mac128(xl, xh, c[u].x, p[u].x);
+                mac128(yl, yh, c[u].y, p[u].y);
+            }
+            if (((i - first) & 31) == 28) {  // every 32 terms: products < 2^122, so 32 + 3 tail terms stay below 2^128
+                xl = barrett128(xl, xh, mc);
+                yl = barrett128(yl, yh, mc);
+                xh = yh = 0;
+            }
+        }
+        for (; i < last; ++i) {
+            const ulonglong2 c = reinterpret_cast<const ulonglong2 *>(tab[i])[w];
+            const ulonglong2 p = reinterpret_cast<const ulonglong2 *>(tab[n + i])[wp];
+            mac128(xl, xh, c.x, p.x);
+            mac128(yl, yh, c.y, p.y);
+        }
+        ulonglong2 r;
+        r.x = barrett128(xl, xh, mc);
+        r.y = barrett128(yl, yh, mc);
+        out[w] = r;
+    }
+}
+
+hipError_t launch_mulplain_sum(const DevTables &T, int L, int size, const u64 *const *d_tab, int n, int group,
+                               hipStream_t s)
+{
+    const size_t total_pairs = (size_t)size * L * ((size_t)1 << T.logn) / 2;
+    int blocks = (int)((total_pairs + 255) / 256);
+    if (blocks > 256 * 8) blocks = 256 * 8;
+    const int groups = (n + group - 1) / group;
+    hipLaunchKernelGGL(mulplain_sum_kernel, dim3(blocks, groups), dim3(256), 0, s, T, L, size, d_tab, n, group);
+    return hipGetLastError();
+}
+
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
                            u64 *out, hipStream_t s)
 {

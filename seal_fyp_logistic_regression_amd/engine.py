@@ -174,6 +174,18 @@ class Engine:
         capi.check(capi.lib().hefx_multiply_plain(self._h, L, size, count, ct.ptr, pt.ptr, out.ptr, stream))
         return out
 
+    def multiply_plain_sum(self, L, size, cts, pts, group=None, outs=None, stream=None):
+        """outs[g] = sum over group g of cts[i] (.) pts[i] (hefx_multiply_plain_sum); group=None: one sum of all n"""
+        n = len(cts)
+        group = n if group is None else int(group)
+        groups = (n + group - 1) // group
+        if outs is None:
+            outs = self.empty_many(groups, (size, L, self.N))
+        capi.check(capi.lib().hefx_multiply_plain_sum(self._h, L, size, n, group, capi.ptr_array([c.ptr for c in cts]),
+                                                      capi.ptr_array([p.ptr for p in pts]),
+                                                      capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
     def check_transparent(self, stream=None):
         capi.check(capi.lib().hefx_check_transparent(self._h, stream))
 
@@ -257,6 +269,16 @@ class Engine:
         capi.check(f(
             self._h, L, ct.ptr, len(diag_pts), capi.ptr_array([p.ptr for p in diag_pts]), len(keys),
             capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
+        return out
+
+    def linear_transform_plain_bsgs(self, L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted=True, out=None,
+                                    stream=None):
+        """baby-step / giant-step Linear_Transform_Plain in one native call (hefx_linear_transform_plain_bsgs)"""
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        capi.check(capi.lib().hefx_linear_transform_plain_bsgs(
+            self._h, L, ct.ptr, len(shifted_diag_pts), int(n1), capi.ptr_array([p.ptr for p in shifted_diag_pts]),
+            len(keys), capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), 1 if hoisted else 0, out.ptr,
+            stream))
         return out
 
     # ---- randomness, encrypt, decrypt on the GPU

@@ -138,6 +138,9 @@ class GpuBackend:
     def multiply_plain(self, L, size, ct, pt):
         return self.engine.multiply_plain(L, size, ct, pt)
 
+    def multiply_plain_sum(self, L, size, cts, pts, group=None):
+        return self.engine.multiply_plain_sum(L, size, cts, pts, group)
+
     def multiply(self, L, a, b):
         return self.engine.multiply(L, a, b)
 
@@ -170,6 +173,9 @@ class GpuBackend:
 
     def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None):
         return self.engine.rotate_hoisted_batch(L, ct, elts, keys, pts)
+
+    def linear_transform_plain_bsgs(self, L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted=True):
+        return self.engine.linear_transform_plain_bsgs(L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted)
 
     def sample(self, kind, key32, stream_id, npoly, nrows, mod_first=0):
         return self.engine.sample(kind, key32, stream_id, npoly, nrows, mod_first)
@@ -713,6 +719,29 @@ class Evaluator:
 
     def multiply_plain_inplace(self, a, p):
         return self.multiply_plain(a, p, a)
+
+    def multiply_plain_sum(self, cts: Sequence[Ciphertext], pts: Sequence[Plaintext], group: Optional[int] = None):
+        """add_many(multiply_plain(cts[i], pts[i])) per group of `group` consecutive terms (None: one group), in one
+        pass over the operands (hefx_multiply_plain_sum).  Checks and exceptions of the op-by-op sequence
+        (helper.h:271,275), same bits.  Returns the list of group sums."""
+        if not cts or len(cts) != len(pts):
+            raise ValueError("multiply_plain_sum: need as many plaintexts as ciphertexts")
+        L, size = cts[0].parms_id(), cts[0].size()
+        scale = None
+        for a, p in zip(cts, pts):
+            if a.parms_id() != L or a.size() != size:
+                raise ValueError("encrypted parameter mismatch")
+            if a.parms_id() != p.parms_id():
+                raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
+            s = a.scale * p.scale
+            self._check_scale(s, L)
+            if scale is not None and not self._close(scale, s):
+                raise ValueError("scale mismatch")
+            scale = s if scale is None else scale
+            if p.is_zero:
+                raise RuntimeError("result ciphertext is transparent")
+        outs = self.be.multiply_plain_sum(L, size, [a.data for a in cts], [p.data for p in pts], group)
+        return [Ciphertext()._set(o, size, L, scale) for o in outs]
 
     def multiply(self, a: Ciphertext, b: Ciphertext, destination=None):
         self._check_same(a, b)

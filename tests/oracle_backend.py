@@ -57,6 +57,13 @@ class OracleBackend:
     def multiply_plain(self, L, size, ct, pt):
         return self.o.multiply_plain(self._ct(ct, size, L), np.ascontiguousarray(pt).reshape(L, self.N))
 
+    def multiply_plain_sum(self, L, size, cts, pts, group=None):
+        # the op-by-op statement: multiply_plain each (helper.h:271), add_many per group (:275)
+        n = len(cts)
+        group = n if group is None else group
+        return [self.add_many(L, size, [self.multiply_plain(L, size, cts[i], pts[i])
+                                        for i in range(g, min(n, g + group))]) for g in range(0, n, group)]
+
     def multiply(self, L, a, b):
         return self.o.multiply(self._ct(a, 2, L), self._ct(b, 2, L))
 

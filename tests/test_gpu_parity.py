@@ -132,6 +132,38 @@ def test_add_many(c2):
     assert (e.add_many(L, 3, [d3[i % 4] for i in range(100)]).download() == want3).all()
 
 
+def test_multiply_plain_sum_bit_exact(c2):
+    """hefx_multiply_plain_sum (helper.h:265-278 in one pass): uniform residues, against multiply_plain + add per term;
+    one group, ragged groups, a sum longer than one accumulator fold (128), more groups than one pointer-table slice,
+    size-3 ciphertexts, and the argument checks."""
+    o, e, _ = c2
+    L = 3
+    cts = [o.uniform(L, 2, 7000 + i) for i in range(9)]
+    pts = [o.uniform(L, 1, 7100 + i)[0] for i in range(7)]
+    dct, dpt = [e.to_device(c) for c in cts], [e.to_device(p) for p in pts]
+
+    def want(idx):
+        acc = None
+        for ci, pi in idx:
+            t = o.multiply_plain(cts[ci], pts[pi])
+            acc = t if acc is None else o.add(acc, t)
+        return acc
+
+    for n, group in ((5, None), (23, 4), (300, 300), (700, 3)):
+        idx = [(i % 9, (3 * i + 1) % 7) for i in range(n)]
+        g = n if group is None else group
+        outs = e.multiply_plain_sum(L, 2, [dct[a] for a, _ in idx], [dpt[b] for _, b in idx], group)
+        assert len(outs) == (n + g - 1) // g
+        for k in (0, len(outs) // 2, len(outs) - 1):
+            assert (outs[k].download() == want(idx[k * g:(k + 1) * g])).all(), (n, group, k)
+    c3 = np.ascontiguousarray(o.multiply(cts[0], cts[1])[:, :2])  # size 3, one level down
+    p0, p1 = np.ascontiguousarray(pts[0][:2]), np.ascontiguousarray(pts[1][:2])
+    got = e.multiply_plain_sum(2, 3, [e.to_device(c3)] * 2, [e.to_device(p0), e.to_device(p1)])[0]
+    assert (got.download() == o.add(o.multiply_plain(c3, p0), o.multiply_plain(c3, p1))).all()
+    with pytest.raises(ValueError):
+        e.multiply_plain_sum(L, 2, [dct[0]], [dpt[0]], outs=[dct[0]])  # output aliases an input
+
+
 def _rand_key(o, seed):
     return o.uniform(o.k, 2 * (o.k - 1), seed).reshape(o.k - 1, 2, o.k, o.N)
 

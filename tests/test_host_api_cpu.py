@@ -231,3 +231,56 @@ def test_double_hoisted_linear_transform_decrypts_to_the_matrix_product(env):
     assert np.abs(dec(e, h2, d).real - dec(e, ref, d).real).max() < 1e-3
     with pytest.raises(ValueError, match="key-level"):
         alg.linear_transform_plain(ev, cw, diags, gk, hoisted=2)
+
+
+def test_multiply_plain_sum_equals_the_op_by_op_sequence_and_checks_like_it(env):
+    """Evaluator.multiply_plain_sum = add_many(multiply_plain(...)) per group (helper.h:271,275): same payload on the
+    oracle twin by construction, SEAL's exceptions for mismatched scale / level / transparent operands."""
+    e = env
+    ev, encoder = e["ev"], e["encoder"]
+    rng = np.random.default_rng(5)
+    scale = 2.0 ** 30
+    vs, ws = rng.standard_normal((5, 8)), rng.standard_normal((5, 8))
+    cts = [e["enc"].encrypt(encoder.encode(v, scale)) for v in vs]
+    pts = [encoder.encode(w, scale) for w in ws]
+    one = ev.multiply_plain_sum(cts, pts)
+    assert len(one) == 1 and np.abs(dec(e, one[0], 8).real - (vs * ws).sum(0)).max() < 1e-3
+    ref = ev.add_many([ev.multiply_plain(c, p) for c, p in zip(cts, pts)])
+    assert (one[0].data == ref.data).all() and one[0].scale == ref.scale
+    grouped = ev.multiply_plain_sum(cts, pts, group=2)
+    assert len(grouped) == 3
+    assert np.abs(dec(e, grouped[2], 8).real - vs[4] * ws[4]).max() < 1e-3
+    pv = alg.linear_transform_ciphermatrix_plainvector(ev, pts, cts)       # helper.h:265-278
+    assert (pv.data == ref.data).all()
+    with pytest.raises(ValueError, match="scale mismatch"):
+        ev.multiply_plain_sum(cts, pts[:4] + [encoder.encode(ws[4], 2.0 ** 20)])
+    with pytest.raises(RuntimeError, match="transparent"):
+        ev.multiply_plain_sum(cts, pts[:4] + [encoder.encode(np.zeros(8), scale)])
+    low = encoder.encode(ws[4], scale, parms_id=cts[0].parms_id() - 1)
+    with pytest.raises(ValueError, match="parameter mismatch"):
+        ev.multiply_plain_sum(cts, pts[:4] + [low])
+
+
+@pytest.mark.parametrize("d,n1", [(6, None), (7, 2), (9, 4), (5, 5)])
+def test_bsgs_linear_transform_decrypts_to_the_matrix_product(env, d, n1):
+    """baby-step / giant-step form of Linear_Transform_Plain: n1-1 + n2-1 key switches, M.v in the first d slots,
+    with and without hoisted baby steps; missing direct keys are refused."""
+    e = env
+    ctx, ev, kg, encoder = e["ctx"], e["ev"], e["kg"], e["encoder"]
+    steps = alg.bsgs_steps(d, n1)
+    a, b = alg.bsgs_split(d, n1)
+    assert a * b >= d and len(steps) == a + b - 1
+    gk = kg.galois_keys(steps)
+    rng = np.random.default_rng(d)
+    M, w = rng.standard_normal((d, d)), rng.standard_normal(d)
+    scale = 2.0 ** 30
+    sd = [encoder.encode(x, scale) for x in alg.bsgs_diagonals(alg.get_all_diagonals(M), n1)]
+    cw = e["enc"].encrypt(encoder.encode(w, scale))
+    ref = alg.linear_transform_plain(ev, cw, [encoder.encode(x, scale) for x in alg.get_all_diagonals(M)],
+                                     kg.galois_keys([-d] + list(range(1, d))))
+    for hoisted in (True, False):
+        r = alg.linear_transform_plain_bsgs(ev, cw, sd, gk, n1, hoisted=hoisted)
+        assert r.parms_id() == ref.parms_id() and r.scale == ref.scale and r.size() == 2
+        assert np.abs(dec(e, r, d).real - M @ w).max() < 1e-2
+    with pytest.raises(ValueError, match="direct Galois key"):
+        alg.linear_transform_plain_bsgs(ev, cw, sd, e["gk"], n1)  # power-of-two keys only: step 3 (or 6) is missing

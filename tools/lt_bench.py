@@ -4,7 +4,9 @@ timer at linear_transformation.cpp:540-542.  Three modes:
   naf      the reference's setup: default power-of-two Galois keys, NAF chains (bit-exact to the op-by-op sequence)
   direct   a direct Galois key per step (keygen.galois_keys(steps)): one key switch per rotation (bit-exact)
   hoisted  direct keys + shared digit decomposition (fast mode, not SEAL's bits; same decryption)
-  hoisted2 double hoisting: additionally ONE mod-down for the whole transform (key-level diagonals)"""
+  hoisted2 double hoisting: additionally ONE mod-down for the whole transform (key-level diagonals)
+  bsgs     baby-step/giant-step (algorithms.linear_transform_plain_bsgs): ~2*sqrt(d) keys and key switches, hoisted
+           baby steps, inner sums through hefx_multiply_plain_sum"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -29,11 +31,21 @@ for d in [int(x) for x in (sys.argv[1:] or ["10", "100", "1000"])]:
     gk_direct = kg.galois_keys(steps)
     keygen_s = time.perf_counter() - t0
     diags_key = encoder.encode_many(list(alg.get_all_diagonals(M)), scale, parms_id=ctx.k)
+    t0 = time.perf_counter()
+    gk_bsgs = kg.galois_keys(alg.bsgs_steps(d))
+    keygen_bsgs_s = time.perf_counter() - t0
+    diags_bsgs = encoder.encode_many(alg.bsgs_diagonals(alg.get_all_diagonals(M)), scale)
     for mode, gk, hoisted in (("naf", gk_default, False), ("direct", gk_direct, False), ("hoisted", gk_direct, True),
-                              ("hoisted2", gk_direct, 2)):
-        ks = sum(len(ev.rotation_plan(s, gk)) for s in steps)
-        diags = diags_key if hoisted == 2 else diags_data
-        alg.linear_transform_plain(ev, ct, diags, gk, hoisted=hoisted); ctx.backend.engine.sync()
+                              ("hoisted2", gk_direct, 2), ("bsgs", gk_bsgs, "bsgs")):
+        if hoisted == "bsgs":
+            ks = len(alg.bsgs_steps(d))
+            diags = diags_bsgs
+            run = lambda: alg.linear_transform_plain_bsgs(ev, ct, diags_bsgs, gk_bsgs)
+        else:
+            ks = sum(len(ev.rotation_plan(s, gk)) for s in steps)
+            diags = diags_key if hoisted == 2 else diags_data
+            run = lambda: alg.linear_transform_plain(ev, ct, diags, gk, hoisted=hoisted)
+        run(); ctx.backend.engine.sync()
         reps = 10
         eng = ctx.backend.engine
         e0, e1 = eng.event(), eng.event()
@@ -41,7 +53,7 @@ for d in [int(x) for x in (sys.argv[1:] or ["10", "100", "1000"])]:
         eng.event_record(e0)
         for _ in range(reps):
             t = time.perf_counter()
-            r = alg.linear_transform_plain(ev, ct, diags, gk, hoisted=hoisted)
+            r = run()
             eng.sync()
             walls.append(time.perf_counter() - t)
         eng.event_record(e1)
@@ -50,7 +62,8 @@ for d in [int(x) for x in (sys.argv[1:] or ["10", "100", "1000"])]:
         busy = eng.event_elapsed_ms(e0, e1) / reps * 1e3
         err = float(np.abs(encoder.decode(dec.decrypt(r))[:d].real - M @ v).max())
         out["runs"].append({"d": d, "mode": mode, "key_switches_in_SEAL_order": ks, "gpu_us": dt * 1e6, "hip_event_us": busy, "samples_us": [round(w * 1e6) for w in walls],
-                            "max_abs_err": err, "direct_keygen_s": keygen_s if mode != "naf" else None})
+                            "max_abs_err": err, "direct_keygen_s": None if mode == "naf" else (keygen_bsgs_s if mode == "bsgs" else keygen_s),
+                            "galois_keys": len(gk.keys)})
         print(out["runs"][-1], flush=True)
-    del gk_direct
+    del gk_direct, gk_bsgs
 print(json.dumps(out))
