@@ -60,7 +60,13 @@ uint64_t hefx_prime(const hefx_context *ctx, int j);
 /* minimal primitive 2N-th root used for prime j (SEAL try_minimal_primitive_root) */
 uint64_t hefx_psi(const hefx_context *ctx, int j);
 
-/* ---- device memory + transfers (Ciphertext/Plaintext/key payload ownership stays with the caller) */
+/* ---- device memory + transfers (Ciphertext/Plaintext/key payload ownership stays with the caller).
+ *      hefx_malloc / hefx_free are POOLED per context: a freed block is parked (up to HEFX_POOL_MB megabytes,
+ *      default 16384; 0 = plain hipMalloc / hipFree) and handed out again by a later hefx_malloc of the same size,
+ *      with no device synchronisation -- SEAL's MemoryPoolHandle in spirit (SURVEY 8b "Ownership").  A recycled block
+ *      may still be in use by work submitted before the free; that is correct as long as this earlier work and the
+ *      new owner's work are ordered on the device: one stream (what the shim and seal.py do), or streams the caller
+ *      has ordered with events before calling hefx_free.  Blocks not obtained from hefx_malloc are passed to hipFree. */
 int hefx_malloc(hefx_context *ctx, size_t bytes, void **d_ptr);
 int hefx_free(hefx_context *ctx, void *d_ptr);
 int hefx_upload(hefx_context *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);

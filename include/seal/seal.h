@@ -127,8 +127,7 @@ inline void check(int rc)
 
 // One engine context per distinct (N, primes); created on first use and kept for the life of the process, so the
 // reference's habit of rebuilding SEALContext + Evaluator inside every Linear_Transform_Plain call
-// (helper.h:239-240) costs a map lookup.  Also owns a size-bucketed device-buffer pool: hipFree synchronises the
-// device, so freed payload buffers are recycled instead (all work is ordered on the default stream).
+// (helper.h:239-240) costs a map lookup.
 struct Buf;
 using BufPtr = std::shared_ptr<Buf>;
 
@@ -137,7 +136,6 @@ struct Engine {
     std::uint32_t n = 0;
     std::vector<std::uint64_t> primes;
     std::mutex mu;
-    std::map<std::size_t, std::vector<std::uint64_t *>> pool;
 
     // ---- deferred rotations -------------------------------------------------------------------------------
     // The reference issues its rotations one call at a time (helper.h:252-257: rotate_vector, multiply_plain, next
@@ -163,7 +161,6 @@ struct Engine {
     std::map<const std::uint64_t *, int> pend_dst;                           // output buffer -> node
     std::map<const std::uint64_t *, int> pend_mul_dst;
     bool lazy = true;
-
     hefx_context *live()  // the context, with everything recorded so far submitted
     {
         if (!pend_ks.empty()) flush();
@@ -176,26 +173,16 @@ struct Engine {
                                 bool ct = false);
     inline void flush();
 
+    // payload buffers come from the engine's pooled allocator (hefx_malloc / hefx_free: slab-carved, no hipFree and so no
+    // device synchronisation on the hot path; all work is ordered on the default stream)
     std::uint64_t *alloc(std::size_t words)
     {
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            auto it = pool.find(words);
-            if (it != pool.end() && !it->second.empty()) {
-                std::uint64_t *p = it->second.back();
-                it->second.pop_back();
-                return p;
-            }
-        }
         void *p = nullptr;
-        check(hefx_malloc(ctx_raw, words * sizeof(std::uint64_t), &p));
+        const int rc = hefx_malloc(ctx_raw, words * sizeof(std::uint64_t), &p);
+        if (rc != HEFX_OK) raise(rc);
         return static_cast<std::uint64_t *>(p);
     }
-    void release(std::uint64_t *p, std::size_t words)
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        pool[words].push_back(p);
-    }
+    void release(std::uint64_t *p, std::size_t) { (void)hefx_free(ctx_raw, p); }
 };
 
 inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std::uint64_t> &primes)

@@ -376,6 +376,120 @@ def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, di
     return ctAB
 
 
+# ---- the matrix product restricted to the non-zero diagonals ------------------------------------
+# The permutation matrices of CC_Matrix_Multiplication have 2n-1 (sigma), n (tau), 2 (phi_k) and 1 (psi_k) non-zero
+# diagonals out of n^2; the reference adds 1e-8 to every entry (matrix_multiplication.cpp:239-297) so that SEAL does
+# not refuse the all-zero ones as transparent, and rotates for all n^2.  Dropping them changes the result by those
+# epsilons only (below CKKS noise) -- a fast mode, not the reference's bits: 2n * n^2 rotations become 3n + 3(n-1) - 1.
+def matmul_permutation_matrices(n: int):
+    """U_sigma, U_tau, [V_k], [W_k] (k = 1..n-1) on the row-major flattening: helper.h:702-851 (get_U_sigma, get_U_tau,
+    get_V_k, get_W_k), i.e. sigma, tau, phi^k, psi^k of Jiang et al. 2018/1041."""
+    d = n * n
+    Us, Ut = np.zeros((d, d)), np.zeros((d, d))
+    for i in range(n):
+        for j in range(n):
+            Us[n * i + j, n * i + (i + j) % n] = 1
+            Ut[n * i + j, n * ((i + j) % n) + j] = 1
+    V, W = [], []
+    for k in range(1, n):
+        Vk, Wk = np.zeros((d, d)), np.zeros((d, d))
+        for i in range(n):
+            for j in range(n):
+                Vk[n * i + j, n * i + (j + k) % n] = 1
+                Wk[n * i + j, n * ((i + k) % n) + j] = 1
+        V.append(Vk)
+        W.append(Wk)
+    return Us, Ut, V, W
+
+
+def nonzero_diagonals(U: np.ndarray) -> dict:
+    """{l: l-th diagonal (helper.h:175-195)} for the diagonals of U that are not identically zero"""
+    n = U.shape[0]
+    idx = np.arange(n)
+    out = {}
+    for l in range(n):
+        dg = U[idx, (idx + l) % n]
+        if dg.any():
+            out[l] = dg
+    return out
+
+
+def matmul_permutation_diagonals(n: int):
+    """nonzero_diagonals of the four families of matmul_permutation_matrices(n), built directly from the index maps
+    (the dense d x d matrices take 134 MB each at n = 64): ({l: diag} for sigma, for tau, [for phi^k], [for psi^k])"""
+    d = n * n
+
+    def collect(entries):
+        out = {}
+        for r, c in entries:
+            out.setdefault((c - r) % d, np.zeros(d))[r] = 1.0
+        return dict(sorted(out.items()))
+
+    ij = [(i, j) for i in range(n) for j in range(n)]
+    sigma = collect((n * i + j, n * i + (i + j) % n) for i, j in ij)
+    tau = collect((n * i + j, n * ((i + j) % n) + j) for i, j in ij)
+    phi = [collect((n * i + j, n * i + (j + k) % n) for i, j in ij) for k in range(1, n)]
+    psi = [collect((n * i + j, n * ((i + k) % n) + j) for i, j in ij) for k in range(1, n)]
+    return sigma, tau, phi, psi
+
+
+def _duplicate(ev: Evaluator, ct: Ciphertext, d: int, gal_keys: KSwitchKeys) -> Ciphertext:
+    return ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))            # helper.h:244-247
+
+
+def _sparse_products(ev: Evaluator, ct_new: Ciphertext, terms, gal_keys: KSwitchKeys) -> List[Ciphertext]:
+    """[diag (.) rot_l(ct_new) for (l, diag) in terms], the rotations as one batch (fused with their products)"""
+    rot = [(i, l, p) for i, (l, p) in enumerate(terms) if l]
+    out = [None] * len(terms)
+    for i, (l, p) in enumerate(terms):
+        if not l:
+            out[i] = ev.multiply_plain(ct_new, p)                    # :250
+    for (i, _, _), c in zip(rot, _rotations_batched(ev, ct_new, [l for _, l, _ in rot], gal_keys,
+                                                    [p for _, _, p in rot])):   # :252-257
+        out[i] = c
+    return out
+
+
+def linear_transform_plain_sparse(ev: Evaluator, ct: Ciphertext, d: int, diagonals: dict,
+                                  gal_keys: KSwitchKeys) -> Ciphertext:
+    """Linear_Transform_Plain (helper.h:237-262) of a d x d matrix given by its non-zero diagonals {l: Plaintext}"""
+    if not diagonals:
+        raise ValueError("encrypteds cannot be empty")
+    ct_new = _duplicate(ev, ct, d, gal_keys)
+    return ev.add_many(_sparse_products(ev, ct_new, sorted(diagonals.items()), gal_keys))   # :259
+
+
+def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int, U_sigma: dict,
+                                    U_tau: dict, V_diagonals: Sequence[dict], W_diagonals: Sequence[dict],
+                                    gal_keys: KSwitchKeys) -> Ciphertext:
+    """CC_Matrix_Multiplication (matrix_multiplication.cpp:11-132) over the non-zero diagonals only.  The 2(n-1)
+    Step-2 transforms read the same two duplicated ciphertexts, so all their rotations go out as two batches."""
+    d = dimension * dimension
+    ctA0 = linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys)   # :22
+    ctB0 = linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys)     # :25
+    out = []
+    for ct0, diags in ((ctA0, V_diagonals), (ctB0, W_diagonals)):        # :42-43
+        ct_new = _duplicate(ev, ct0, d, gal_keys)
+        terms = [(l, p) for k in range(dimension - 1) for l, p in sorted(diags[k].items())]
+        prods = _sparse_products(ev, ct_new, terms, gal_keys)
+        cts, pos = [], 0
+        for k in range(dimension - 1):
+            cnt = len(diags[k])
+            cts.append(ev.add_many(prods[pos:pos + cnt]))
+            pos += cnt
+        out.append(cts)
+    ctAk, ctBk = out
+    for c in ctAk + ctBk:
+        ev.rescale_to_next_inplace(c)                                # :69-73
+    ctAB = ev.multiply(ctA0, ctB0)                                   # :104
+    ev.mod_switch_to_next_inplace(ctAB)                              # :112
+    for c in ctAk + ctBk:
+        c.scale = 2.0 ** int(np.log2(c.scale))                       # :117-121 "manual rescale"
+    for k in range(dimension - 1):
+        ev.add_inplace(ctAB, ev.multiply(ctAk[k], ctBk[k]))          # :123-129
+    return ctAB
+
+
 # ---- polynomial evaluation and encrypted logistic regression (logistic_regression_ckks.cpp) -------------------
 def tree_cipher(ev: Evaluator, encoder: CKKSEncoder, encryptor, ctx: Ciphertext, degree: int, scale: float,
                 coeffs: Sequence[float], relin_keys: KSwitchKeys) -> Ciphertext:

@@ -141,6 +141,22 @@ struct hefx_context {
     // linear-transform workspace (rotated copies and products of one hefx_linear_transform_plain call)
     u64 *lt_ws = nullptr;
     size_t lt_cap = 0;
+    // hefx_malloc / hefx_free pool: freed blocks are kept (keyed by their rounded size) and handed out again without
+    // a hipFree -- which synchronises the whole device -- or a hipMalloc.  See the contract at hefx_malloc.
+    struct PoolSlab {
+        void *base;
+        size_t block;       // rounded block size
+        int blocks, parked;  // blocks carved from it / currently in the free list
+    };
+    struct PoolBlock {
+        size_t size;
+        int slab;
+    };
+    std::vector<PoolSlab> pool_slabs;                             // one hipMalloc each; blocks are carved from them
+    std::unordered_map<void *, PoolBlock> pool_block;             // live + parked blocks
+    std::unordered_map<size_t, std::vector<void *>> pool_free;    // rounded size -> parked blocks
+    std::unordered_map<size_t, int> pool_next;                    // rounded size -> blocks of its next slab (doubles)
+    size_t pool_cached = 0, pool_cap = (size_t)16 << 30;          // bytes parked / allowed to stay parked (HEFX_POOL_MB)
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
     hipEvent_t ring_ev[KS_RING] = {};
@@ -328,6 +344,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
     for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
+    if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
     if (const char *ev = getenv("HEFX_STREAMS")) {
         const int v = atoi(ev);
@@ -368,6 +385,8 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
+    for (auto &sl : c->pool_slabs)  // every slab, parked or not: the context's memory ends with the context
+        if (sl.base) (void)hipFree(sl.base);
     for (auto &kv : c->perm) (void)hipFree(kv.second);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     for (int s = 0; s < hefx_context::MAX_STREAMS; ++s) {
@@ -404,18 +423,97 @@ extern "C" uint64_t hefx_psi(const hefx_context *c, int j) { return (c && j >= 0
         if (!(c)) return fail(HEFX_ERR_INVALID, "null context"); \
     } while (0)
 
+// Pooled device memory.  Every evaluator call of the shim / seal.py allocates its result; hipMalloc costs ~4 us (a
+// NAF-expanded 1000-diagonal transform allocates 3800 intermediate ciphertexts: 13 ms of hipMalloc around 4.5 ms of
+// GPU work) and hipFree waits for the whole device, which serialises an otherwise asynchronous call sequence.
+// hefx_malloc therefore carves blocks from slabs -- one hipMalloc for 1, 2, 4, .. 128 blocks of a size class (at most
+// 256 MiB) -- and hefx_free parks the block for the next hefx_malloc of that size.  Slabs whose blocks are all parked
+// are returned to the driver when more than HEFX_POOL_MB (default 16384) is parked, on out-of-memory and at
+// hefx_context_destroy.  No synchronisation is involved in malloc / free: a recycled block may still be read or
+// written by work submitted BEFORE the free, and the new owner's work is submitted AFTER the malloc -- correct
+// whenever both are ordered on the device (one stream, the model of the shim and of seal.py, or streams the caller has
+// ordered with events before freeing).  HEFX_POOL_MB=0 restores plain hipMalloc / hipFree.
+static void pool_release(hefx_context *c)  // returns every fully parked slab to the driver (device-synchronising)
+{
+    (void)hipDeviceSynchronize();
+    for (size_t si = 0; si < c->pool_slabs.size(); ++si) {
+        hefx_context::PoolSlab &sl = c->pool_slabs[si];
+        if (!sl.base || sl.parked != sl.blocks) continue;
+        std::vector<void *> &fl = c->pool_free[sl.block];
+        for (int b = 0; b < sl.blocks; ++b) {
+            void *p = static_cast<char *>(sl.base) + (size_t)b * sl.block;
+            c->pool_block.erase(p);
+            for (size_t t = 0; t < fl.size(); ++t)
+                if (fl[t] == p) {
+                    fl[t] = fl.back();
+                    fl.pop_back();
+                    break;
+                }
+        }
+        c->pool_cached -= (size_t)sl.blocks * sl.block;
+        (void)hipFree(sl.base);
+        sl.base = nullptr;
+    }
+}
 extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
 {
     CTXCHK(c);
     if (!d_ptr) return fail(HEFX_ERR_INVALID, "null out pointer");
-    HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 8));
+    const size_t rounded = ((bytes ? bytes : 8) + 255) & ~(size_t)255;
+    if (!c->pool_cap) {
+        HIPCHK(hipSetDevice(c->device));
+        HIPCHK(hipMalloc(d_ptr, rounded));
+        return HEFX_OK;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::vector<void *> &fl = c->pool_free[rounded];
+    if (fl.empty()) {  // a new slab for this size class
+        int &next = c->pool_next[rounded];
+        if (next < 1) next = 1;
+        int n = next;
+        while (n > 1 && (size_t)n * rounded > ((size_t)256 << 20)) n >>= 1;
+        HIPCHK(hipSetDevice(c->device));
+        void *base = nullptr;
+        hipError_t e = hipMalloc(&base, (size_t)n * rounded);
+        if (e != hipSuccess) {  // out of memory: give back what is parked, then ask for a single block
+            (void)hipGetLastError();
+            pool_release(c);
+            n = 1;
+            e = hipMalloc(&base, rounded);
+        }
+        if (e != hipSuccess) return hipfail(e, "hipMalloc");
+        if (next < 128) next *= 2;
+        const int si = (int)c->pool_slabs.size();
+        c->pool_slabs.push_back(hefx_context::PoolSlab{base, rounded, n, n});
+        for (int b = n - 1; b >= 0; --b) {
+            void *p = static_cast<char *>(base) + (size_t)b * rounded;
+            c->pool_block[p] = hefx_context::PoolBlock{rounded, si};
+            fl.push_back(p);
+        }
+        c->pool_cached += (size_t)n * rounded;
+    }
+    *d_ptr = fl.back();
+    fl.pop_back();
+    c->pool_cached -= rounded;
+    --c->pool_slabs[c->pool_block[*d_ptr].slab].parked;
     return HEFX_OK;
 }
 extern "C" int hefx_free(hefx_context *c, void *d_ptr)
 {
     CTXCHK(c);
-    if (d_ptr) HIPCHK(hipFree(d_ptr));
+    if (!d_ptr) return HEFX_OK;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        auto it = c->pool_block.find(d_ptr);
+        if (it != c->pool_block.end()) {
+            c->pool_free[it->second.size].push_back(d_ptr);
+            c->pool_cached += it->second.size;
+            ++c->pool_slabs[it->second.slab].parked;
+            if (c->pool_cached > c->pool_cap) pool_release(c);
+            return HEFX_OK;
+        }
+    }
+    HIPCHK(hipFree(d_ptr));  // not one of ours (or the pool is off)
     return HEFX_OK;
 }
 extern "C" int hefx_upload(hefx_context *c, void *d_dst, const void *h_src, size_t bytes, void *stream)

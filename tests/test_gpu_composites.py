@@ -119,24 +119,7 @@ def test_cc_matrix_multiplication_n4_known_answer():
     A = np.arange(1, n * n + 1, dtype=float).reshape(n, n)
     want = A @ A
 
-    def u_matrices():
-        # Jiang et al. permutation matrices on the row-major flattening (helper.h:702-851 restated)
-        d = n * n
-        Us, Ut = np.zeros((d, d)), np.zeros((d, d))
-        for i in range(n):
-            for j in range(n):
-                Us[n * i + j, n * i + (i + j) % n] = 1
-                Ut[n * i + j, n * ((i + j) % n) + j] = 1
-        V, W = [], []
-        for k in range(1, n):
-            Vk, Wk = np.zeros((d, d)), np.zeros((d, d))
-            for i in range(n):
-                for j in range(n):
-                    Vk[n * i + j, n * i + (j + k) % n] = 1
-                    Wk[n * i + j, n * ((i + k) % n) + j] = 1
-            V.append(Vk)
-            W.append(Wk)
-        return Us, Ut, V, W
+    u_matrices = lambda: alg.matmul_permutation_matrices(n)  # helper.h:702-851
 
     def run(e):
         scale = 2.0 ** 40
@@ -172,6 +155,49 @@ def test_cpp_shim_selftest():
     import subprocess
     r = subprocess.run([_driver("shim_selftest")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "SELFTEST PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sparse_matrix_product_bit_exact_and_at_config5_size():
+    """cc_matrix_multiplication_sparse (the zero diagonals skipped): the same composition on the
+    oracle twin gives the same bits at n = 4 (config 3's ring); and BASELINE config 5 -- a 64 x 64 product at
+    N = 32768 {60,40,40,40,40,60}, 4096 of the 16384 slots, 380 rotations instead of 524 288 -- decrypts to A.B."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from seal_fyp_logistic_regression_amd import seal as S
+    n = 4
+    rng = np.random.default_rng(4)
+    A, B = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+
+    def run(e):
+        scale = 2.0 ** 40
+        sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+        enc = lambda dd: {l: e["encoder"].encode(v, scale) for l, v in dd.items()}
+        ctA = e["enc"].encrypt(e["encoder"].encode(A.reshape(-1), scale))
+        ctB = e["enc"].encrypt(e["encoder"].encode(B.reshape(-1), scale))
+        return alg.cc_matrix_multiplication_sparse(e["ev"], ctA, ctB, n, enc(sig), enc(tau), [enc(x) for x in phi],
+                                                   [enc(x) for x in psi], e["gk"])
+
+    r = both(16384, [60, 40, 40, 40, 40, 60], run)
+    (eg, cg), (eo, co) = r["gpu"], r["oracle"]
+    assert cg.size() == 3 and (bits(eg, cg) == bits(eo, co)).all()
+    assert np.allclose(decode(eg, cg, n * n).reshape(n, n), A @ B, atol=1e-4)
+    # config 5 at full size, GPU only
+    n, N = 64, 32768
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(S.CoeffModulus.Create(N, [60, 40, 40, 40, 40, 60]))
+    ctx = S.SEALContext.Create(parms)
+    kg = S.KeyGenerator(ctx, 31)
+    enc_, dec_ = S.Encryptor(ctx, kg.public_key(), 32), S.Decryptor(ctx, kg.secret_key())
+    encoder, ev, gk = S.CKKSEncoder(ctx), S.Evaluator(ctx), kg.galois_keys()
+    A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+    scale = 2.0 ** 40
+    sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+    enc = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale)))
+    ctA, ctB = enc_.encrypt(encoder.encode(A.reshape(-1), scale)), enc_.encrypt(encoder.encode(B.reshape(-1), scale))
+    res = alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, enc(sig), enc(tau), [enc(x) for x in phi],
+                                              [enc(x) for x in psi], gk)
+    got = encoder.decode(dec_.decrypt(res))[:n * n].real.reshape(n, n)
+    assert np.abs(got - A @ B).max() < 1e-3, np.abs(got - A @ B).max()  # entries of A.B are O(5); CKKS at 2^40
 
 
 def test_reference_matrix_multiplication_driver_unchanged():

@@ -164,6 +164,40 @@ def test_multiply_plain_sum_bit_exact(c2):
         e.multiply_plain_sum(L, 2, [dct[0]], [dpt[0]], outs=[dct[0]])  # output aliases an input
 
 
+def test_pooled_allocator_recycles_without_overlap(c2):
+    """hefx_malloc / hefx_free (include/hefx.h): freed blocks come back for the same size, blocks carved from one slab
+    never overlap, data written through one block is not disturbed by its neighbours, and HEFX_POOL_MB=0 (plain
+    hipMalloc / hipFree) gives the same results."""
+    import os, subprocess, sys
+    o, e, _ = c2
+    L, N = 3, o.N
+    a = e.empty(2, L, N)
+    p = a.ptr
+    del a
+    b = e.empty(2, L, N)
+    assert b.ptr == p  # recycled, no hipFree / hipMalloc round trip
+    bufs = [e.empty(2, L, N) for _ in range(300)]  # several slabs of this size class
+    ptrs = sorted(x.ptr for x in bufs + [b])
+    assert all(q - r >= 2 * L * N * 8 for r, q in zip(ptrs, ptrs[1:]))
+    cts = [o.uniform(L, 2, 8000 + i) for i in range(8)]
+    dev = [e.to_device(c) for c in cts]
+    del bufs, b
+    tmp = [e.add(L, 2, dev[i], dev[(i + 1) % 8]) for i in range(8)]  # results land in recycled blocks
+    for i in range(8):
+        assert (dev[i].download() == cts[i]).all()
+        assert (tmp[i].download() == o.add(cts[i], cts[(i + 1) % 8])).all()
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from oracle import oracle as O\nfrom seal_fyp_logistic_regression_amd import Engine\n"
+            "primes=%r; o=O.Oracle(8192, primes); e=Engine(8192, primes)\n"
+            "a,b=o.uniform(3,2,1),o.uniform(3,2,2)\n"
+            "for _ in range(50): r=e.add(3,2,e.to_device(a),e.to_device(b))\n"
+            "print('PARITY', bool((r.download()==o.add(a,b)).all()))\n") % (
+                os.path.dirname(os.path.dirname(os.path.abspath(__file__))), o.primes)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_POOL_MB": "0"}, capture_output=True,
+                       text=True, timeout=600)
+    assert "PARITY True" in r.stdout, (r.stdout[-300:], r.stderr[-1500:])
+
+
 def _rand_key(o, seed):
     return o.uniform(o.k, 2 * (o.k - 1), seed).reshape(o.k - 1, 2, o.k, o.N)
 

@@ -284,3 +284,35 @@ def test_bsgs_linear_transform_decrypts_to_the_matrix_product(env, d, n1):
         assert np.abs(dec(e, r, d).real - M @ w).max() < 1e-2
     with pytest.raises(ValueError, match="direct Galois key"):
         alg.linear_transform_plain_bsgs(ev, cw, sd, e["gk"], n1)  # power-of-two keys only: step 3 (or 6) is missing
+
+
+def test_sparse_matrix_product_matches_the_dense_one_up_to_the_epsilons():
+    """cc_matrix_multiplication_sparse (non-zero diagonals only, 3n + 3(n-1) - 1 rotations) against the reference's
+    form with 1e-8 on every entry of all n^2 diagonals (matrix_multiplication.cpp:239-297): A.B to CKKS precision, and
+    the diagonal index maps equal the dense matrices' non-zero diagonals."""
+    n = 3
+    for m in (2, 3, 5):
+        Us, Ut, V, W = alg.matmul_permutation_matrices(m)
+        s_, t_, p_, q_ = alg.matmul_permutation_diagonals(m)
+        for dense, sparse in [(Us, s_), (Ut, t_)] + list(zip(V, p_)) + list(zip(W, q_)):
+            want = alg.nonzero_diagonals(dense)
+            assert list(want) == list(sparse) and all((want[l] == sparse[l]).all() for l in want)
+        assert (len(s_), len(t_), len(p_[0]), len(q_[0])) == (2 * m - 1, m, 2, 1)
+    e = make(4096, [60, 40, 40, 40, 40, 60])  # at 2^30 the all-epsilon diagonals would round to zero polynomials
+    scale = 2.0 ** 40
+    rng = np.random.default_rng(3)
+    A, B = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+    enc = lambda dd: {l: e["encoder"].encode(v, scale) for l, v in dd.items()}
+    ctA = e["enc"].encrypt(e["encoder"].encode(A.reshape(-1), scale))
+    ctB = e["enc"].encrypt(e["encoder"].encode(B.reshape(-1), scale))
+    r = alg.cc_matrix_multiplication_sparse(e["ev"], ctA, ctB, n, enc(sig), enc(tau), [enc(x) for x in phi],
+                                            [enc(x) for x in psi], e["gk"])
+    Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+    dense = lambda U: [e["encoder"].encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)]
+    ref = alg.cc_matrix_multiplication(e["ev"], ctA, ctB, n, dense(Us), dense(Ut), [dense(v) for v in V],
+                                       [dense(w) for w in W], e["gk"])
+    assert (r.size(), r.parms_id(), r.scale) == (ref.size(), ref.parms_id(), ref.scale)
+    got = dec(e, r, n * n).real.reshape(n, n)
+    assert np.abs(got - A @ B).max() < 1e-2
+    assert np.abs(got - dec(e, ref, n * n).real.reshape(n, n)).max() < 1e-2
