@@ -116,6 +116,11 @@ int hefx_multiply_plain_sum(hefx_context *ctx, int L, int size, int n, int group
 int hefx_multiply(hefx_context *ctx, int L, const uint64_t *d_a, const uint64_t *d_b, uint64_t *d_out3,
                   void *stream);
 int hefx_square(hefx_context *ctx, int L, const uint64_t *d_a, uint64_t *d_out3, void *stream);
+/* n independent size 2 x size 2 products in one launch: d_out3[i] = d_a[i] * d_b[i] (the loop of cipher_dot_product
+ * over the rows of a data set, logistic_regression_ckks.cpp:217-220 -> helper.h:432).  Host arrays of device
+ * pointers; d_b may repeat one ciphertext; outputs must not alias inputs. */
+int hefx_multiply_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_a, const uint64_t *const *d_b,
+                        uint64_t *const *d_out3, void *stream);
 
 /* ---- K5/K6/K7: Evaluator::apply_galois_inplace = Galois permutation + key switch (one term of
  *      rotate_vector; helper.h:216,227,244,255,316,352,455,474; 5_rotation.cpp:215).

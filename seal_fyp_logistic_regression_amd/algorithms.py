@@ -535,17 +535,9 @@ def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequenc
     batched key-switch launch over all rows.  Same calls in the same order per row -> same bits as the loop at
     logistic_regression_ckks.cpp:217-220."""
     be, n = ev.be, len(As)
-    mults = [ev.multiply(a, b) for a, b in zip(As, Bs)]
-    L = mults[0].parms_id()
-    if hasattr(be, "engine"):
-        outs = be.engine.relinearize_batch(L, [m.data for m in mults], relin_keys.key(0))
-        for m, o in zip(mults, outs):
-            m._set(o, 2, L, m.scale)
-    else:
-        for m in mults:
-            ev.relinearize_inplace(m, relin_keys)
-    for m in mults:
-        ev.rescale_to_next_inplace(m)
+    mults = ev.multiply_many(As, Bs)                                 # :432
+    ev.relinearize_many_inplace(mults, relin_keys)                   # :440
+    ev.rescale_to_next_many_inplace(mults)                           # :441
     L = mults[0].parms_id()
 
     def rotate_all(cts, step):
@@ -555,13 +547,12 @@ def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequenc
             data = be.apply_galois_batch(L, data, [elt] * n, [gal_keys.key(elt)] * n)
         return [Ciphertext()._set(d, 2, L, c.scale) for d, c in zip(data, cts)]
 
-    dups = [ev.add(m, z) for m, z in zip(mults, rotate_all(mults, -size))]
-    for _ in range(1, size):
+    dups = ev.add_pairs(mults, rotate_all(mults, -size))             # :455, :464
+    for _ in range(1, size):                                         # :472-476
         dups = rotate_all(dups, 1)
-        for m, d in zip(mults, dups):
-            ev.add_inplace(m, d)
+        mults = ev.add_pairs(mults, dups)
     for m in mults:
-        m.scale = 2.0 ** int(np.log2(m.scale))
+        m.scale = 2.0 ** int(np.log2(m.scale))                       # :489 "manual rescale"
     return mults
 
 
@@ -578,12 +569,11 @@ def predict_cipher_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, featu
     results = cipher_dot_product_many(ev, features, [weights] * num_rows, num_weights, relin_keys, gal_keys)  # :220
     # the reference encodes one one-hot mask per row inside the loop (:222-225, 2000 CPU FFTs per iteration); here all
     # masks go through one batched encode (one GPU launch on the HIP engine) -- same plaintexts, same order of use
-    masks = encoder.encode_many(list(np.eye(num_rows)), scale)
-    for i in range(num_rows):
-        mask_pt = masks[i]
-        ev.mod_switch_to_next_inplace(mask_pt)                                                             # :227
-        ev.multiply_plain_inplace(results[i], mask_pt)                                                     # :229
-    lin = ev.add_many(results)                                                                             # :233
+    # masks go through one batched encode (one GPU launch on the HIP engine) -- same plaintexts, same order of use.
+    # Encoding at the level below the top IS encode + mod_switch_to_next (:227): CKKS drops RNS rows, no arithmetic.
+    top = ev.ctx.first_parms_id()
+    masks = encoder.encode_many(list(np.eye(num_rows)), scale, parms_id=top - 1)                           # :222-227
+    lin = ev.multiply_plain_sum(results, masks)[0]                                                         # :229, :233
     ev.relinearize_inplace(lin, relin_keys)                                                                # :237 (no-op)
     ev.rescale_to_next_inplace(lin)                                                                        # :239
     lin.scale = 2.0 ** int(np.log2(lin.scale))                                                             # :242
@@ -608,12 +598,8 @@ def update_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, features: Seq
     for f in fT:
         ev.mod_switch_to_inplace(f, pred_labels.parms_id())                                                # :298
     grads = cipher_dot_product_many(ev, fT, [pred_labels] * num_weights, num_obs, relin_keys, gal_keys)    # :299
-    masks = encoder.encode_many(list(np.eye(num_weights)), scale)                                          # :302-305, batched
-    for i in range(num_weights):
-        mask_pt = masks[i]
-        ev.mod_switch_to_inplace(mask_pt, grads[i].parms_id())                                             # :308
-        ev.multiply_plain_inplace(grads[i], mask_pt)                                                       # :310
-    gradient = ev.add_many(grads)                                                                          # :316
+    masks = encoder.encode_many(list(np.eye(num_weights)), scale, parms_id=grads[0].parms_id())           # :302-308
+    gradient = ev.multiply_plain_sum(grads, masks)[0]                                                      # :310, :316
     ev.relinearize_inplace(gradient, relin_keys)                                                           # :319
     ev.rescale_to_next_inplace(gradient)                                                                   # :321
     gradient.scale = 2.0 ** int(np.log2(gradient.scale))                                                   # :324

@@ -59,6 +59,7 @@ _SIGS = {
     "hefx_multiply_plain_sum": (_i, [_vp, _i, _i, _i, _i, _pp, _pp, _pp, _vp]),
     "hefx_multiply": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "hefx_square": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "hefx_multiply_batch": (_i, [_vp, _i, _i, _pp, _pp, _pp, _vp]),
     "hefx_apply_galois": (_i, [_vp, _i, _vp, _u32, _vp, _vp, _vp]),
     "hefx_apply_galois_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _vp]),
     "hefx_rotate_multiply_plain_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _vp]),

@@ -729,7 +729,19 @@ extern "C" int hefx_multiply_plain_sum(hefx_context *c, int L, int size, int n, 
     }
     // the pointer table travels through a ring slot of the key-switch descriptors; whole groups per slice
     constexpr int TABLE_MAX = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *));
-    if (2 * group + 1 > TABLE_MAX) return fail(HEFX_ERR_INVALID, "multiply_plain_sum group too large");
+    if (2 * group + 1 > TABLE_MAX) {  // a group longer than one table slice: partial sums in scratch, then add_many
+        const int part = (TABLE_MAX - 1) / 2;
+        const size_t words = (size_t)size * L * c->n;
+        for (int g = 0; g < groups; ++g) {
+            const int i0 = g * group, len = (n - i0 < group) ? n - i0 : group, nparts = (len + part - 1) / part;
+            if (int rc = ensure_scratch(c, words * nparts)) return rc;
+            std::vector<uint64_t *> pp(nparts);
+            for (int t = 0; t < nparts; ++t) pp[t] = reinterpret_cast<uint64_t *>(c->scratch + (size_t)t * words);
+            if (int rc = hefx_multiply_plain_sum(c, L, size, len, part, cts + i0, pts + i0, pp.data(), stream)) return rc;
+            if (int rc = hefx_add_many(c, L, size, nparts, pp.data(), outs[g], stream)) return rc;
+        }
+        return HEFX_OK;
+    }
     const int gps = TABLE_MAX / (2 * group + 1);  // groups per slice
     hipStream_t s = (hipStream_t)stream;
     for (int g0 = 0; g0 < groups; g0 += gps) {
@@ -759,6 +771,35 @@ extern "C" int hefx_multiply(hefx_context *c, int L, const uint64_t *a, const ui
     if (int rc = check_level(c, L)) return rc;
     if (!a || !b || !out3) return fail(HEFX_ERR_INVALID, "null operand");
     HIPCHK(launch_multiply(c->T, L, (const u64 *)a, (const u64 *)b, (u64 *)out3, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_multiply_batch(hefx_context *c, int L, int n, const uint64_t *const *a, const uint64_t *const *b,
+                                   uint64_t *const *out3, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (n < 1 || !a || !b || !out3) return fail(HEFX_ERR_INVALID, "bad multiply batch arguments");
+    for (int i = 0; i < n; ++i)
+        if (!a[i] || !b[i] || !out3[i] || out3[i] == a[i] || out3[i] == b[i])
+            return fail(HEFX_ERR_INVALID, "null or aliasing operand in multiply batch");
+    constexpr int SLICE = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *)) / 3;  // pointer-table ring slot
+    hipStream_t s = (hipStream_t)stream;
+    for (int i0 = 0; i0 < n; i0 += SLICE) {
+        const int cnt = n - i0 < SLICE ? n - i0 : SLICE;
+        const unsigned slot = c->ring_next++ % KS_RING;
+        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));
+        const uint64_t **hp = reinterpret_cast<const uint64_t **>(c->h_items + (size_t)slot * KS_MAX_CHUNK);
+        const u64 *const *dp = reinterpret_cast<const u64 *const *>(c->d_items + (size_t)slot * KS_MAX_CHUNK);
+        for (int i = 0; i < cnt; ++i) {
+            hp[i] = a[i0 + i];
+            hp[cnt + i] = b[i0 + i];
+            hp[2 * cnt + i] = out3[i0 + i];
+        }
+        HIPCHK(hipMemcpyAsync((void *)dp, hp, sizeof(void *) * 3 * (size_t)cnt, hipMemcpyHostToDevice, s));
+        HIPCHK(launch_multiply_table(c->T, L, dp, cnt, s));
+        HIPCHK(hipEventRecord(c->ring_ev[slot], s));
+        c->ring_busy[slot] = true;
+    }
     return HEFX_OK;
 }
 extern "C" int hefx_square(hefx_context *c, int L, const uint64_t *a, uint64_t *out3, void *stream)

@@ -79,6 +79,8 @@ hipError_t launch_add_many_table(const DevTables &T, int L, int size, const u64 
 // table: n ciphertext pointers | n plaintext pointers | ceil(n/group) output pointers (device memory)
 hipError_t launch_mulplain_sum(const DevTables &T, int L, int size, const u64 *const *d_tab, int n, int group,
                                hipStream_t s);
+// table: n a-pointers | n b-pointers | n output pointers (device memory)
+hipError_t launch_multiply_table(const DevTables &T, int L, const u64 *const *d_tab, int n, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
 // profiling: an event is recorded before every launch (tagged with its stage) and one after the last
 constexpr int KS_STAGES = 7;

@@ -330,6 +330,49 @@ hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b
     return hipGetLastError();
 }
 
+// n independent size-2 x size-2 products through a DEVICE pointer table  a[0..n) | b[0..n) | out[0..n)  (the rows of
+// an encrypted data set times one weight ciphertext, logistic_regression_ckks.cpp:217-220 -> helper.h:432): one
+// launch instead of n.  Same arithmetic as multiply_kernel.
+__global__ __launch_bounds__(256) void multiply_table_kernel(DevTables T, int L, size_t pairs_per_poly,
+                                                             const u64 *const *__restrict__ tab, int n)
+{
+    const int logn = T.logn;
+    const int item = blockIdx.y;
+    const ulonglong2 *__restrict__ a = reinterpret_cast<const ulonglong2 *>(tab[item]);
+    const ulonglong2 *__restrict__ b = reinterpret_cast<const ulonglong2 *>(tab[n + item]);
+    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + item]));
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < pairs_per_poly;
+         w += (size_t)gridDim.x * blockDim.x) {
+        const ModConst mc = T.mods[(int)(w >> (logn - 1))];
+        const ulonglong2 a0 = a[w], a1 = a[w + pairs_per_poly], b0 = b[w], b1 = b[w + pairs_per_poly];
+        ulonglong2 c0, c1, c2;
+        c0.x = mulmod(a0.x, b0.x, mc);
+        c0.y = mulmod(a0.y, b0.y, mc);
+        c2.x = mulmod(a1.x, b1.x, mc);
+        c2.y = mulmod(a1.y, b1.y, mc);
+        u64 lo = 0, hi = 0;
+        mac128(lo, hi, a0.x, b1.x);
+        mac128(lo, hi, a1.x, b0.x);
+        c1.x = barrett128(lo, hi, mc);
+        lo = hi = 0;
+        mac128(lo, hi, a0.y, b1.y);
+        mac128(lo, hi, a1.y, b0.y);
+        c1.y = barrett128(lo, hi, mc);
+        out[w] = c0;
+        out[w + pairs_per_poly] = c1;
+        out[w + 2 * pairs_per_poly] = c2;
+    }
+}
+
+hipError_t launch_multiply_table(const DevTables &T, int L, const u64 *const *d_tab, int n, hipStream_t s)
+{
+    const size_t pairs = (size_t)L * ((size_t)1 << T.logn) / 2;
+    int blocks = (int)((pairs + 255) / 256);
+    if (blocks > 64) blocks = 64;  // n items in grid.y fill the chip
+    hipLaunchKernelGGL(multiply_table_kernel, dim3(blocks, n), dim3(256), 0, s, T, L, pairs, d_tab, n);
+    return hipGetLastError();
+}
+
 
 // HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
 // that once, up front, instead of the first encode / rotation / encryption of a program.

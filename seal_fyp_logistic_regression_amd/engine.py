@@ -194,6 +194,43 @@ class Engine:
         capi.check(capi.lib().hefx_multiply(self._h, L, a.ptr, b.ptr, out.ptr, stream))
         return out
 
+    def multiply_batch(self, L, As, Bs, outs=None, stream=None):
+        """outs[i] = As[i] * Bs[i] (size 2 x 2 -> 3), one launch (hefx_multiply_batch)"""
+        n = len(As)
+        outs = outs if outs is not None else self.empty_many(n, (3, L, self.N))
+        capi.check(capi.lib().hefx_multiply_batch(self._h, L, n, capi.ptr_array([a.ptr for a in As]),
+                                                  capi.ptr_array([b.ptr for b in Bs]),
+                                                  capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
+    @staticmethod
+    def contiguous(arrs) -> bool:
+        """equally sized buffers laid out back to back (views of one slab, in order)"""
+        base, step = arrs[0].ptr, arrs[0].nbytes
+        return all(a.nbytes == step and a.ptr == base + i * step for i, a in enumerate(arrs))
+
+    def add_batch(self, L, size, As, Bs, stream=None):
+        """[As[i] + Bs[i]]: one launch when both lists are slabs (count = n), else one call per pair"""
+        n = len(As)
+        outs = self.empty_many(n, (size, L, self.N))
+        if n > 1 and self.contiguous(As) and self.contiguous(Bs):
+            capi.check(capi.lib().hefx_add(self._h, L, size, n, As[0].ptr, Bs[0].ptr, outs[0].ptr, stream))
+        else:
+            for a, b, o in zip(As, Bs, outs):
+                capi.check(capi.lib().hefx_add(self._h, L, size, 1, a.ptr, b.ptr, o.ptr, stream))
+        return outs
+
+    def rescale_batch(self, L, size, cts, stream=None):
+        """[rescale_to_next(ct)]: one launch when the inputs are a slab"""
+        n = len(cts)
+        outs = self.empty_many(n, (size, L - 1, self.N))
+        if n > 1 and self.contiguous(cts):
+            capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, n, cts[0].ptr, outs[0].ptr, stream))
+        else:
+            for c, o in zip(cts, outs):
+                capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, 1, c.ptr, o.ptr, stream))
+        return outs
+
     def square(self, L, a, out=None, stream=None):
         out = out if out is not None else DeviceArray(self, (3, L, self.N))
         capi.check(capi.lib().hefx_square(self._h, L, a.ptr, out.ptr, stream))

@@ -141,6 +141,18 @@ class GpuBackend:
     def multiply_plain_sum(self, L, size, cts, pts, group=None):
         return self.engine.multiply_plain_sum(L, size, cts, pts, group)
 
+    def multiply_batch(self, L, As, Bs):
+        return self.engine.multiply_batch(L, As, Bs)
+
+    def add_batch(self, L, size, As, Bs):
+        return self.engine.add_batch(L, size, As, Bs)
+
+    def rescale_batch(self, L, size, cts):
+        return self.engine.rescale_batch(L, size, cts)
+
+    def relinearize_batch(self, L, ct3s, key):
+        return self.engine.relinearize_batch(L, ct3s, key)
+
     def multiply(self, L, a, b):
         return self.engine.multiply(L, a, b)
 
@@ -719,6 +731,59 @@ class Evaluator:
 
     def multiply_plain_inplace(self, a, p):
         return self.multiply_plain(a, p, a)
+
+    # ---- the same operation over many independent ciphertexts (the rows of a data set): one engine launch per
+    # list where the backend offers it, otherwise the per-item calls -- identical checks and bits either way
+    def _uniform(self, cts):
+        L, size, scale = cts[0].parms_id(), cts[0].size(), cts[0].scale
+        return all(c._parms_id == L and c._size == size and c._scale == scale for c in cts)
+
+    def multiply_many(self, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext]) -> List[Ciphertext]:
+        f = getattr(self.be, "multiply_batch", None)
+        if f is None or not (self._uniform(As) and self._uniform(Bs)) or any(a.data is b.data for a, b in zip(As, Bs)):
+            return [self.multiply(a, b) for a, b in zip(As, Bs)]
+        a, b = As[0], Bs[0]
+        self._check_same(a, b)
+        if a.size() != 2 or b.size() != 2:
+            raise ValueError("multiply: only size-2 operands are supported (all reference call sites)")
+        s = a.scale * b.scale
+        self._check_scale(s, a.parms_id())
+        outs = f(a.parms_id(), [x.data for x in As], [x.data for x in Bs])
+        return [Ciphertext()._set(o, 3, a.parms_id(), s) for o in outs]
+
+    def relinearize_many_inplace(self, cts: Sequence[Ciphertext], relin_keys: KSwitchKeys):
+        f = getattr(self.be, "relinearize_batch", None)
+        if f is None or not self._uniform(cts) or cts[0].size() != 3:
+            for c in cts:
+                self.relinearize_inplace(c, relin_keys)
+            return cts
+        L = cts[0].parms_id()
+        for c, o in zip(cts, f(L, [c.data for c in cts], relin_keys.key(0))):
+            c._set(o, 2, L, c.scale)
+        return cts
+
+    def rescale_to_next_many_inplace(self, cts: Sequence[Ciphertext]):
+        f = getattr(self.be, "rescale_batch", None)
+        if f is None or not self._uniform(cts) or cts[0].parms_id() < 2:
+            for c in cts:
+                self.rescale_to_next_inplace(c)
+            return cts
+        L, size = cts[0].parms_id(), cts[0].size()
+        new_scale = cts[0].scale / float(self.ctx.primes[L - 1])
+        for c, o in zip(cts, f(L, size, [c.data for c in cts])):
+            c._set(o, size, L - 1, new_scale)
+        return cts
+
+    def add_pairs(self, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext]) -> List[Ciphertext]:
+        f = getattr(self.be, "add_batch", None)
+        if f is None or not (self._uniform(As) and self._uniform(Bs)) or As[0].size() != Bs[0].size():
+            return [self.add(a, b) for a, b in zip(As, Bs)]
+        a, b = As[0], Bs[0]
+        self._check_same(a, b)
+        if not self._close(a.scale, b.scale):
+            raise ValueError("scale mismatch")
+        outs = f(a.parms_id(), a.size(), [x.data for x in As], [x.data for x in Bs])
+        return [Ciphertext()._set(o, a.size(), a.parms_id(), a.scale) for o in outs]
 
     def multiply_plain_sum(self, cts: Sequence[Ciphertext], pts: Sequence[Plaintext], group: Optional[int] = None):
         """add_many(multiply_plain(cts[i], pts[i])) per group of `group` consecutive terms (None: one group), in one

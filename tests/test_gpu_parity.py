@@ -149,7 +149,7 @@ def test_multiply_plain_sum_bit_exact(c2):
             acc = t if acc is None else o.add(acc, t)
         return acc
 
-    for n, group in ((5, None), (23, 4), (300, 300), (700, 3)):
+    for n, group in ((5, None), (23, 4), (300, 300), (700, 3), (1500, 1400)):  # last: groups beyond one table slice
         idx = [(i % 9, (3 * i + 1) % 7) for i in range(n)]
         g = n if group is None else group
         outs = e.multiply_plain_sum(L, 2, [dct[a] for a, _ in idx], [dpt[b] for _, b in idx], group)
