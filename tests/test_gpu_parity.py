@@ -164,6 +164,36 @@ def test_multiply_plain_sum_bit_exact(c2):
         e.multiply_plain_sum(L, 2, [dct[0]], [dpt[0]], outs=[dct[0]])  # output aliases an input
 
 
+def test_row_batched_ops_bit_exact(c2):
+    """hefx_multiply_batch and the count-batched add / rescale behind Evaluator.multiply_many / add_pairs /
+    rescale_to_next_many_inplace: n independent ciphertexts per launch, same bits as one call each -- with one shared
+    right operand (the weight ciphertext of logistic_regression_ckks.cpp:217-220), across pointer-table slices, and
+    for inputs that are NOT views of one slab (per-item fallback)."""
+    o, e, _ = c2
+    L, n = 3, 450
+    cts = [o.uniform(L, 2, 9000 + i) for i in range(7)]
+    dev = [e.to_device(c) for c in cts]
+    As = [dev[i % 7] for i in range(n)]
+    outs = e.multiply_batch(L, As, [dev[3]] * n)
+    for i in (0, 1, 6, 425, 426, n - 1):
+        assert (outs[i].download() == o.multiply(cts[i % 7], cts[3])).all(), i
+    assert e.contiguous(outs) and not e.contiguous(As)
+    r2 = e.relinearize_batch(L, outs[:9], e.to_device(_rand_key(o, 5)))
+    rs = e.rescale_batch(L, 2, r2)          # slab in, one launch
+    key = _rand_key(o, 5)
+    for i in (0, 8):
+        want = o.rescale(o.relinearize(o.multiply(cts[i % 7], cts[3]), key))
+        assert (rs[i].download() == want).all()
+    sums = e.add_batch(L, 2, r2, r2[::-1])  # second list is not in slab order -> per-item path
+    sums2 = e.add_batch(L, 2, r2, r2)       # both slabs -> one launch
+    a = [x.download() for x in r2]
+    for i in (0, 4, 8):
+        assert (sums[i].download() == o.add(a[i], a[8 - i])).all()
+        assert (sums2[i].download() == o.add(a[i], a[i])).all()
+    with pytest.raises(ValueError):
+        e.multiply_batch(L, [dev[0]], [dev[1]], outs=[dev[0]])
+
+
 def test_pooled_allocator_recycles_without_overlap(c2):
     """hefx_malloc / hefx_free (include/hefx.h): freed blocks come back for the same size, blocks carved from one slab
     never overlap, data written through one block is not disturbed by its neighbours, and HEFX_POOL_MB=0 (plain
