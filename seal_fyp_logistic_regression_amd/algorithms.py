@@ -356,6 +356,25 @@ def compute_all_powers(ev: Evaluator, ct: Ciphertext, degree: int, relin_keys: K
     return powers
 
 
+def _linear_transforms_of_one_input(ev: Evaluator, ct: Ciphertext, diag_sets: Sequence[Sequence[Plaintext]],
+                                    gal_keys: KSwitchKeys) -> List[Ciphertext]:
+    """[Linear_Transform_Plain(ct, diags, gal_keys) for diags in diag_sets] (matrix_multiplication.cpp:40-43: the n-1
+    transforms V_k of ctA0, W_k of ctB0).  Every one of them starts by forming the same ct_new = ct + rotate(ct, -d)
+    and the same rotations rotate(ct_new, l) -- deterministic functions of ct -- so they are formed ONCE and each
+    transform keeps only its sum of plaintext products (helper.h:250-259) -- the bits of the transform-by-transform
+    loop with (n-1)x fewer key switches."""
+    if not diag_sets:
+        return []
+    d = len(diag_sets[0])
+    if any(len(ds) != d for ds in diag_sets):
+        return [linear_transform_plain(ev, ct, ds, gal_keys) for ds in diag_sets]
+    ct_new = _duplicate(ev, ct, d, gal_keys)                          # helper.h:244-247
+    rots = [ct_new] + _rotations_batched(ev, ct_new, list(range(1, d)), gal_keys)   # :255
+    terms_ct = [rots[l] for _ in diag_sets for l in range(d)]
+    terms_pt = [ds[l] for ds in diag_sets for l in range(d)]
+    return ev.multiply_plain_sum(terms_ct, terms_pt, group=d)        # :250, :256, :259
+
+
 def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int,
                              U_sigma: Sequence[Plaintext], U_tau: Sequence[Plaintext],
                              V_diagonals: Sequence[Sequence[Plaintext]], W_diagonals: Sequence[Sequence[Plaintext]],
@@ -363,8 +382,8 @@ def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, di
     """CC_Matrix_Multiplication, /root/reference/matrix_multiplication.cpp:11-132 (Jiang et al. 2018/1041)."""
     ctA0 = linear_transform_plain(ev, ctA, U_sigma, gal_keys)        # :22
     ctB0 = linear_transform_plain(ev, ctB, U_tau, gal_keys)          # :25
-    ctAk = [linear_transform_plain(ev, ctA0, V_diagonals[k], gal_keys) for k in range(dimension - 1)]   # :42
-    ctBk = [linear_transform_plain(ev, ctB0, W_diagonals[k], gal_keys) for k in range(dimension - 1)]   # :43
+    ctAk = _linear_transforms_of_one_input(ev, ctA0, V_diagonals, gal_keys)   # :42
+    ctBk = _linear_transforms_of_one_input(ev, ctB0, W_diagonals, gal_keys)   # :43
     for c in ctAk + ctBk:
         ev.rescale_to_next_inplace(c)                                # :69-73
     ctAB = ev.multiply(ctA0, ctB0)                                   # :104

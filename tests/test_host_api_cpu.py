@@ -316,3 +316,22 @@ def test_sparse_matrix_product_matches_the_dense_one_up_to_the_epsilons():
     got = dec(e, r, n * n).real.reshape(n, n)
     assert np.abs(got - A @ B).max() < 1e-2
     assert np.abs(got - dec(e, ref, n * n).real.reshape(n, n)).max() < 1e-2
+
+
+def test_shared_rotations_in_the_matrix_product_keep_the_bits_of_the_per_transform_loop():
+    """cc_matrix_multiplication forms the rotations of ctA0 / ctB0 once for all n-1 Step-2 transforms; the literal
+    loop of matrix_multiplication.cpp:40-43 (one Linear_Transform_Plain per k) must give the same ciphertext bits."""
+    n = 3
+    e = make(4096, [60, 40, 40, 40, 40, 60])
+    scale = 2.0 ** 40
+    rng = np.random.default_rng(8)
+    A = rng.standard_normal((n, n))
+    Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+    dense = lambda U: [e["encoder"].encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)]
+    ct = e["enc"].encrypt(e["encoder"].encode(A.reshape(-1), scale))
+    ct0 = alg.linear_transform_plain(e["ev"], ct, dense(Us), e["gk"])
+    Vd = [dense(v) for v in V]
+    shared = alg._linear_transforms_of_one_input(e["ev"], ct0, Vd, e["gk"])
+    literal = [alg.linear_transform_plain(e["ev"], ct0, vd, e["gk"]) for vd in Vd]
+    for a, b in zip(shared, literal):
+        assert a.parms_id() == b.parms_id() and a.scale == b.scale and (a.data == b.data).all()
