@@ -2,8 +2,9 @@
 encoded / encrypted, keys generated beforehand), median of 5 calls incl. the host side:
   dense   the reference's form: all n^2 diagonals of every permutation matrix, 1e-8 added to each entry (:239-297),
           default power-of-two Galois keys (bit-exact to the op-by-op sequence)
-  sparse  algorithms.cc_matrix_multiplication_sparse: the non-zero diagonals only (fast mode)
-usage: matmul_bench.py [C3|C5] n [dense|sparse ...]"""
+  sparse  algorithms.cc_matrix_multiplication_sparse: the non-zero diagonals only (fast mode), the reference's keys
+  sparse_direct  the same with a direct Galois key for every step it uses (one key switch per rotation)
+usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct ...]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -30,11 +31,15 @@ for mode in modes:
         args = (e_(Us), e_(Ut), [e_(v) for v in V], [e_(w) for w in W])
         run = lambda: alg.cc_matrix_multiplication(ev, ctA, ctB, n, *args, gk)
         rotations = 2 * n * n * n
-    else:
+    else:  # "sparse": the reference's power-of-two keys (NAF chains); "sparse_direct": a direct key per step used
         sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
         e_ = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale)))
         args = (e_(sig), e_(tau), [e_(x) for x in phi], [e_(x) for x in psi])
-        run = lambda: alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, gk)
+        keys = gk
+        if mode == "sparse_direct":
+            steps = sorted({-n * n} | {l for dd in [sig, tau] + phi + psi for l in dd if l})
+            keys = kg.galois_keys(steps)
+        run = lambda keys=keys: alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, keys)
         rotations = len(sig) + len(tau) + sum(len(x) for x in phi) + sum(len(x) for x in psi) + 4
     eng.sync()
     encode_s = time.perf_counter() - t0

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off randomized parity stress (GPU vs CPU oracle), longer than the pytest suite: random parameter sets,
 levels, Galois elements, batch compositions (mixed keys, shared sources, in-place rotations), relinearize,
-rescale, multiply, add_many, sampler streams.  usage: stress_parity.py [seconds]"""
+rescale, multiply, multiply batch, one-pass product sums, sampler streams.  usage: stress_parity.py [seconds]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -55,7 +55,20 @@ while time.time() < t_end:
         assert (r.download() == want).all(), ("relin", N, bits, L)
         if L >= 2:
             assert (e.rescale_to_next(L, 2, r).download() == o.rescale(want)).all(), ("rescale", N, bits, L)
-        checks += 3 * n + 3
+        # row-batched ops and the one-pass product sum (inputs scattered over the pooled allocator)
+        mb = e.multiply_batch(L, dcts, [dcts[0]] * n)
+        back = [dcts[i].download() for i in range(n)]
+        g = int(rng.integers(1, n + 1))
+        ps = e.multiply_plain_sum(L, 2, dcts, [e.to_device(p) for p in pts], g)
+        for i in range(n):
+            assert (mb[i].download() == o.multiply(back[i], back[0])).all(), ("mulbatch", N, bits, L, i)
+        for gi in range(len(ps)):
+            acc = None
+            for i in range(gi * g, min(n, (gi + 1) * g)):
+                t = o.multiply_plain(back[i], pts[i])
+                acc = t if acc is None else o.add(acc, t)
+            assert (ps[gi].download() == acc).all(), ("mulplain_sum", N, bits, L, gi)
+        checks += 4 * n + 3 + len(ps)
     key32 = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
     for kind in ("uniform", "ternary", "noise"):
         sid = int(rng.integers(1 << 40))
