@@ -356,6 +356,22 @@ def compute_all_powers(ev: Evaluator, ct: Ciphertext, degree: int, relin_keys: K
     return powers
 
 
+def _matmul_step3(ev: Evaluator, ctA0: Ciphertext, ctB0: Ciphertext, ctAk: List[Ciphertext],
+                  ctBk: List[Ciphertext]) -> Ciphertext:
+    """matrix_multiplication.cpp:69-129: rescale the 2(n-1) transforms, A0*B0 + sum_k A_k*B_k.  The rescales and the
+    products of the n-1 pairs are independent, so each kind is one launch over its list; the chain of add_inplace
+    (:128) is one n-way sum -- canonical residues of the same integers, hence the same bits."""
+    ev.rescale_to_next_many_inplace(ctAk)                            # :69-73
+    ev.rescale_to_next_many_inplace(ctBk)
+    ctAB = ev.multiply(ctA0, ctB0)                                   # :104
+    ev.mod_switch_to_next_inplace(ctAB)                              # :112
+    for c in ctAk + ctBk:
+        c.scale = 2.0 ** int(np.log2(c.scale))                       # :117-121 "manual rescale"
+    if not ctAk:
+        return ctAB
+    return ev.add_many([ctAB] + ev.multiply_many(ctAk, ctBk))        # :123-129
+
+
 def _linear_transforms_of_one_input(ev: Evaluator, ct: Ciphertext, diag_sets: Sequence[Sequence[Plaintext]],
                                     gal_keys: KSwitchKeys) -> List[Ciphertext]:
     """[Linear_Transform_Plain(ct, diags, gal_keys) for diags in diag_sets] (matrix_multiplication.cpp:40-43: the n-1
@@ -384,15 +400,7 @@ def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, di
     ctB0 = linear_transform_plain(ev, ctB, U_tau, gal_keys)          # :25
     ctAk = _linear_transforms_of_one_input(ev, ctA0, V_diagonals, gal_keys)   # :42
     ctBk = _linear_transforms_of_one_input(ev, ctB0, W_diagonals, gal_keys)   # :43
-    for c in ctAk + ctBk:
-        ev.rescale_to_next_inplace(c)                                # :69-73
-    ctAB = ev.multiply(ctA0, ctB0)                                   # :104
-    ev.mod_switch_to_next_inplace(ctAB)                              # :112
-    for c in ctAk + ctBk:
-        c.scale = 2.0 ** int(np.log2(c.scale))                       # :117-121 "manual rescale"
-    for k in range(dimension - 1):
-        ev.add_inplace(ctAB, ev.multiply(ctAk[k], ctBk[k]))          # :123-129
-    return ctAB
+    return _matmul_step3(ev, ctA0, ctB0, ctAk, ctBk)
 
 
 # ---- the matrix product restricted to the non-zero diagonals ------------------------------------
@@ -490,23 +498,22 @@ def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphert
     for ct0, diags in ((ctA0, V_diagonals), (ctB0, W_diagonals)):        # :42-43
         ct_new = _duplicate(ev, ct0, d, gal_keys)
         terms = [(l, p) for k in range(dimension - 1) for l, p in sorted(diags[k].items())]
-        prods = _sparse_products(ev, ct_new, terms, gal_keys)
-        cts, pos = [], 0
-        for k in range(dimension - 1):
-            cnt = len(diags[k])
-            cts.append(ev.add_many(prods[pos:pos + cnt]))
-            pos += cnt
+        counts = {len(diags[k]) for k in range(dimension - 1)}
+        if len(counts) == 1:  # phi^k: 2 diagonals each, psi^k: 1 -- all sums in one pass, results in one slab
+            steps = sorted({l for l, _ in terms if l})
+            rot = dict(zip(steps, _rotations_batched(ev, ct_new, steps, gal_keys)))
+            rot[0] = ct_new
+            cts = ev.multiply_plain_sum([rot[l] for l, _ in terms], [p for _, p in terms], group=counts.pop())
+        else:
+            prods = _sparse_products(ev, ct_new, terms, gal_keys)
+            cts, pos = [], 0
+            for k in range(dimension - 1):
+                cnt = len(diags[k])
+                cts.append(ev.add_many(prods[pos:pos + cnt]))
+                pos += cnt
         out.append(cts)
     ctAk, ctBk = out
-    for c in ctAk + ctBk:
-        ev.rescale_to_next_inplace(c)                                # :69-73
-    ctAB = ev.multiply(ctA0, ctB0)                                   # :104
-    ev.mod_switch_to_next_inplace(ctAB)                              # :112
-    for c in ctAk + ctBk:
-        c.scale = 2.0 ** int(np.log2(c.scale))                       # :117-121 "manual rescale"
-    for k in range(dimension - 1):
-        ev.add_inplace(ctAB, ev.multiply(ctAk[k], ctBk[k]))          # :123-129
-    return ctAB
+    return _matmul_step3(ev, ctA0, ctB0, ctAk, ctBk)
 
 
 # ---- polynomial evaluation and encrypted logistic regression (logistic_regression_ckks.cpp) -------------------
