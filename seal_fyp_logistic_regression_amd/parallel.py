@@ -118,14 +118,12 @@ def predict_cipher_weights_sharded(ev: Evaluator, encoder, encryptor, features: 
     mine = list(shard(num_rows, rank, world))
     results = alg.cipher_dot_product_many(ev, [features[i] for i in mine], [weights] * len(mine), num_weights,
                                           relin_keys, gal_keys)                     # :220
-    for r, i in zip(results, mine):
-        mask = np.zeros(num_rows)
-        mask[i] = 1
-        mask_pt = encoder.encode(mask, scale)                                       # :222-225
-        ev.mod_switch_to_next_inplace(mask_pt)                                      # :227
-        ev.multiply_plain_inplace(r, mask_pt)                                       # :229
-    if results:
-        partial = ev.add_many(results)                                              # :233 (this rank's share)
+    if results:  # masks of this rank's rows in one batched encode, at the level :227 switches them to; mask-and-sum
+        # in one pass (same plaintexts and the same canonical sum as the serial form, see alg.predict_cipher_weights)
+        eye = np.zeros((len(mine), num_rows))
+        eye[np.arange(len(mine)), mine] = 1
+        masks = encoder.encode_many(list(eye), scale, parms_id=ev.ctx.first_parms_id() - 1)   # :222-227
+        partial = ev.multiply_plain_sum(results, masks)[0]                          # :229, :233 (this rank's share)
     else:  # more ranks than rows: the zero ciphertext at the level / scale a masked dot product has
         one = alg.cipher_dot_product_many(ev, features[:1], [weights], num_weights, relin_keys, gal_keys)[0]
         mask_pt = encoder.encode(np.ones(1), scale)
