@@ -464,13 +464,27 @@ def _duplicate(ev: Evaluator, ct: Ciphertext, d: int, gal_keys: KSwitchKeys) -> 
     return ev.add(ct, ev.rotate_vector(ct, -d, gal_keys))            # helper.h:244-247
 
 
-def _sparse_products(ev: Evaluator, ct_new: Ciphertext, terms, gal_keys: KSwitchKeys) -> List[Ciphertext]:
-    """[diag (.) rot_l(ct_new) for (l, diag) in terms], the rotations as one batch (fused with their products)"""
+def _sparse_products(ev: Evaluator, ct_new: Ciphertext, terms, gal_keys: KSwitchKeys,
+                     hoisted: bool = False) -> List[Ciphertext]:
+    """[diag (.) rot_l(ct_new) for (l, diag) in terms], the rotations as one batch (fused with their products);
+    hoisted=True shares the digit decomposition of ct_new (direct Galois keys, hefx_rotate_hoisted_batch)"""
     rot = [(i, l, p) for i, (l, p) in enumerate(terms) if l]
     out = [None] * len(terms)
     for i, (l, p) in enumerate(terms):
         if not l:
             out[i] = ev.multiply_plain(ct_new, p)                    # :250
+    if hoisted and rot:
+        L = ct_new.parms_id()
+        plans = [ev.rotation_plan(l, gal_keys) for _, l, _ in rot]
+        if any(len(pl) != 1 for pl in plans):
+            raise ValueError("hoisted rotations need a direct Galois key for every step")
+        scale = _plain_product_scale(ev, ct_new, [p for _, _, p in rot])
+        elts = [pl[0] for pl in plans]
+        data = ev.be.rotate_hoisted_batch(L, ct_new.data, elts, [gal_keys.key(x) for x in elts],
+                                          [p.data for _, _, p in rot])
+        for (i, _, _), x in zip(rot, data):
+            out[i] = Ciphertext()._set(x, 2, L, scale)
+        return out
     for (i, _, _), c in zip(rot, _rotations_batched(ev, ct_new, [l for _, l, _ in rot], gal_keys,
                                                     [p for _, _, p in rot])):   # :252-257
         out[i] = c
@@ -478,22 +492,24 @@ def _sparse_products(ev: Evaluator, ct_new: Ciphertext, terms, gal_keys: KSwitch
 
 
 def linear_transform_plain_sparse(ev: Evaluator, ct: Ciphertext, d: int, diagonals: dict,
-                                  gal_keys: KSwitchKeys) -> Ciphertext:
+                                  gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
     """Linear_Transform_Plain (helper.h:237-262) of a d x d matrix given by its non-zero diagonals {l: Plaintext}"""
     if not diagonals:
         raise ValueError("encrypteds cannot be empty")
     ct_new = _duplicate(ev, ct, d, gal_keys)
-    return ev.add_many(_sparse_products(ev, ct_new, sorted(diagonals.items()), gal_keys))   # :259
+    return ev.add_many(_sparse_products(ev, ct_new, sorted(diagonals.items()), gal_keys, hoisted))   # :259
 
 
 def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int, U_sigma: dict,
                                     U_tau: dict, V_diagonals: Sequence[dict], W_diagonals: Sequence[dict],
-                                    gal_keys: KSwitchKeys) -> Ciphertext:
+                                    gal_keys: KSwitchKeys, hoisted: bool = False) -> Ciphertext:
     """CC_Matrix_Multiplication (matrix_multiplication.cpp:11-132) over the non-zero diagonals only.  The 2(n-1)
-    Step-2 transforms read the same two duplicated ciphertexts, so all their rotations go out as two batches."""
+    Step-2 transforms read the same two duplicated ciphertexts, so all their rotations go out as two batches.
+    hoisted=True (direct Galois keys for every step) runs the 2n-1 / n rotations of the sigma / tau transforms on one
+    shared digit decomposition each."""
     d = dimension * dimension
-    ctA0 = linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys)   # :22
-    ctB0 = linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys)     # :25
+    ctA0 = linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys, hoisted)   # :22
+    ctB0 = linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys, hoisted)     # :25
     out = []
     for ct0, diags in ((ctA0, V_diagonals), (ctB0, W_diagonals)):        # :42-43
         ct_new = _duplicate(ev, ct0, d, gal_keys)

@@ -180,6 +180,22 @@ def test_sparse_matrix_product_bit_exact_and_at_config5_size():
     (eg, cg), (eo, co) = r["gpu"], r["oracle"]
     assert cg.size() == 3 and (bits(eg, cg) == bits(eo, co)).all()
     assert np.allclose(decode(eg, cg, n * n).reshape(n, n), A @ B, atol=1e-4)
+
+    def run_hoisted(e):  # direct keys, sigma / tau rotations on a shared digit decomposition
+        scale = 2.0 ** 40
+        sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+        enc = lambda dd: {l: e["encoder"].encode(v, scale) for l, v in dd.items()}
+        ctA = e["enc"].encrypt(e["encoder"].encode(A.reshape(-1), scale))
+        ctB = e["enc"].encrypt(e["encoder"].encode(B.reshape(-1), scale))
+        return alg.cc_matrix_multiplication_sparse(e["ev"], ctA, ctB, n, enc(sig), enc(tau), [enc(x) for x in phi],
+                                                   [enc(x) for x in psi], e["gk"], hoisted=True)
+
+    sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+    steps = sorted({-n * n} | {l for dd in [sig, tau] + phi + psi for l in dd if l})
+    r = both(16384, [60, 40, 40, 40, 40, 60], run_hoisted, galois_steps=steps)
+    (eg, hg), (eo, ho) = r["gpu"], r["oracle"]
+    assert (bits(eg, hg) == bits(eo, ho)).all()
+    assert np.allclose(decode(eg, hg, n * n).reshape(n, n), A @ B, atol=1e-4)
     # config 5 at full size, GPU only
     n, N = 64, 32768
     parms = S.EncryptionParameters("ckks")

@@ -4,7 +4,8 @@ encoded / encrypted, keys generated beforehand), median of 5 calls incl. the hos
           default power-of-two Galois keys (bit-exact to the op-by-op sequence)
   sparse  algorithms.cc_matrix_multiplication_sparse: the non-zero diagonals only (fast mode), the reference's keys
   sparse_direct  the same with a direct Galois key for every step it uses (one key switch per rotation)
-usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct ...]"""
+  sparse_hoisted direct keys + the sigma / tau rotations on a shared digit decomposition
+usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct|sparse_hoisted ...]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -36,10 +37,10 @@ for mode in modes:
         e_ = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale)))
         args = (e_(sig), e_(tau), [e_(x) for x in phi], [e_(x) for x in psi])
         keys = gk
-        if mode == "sparse_direct":
+        if mode in ("sparse_direct", "sparse_hoisted"):
             steps = sorted({-n * n} | {l for dd in [sig, tau] + phi + psi for l in dd if l})
             keys = kg.galois_keys(steps)
-        run = lambda keys=keys: alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, keys)
+        run = lambda keys=keys, h=(mode == "sparse_hoisted"): alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, keys, hoisted=h)
         rotations = len(sig) + len(tau) + sum(len(x) for x in phi) + sum(len(x) for x in psi) + 4
     eng.sync()
     encode_s = time.perf_counter() - t0
