@@ -62,7 +62,7 @@ uint64_t hefx_psi(const hefx_context *ctx, int j);
 
 /* ---- device memory + transfers (Ciphertext/Plaintext/key payload ownership stays with the caller).
  *      hefx_malloc / hefx_free are POOLED per context: a freed block is parked (up to HEFX_POOL_MB megabytes,
- *      default 16384; 0 = plain hipMalloc / hipFree) and handed out again by a later hefx_malloc of the same size,
+ *      default 65536; 0 = plain hipMalloc / hipFree) and handed out again by a later hefx_malloc of the same size,
  *      with no device synchronisation -- SEAL's MemoryPoolHandle in spirit (SURVEY 8b "Ownership").  A recycled block
  *      may still be in use by work submitted before the free; that is correct as long as this earlier work and the
  *      new owner's work are ordered on the device: one stream (what the shim and seal.py do), or streams the caller

@@ -156,7 +156,7 @@ struct hefx_context {
     std::unordered_map<void *, PoolBlock> pool_block;             // live + parked blocks
     std::unordered_map<size_t, std::vector<void *>> pool_free;    // rounded size -> parked blocks
     std::unordered_map<size_t, int> pool_next;                    // rounded size -> blocks of its next slab (doubles)
-    size_t pool_cached = 0, pool_cap = (size_t)16 << 30;          // bytes parked / allowed to stay parked (HEFX_POOL_MB)
+    size_t pool_cached = 0, pool_cap = (size_t)64 << 30;          // bytes parked / allowed to stay parked (HEFX_POOL_MB)
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
     hipEvent_t ring_ev[KS_RING] = {};
@@ -428,7 +428,7 @@ extern "C" uint64_t hefx_psi(const hefx_context *c, int j) { return (c && j >= 0
 // GPU work) and hipFree waits for the whole device, which serialises an otherwise asynchronous call sequence.
 // hefx_malloc therefore carves blocks from slabs -- one hipMalloc for 1, 2, 4, .. 128 blocks of a size class (at most
 // 256 MiB) -- and hefx_free parks the block for the next hefx_malloc of that size.  Slabs whose blocks are all parked
-// are returned to the driver when more than HEFX_POOL_MB (default 16384) is parked, on out-of-memory and at
+// are returned to the driver when more than HEFX_POOL_MB (default 65536) is parked, on out-of-memory and at
 // hefx_context_destroy.  No synchronisation is involved in malloc / free: a recycled block may still be read or
 // written by work submitted BEFORE the free, and the new owner's work is submitted AFTER the malloc -- correct
 // whenever both are ordered on the device (one stream, the model of the shim and of seal.py, or streams the caller has
