@@ -571,11 +571,16 @@ def horner_cipher(ev: Evaluator, encoder: CKKSEncoder, encryptor, ctx: Ciphertex
 
 
 def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext], size: int,
-                            relin_keys: KSwitchKeys, gal_keys: KSwitchKeys) -> List[Ciphertext]:
+                            relin_keys: KSwitchKeys, gal_keys: KSwitchKeys, log_sum: bool = False) -> List[Ciphertext]:
     """len(As) independent cipher_dot_product calls (helper.h:416-502) advanced in lockstep: the rotate-by-1 chain
     inside one dot product is sequential, but the chains of different rows are independent, so every step is ONE
     batched key-switch launch over all rows.  Same calls in the same order per row -> same bits as the loop at
-    logistic_regression_ckks.cpp:217-220."""
+    logistic_regression_ckks.cpp:217-220.
+
+    log_sum=True is a fast mode (not the reference's bits): the window sum sum_{t<size} rot^t(dup) by doubling --
+    S(2k) = S(k) + rot^k(S(k)), S(2k+1) = S(2k) + rot^(2k)(dup) -- i.e. about log2(size) rotations instead of size-1
+    (size 8: 3 instead of 7).  Slots 0..size-1 hold the same replicated dot product as the reference's chain; slots
+    size..2*size-1 differ (they carry one more copy of the products), which no caller reads."""
     be, n = ev.be, len(As)
     mults = ev.multiply_many(As, Bs)                                 # :432
     ev.relinearize_many_inplace(mults, relin_keys)                   # :440
@@ -590,9 +595,17 @@ def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequenc
         return [Ciphertext()._set(d, 2, L, c.scale) for d, c in zip(data, cts)]
 
     dups = ev.add_pairs(mults, rotate_all(mults, -size))             # :455, :464
-    for _ in range(1, size):                                         # :472-476
-        dups = rotate_all(dups, 1)
-        mults = ev.add_pairs(mults, dups)
+    if log_sum:
+        acc, k = dups, 1
+        for b in bin(size)[3:]:  # the bits of size below its leading one
+            acc, k = ev.add_pairs(acc, rotate_all(acc, k)), 2 * k
+            if b == "1":
+                acc, k = ev.add_pairs(acc, rotate_all(dups, k)), k + 1
+        mults = acc
+    else:
+        for _ in range(1, size):                                     # :472-476
+            dups = rotate_all(dups, 1)
+            mults = ev.add_pairs(mults, dups)
     for m in mults:
         m.scale = 2.0 ** int(np.log2(m.scale))                       # :489 "manual rescale"
     return mults
@@ -605,10 +618,12 @@ SIGMOID_COEFFS = {3: [0.5, 1.20069, 0.00001, -0.81562],
 
 def predict_cipher_weights(ev: Evaluator, encoder: CKKSEncoder, encryptor, features: Sequence[Ciphertext],
                            weights: Ciphertext, num_weights: int, scale: float, gal_keys: KSwitchKeys,
-                           relin_keys: KSwitchKeys, degree: int = 3) -> Ciphertext:
-    """predict_cipher_weights, /root/reference/logistic_regression_ckks.cpp:208-266."""
+                           relin_keys: KSwitchKeys, degree: int = 3, log_sum: bool = False) -> Ciphertext:
+    """predict_cipher_weights, /root/reference/logistic_regression_ckks.cpp:208-266.  log_sum=True: the fast window
+    sum of cipher_dot_product_many (same prediction values, not the reference's noise bits)."""
     num_rows = len(features)
-    results = cipher_dot_product_many(ev, features, [weights] * num_rows, num_weights, relin_keys, gal_keys)  # :220
+    results = cipher_dot_product_many(ev, features, [weights] * num_rows, num_weights, relin_keys, gal_keys,
+                                      log_sum)                                                             # :220
     # the reference encodes one one-hot mask per row inside the loop (:222-225, 2000 CPU FFTs per iteration); here all
     # masks go through one batched encode (one GPU launch on the HIP engine) -- same plaintexts, same order of use
     # masks go through one batched encode (one GPU launch on the HIP engine) -- same plaintexts, same order of use.

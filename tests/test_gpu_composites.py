@@ -284,6 +284,31 @@ def test_logistic_regression_step_bit_exact():
     assert np.allclose(decode(eg, tg, 2), c[0] + c[1] * xs + c[2] * xs ** 2 + c[3] * xs ** 3, atol=1e-3)
 
 
+def test_lr_prediction_fast_window_sum_bit_exact_against_the_twin():
+    """predict_cipher_weights(log_sum=True): the dot products' window sums by doubling (4 instead of 9 key switches per
+    row at 8 weights).  Same composition on the oracle twin -> same bits; same predictions as the reference's chain."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    rng = np.random.default_rng(77)
+    X, w = rng.uniform(-1, 1, (6, 8)), rng.uniform(-0.5, 0.5, 8)
+    c = alg.SIGMOID_COEFFS[3]
+
+    def run(e):
+        scale = 2.0 ** 40
+        feats = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in X]
+        cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+        return (alg.predict_cipher_weights(e["ev"], e["encoder"], e["enc"], feats, cw, 8, scale, e["gk"], e["rk"],
+                                           log_sum=True),
+                alg.predict_cipher_weights(e["ev"], e["encoder"], e["enc"], feats, cw, 8, scale, e["gk"], e["rk"]))
+
+    r = both(4096, [60, 40, 40, 40, 40, 40, 40, 40, 60], run, seed=6)
+    (eg, (fg, rg)), (eo, (fo, ro)) = r["gpu"], r["oracle"]
+    assert (bits(eg, fg) == bits(eo, fo)).all() and (bits(eg, rg) == bits(eo, ro)).all()
+    z = X @ w
+    want = c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3
+    assert np.allclose(decode(eg, fg, 6), want, atol=5e-3) and np.allclose(decode(eg, rg, 6), want, atol=5e-3)
+    assert (bits(eg, fg) != bits(eg, rg)).any()
+
+
 def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
     """Direct keys for every step (keygen.galois_keys(steps)): SEAL then applies ONE key switch per rotation and the
     regular path stays bit-exact.  hoisted=True additionally shares the digit decomposition of ct_new across the

@@ -335,3 +335,21 @@ def test_shared_rotations_in_the_matrix_product_keep_the_bits_of_the_per_transfo
     literal = [alg.linear_transform_plain(e["ev"], ct0, vd, e["gk"]) for vd in Vd]
     for a, b in zip(shared, literal):
         assert a.parms_id() == b.parms_id() and a.scale == b.scale and (a.data == b.data).all()
+
+
+@pytest.mark.parametrize("size", [8, 5, 7])
+def test_log_depth_window_sum_gives_the_same_dot_products(size):
+    """cipher_dot_product_many(log_sum=True): about log2(size) rotations instead of size-1; slots 0..size-1 carry the
+    same replicated dot product as the reference's rotate-by-1 chain (helper.h:472-476)."""
+    e = make(2048, [50, 30, 30, 50])
+    scale = 2.0 ** 30
+    rng = np.random.default_rng(size)
+    X, w = rng.uniform(-1, 1, (3, size)), rng.uniform(-1, 1, size)
+    feats = [e["enc"].encrypt(e["encoder"].encode(r, scale)) for r in X]
+    cw = e["enc"].encrypt(e["encoder"].encode(w, scale))
+    ref = alg.cipher_dot_product_many(e["ev"], feats, [cw] * 3, size, e["rk"], e["gk"])
+    fast = alg.cipher_dot_product_many(e["ev"], feats, [cw] * 3, size, e["rk"], e["gk"], log_sum=True)
+    for i in range(3):
+        assert fast[i].parms_id() == ref[i].parms_id() and fast[i].scale == ref[i].scale
+        a, b = dec(e, ref[i], size).real, dec(e, fast[i], size).real
+        assert np.abs(a - X[i] @ w).max() < 1e-3 and np.abs(b - X[i] @ w).max() < 1e-3

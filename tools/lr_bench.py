@@ -1,6 +1,7 @@
 """predict_cipher_weights (logistic_regression_ckks.cpp:208-266) on the reference's LR parameter set
 (N=16384, {60,40x7,60}, scale 2^40, 8 weights): rows x (multiply + relinearize + rescale + 8 sequential rotations),
 masks, add_many, degree-3 sigmoid by Horner.  Compute phase only (rows encrypted beforehand), median of 3.
+LR_LOG_SUM=1 selects the fast window sum (log2(size) rotations per dot product, not the reference's bits).
 usage: lr_bench.py [rows ...]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,6 +9,7 @@ import numpy as np
 from seal_fyp_logistic_regression_amd import algorithms as alg
 from seal_fyp_logistic_regression_amd import seal as S
 
+LOG_SUM = os.environ.get("LR_LOG_SUM", "0") != "0"
 N, bits, scale, nw = 16384, [60] + [40] * 7 + [60], 2.0 ** 40, 8
 parms = S.EncryptionParameters("ckks"); parms.set_poly_modulus_degree(N); parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
 ctx = S.SEALContext.Create(parms)
@@ -15,7 +17,7 @@ kg = S.KeyGenerator(ctx, 1); gk = kg.galois_keys(); rk = kg.relin_keys()
 enc, dec = S.Encryptor(ctx, kg.public_key()), S.Decryptor(ctx, kg.secret_key())
 encoder, ev, eng = S.CKKSEncoder(ctx), S.Evaluator(ctx), ctx.backend.engine
 rng = np.random.default_rng(0)
-out = {"params": f"N={N} {bits} scale 2^40, {nw} weights", "runs": []}
+out = {"params": f"N={N} {bits} scale 2^40, {nw} weights", "window_sum": "doubling (fast mode)" if LOG_SUM else "rotate-by-1 chain (reference, bit-exact)", "runs": []}
 for rows in [int(x) for x in (sys.argv[1:] or ["100", "2000"])]:
     X = rng.uniform(-1, 1, (rows, nw)); w = rng.uniform(-0.5, 0.5, nw)
     t0 = time.perf_counter()
@@ -25,7 +27,7 @@ for rows in [int(x) for x in (sys.argv[1:] or ["100", "2000"])]:
     walls = []
     for _ in range(4):
         t = time.perf_counter()
-        pred = alg.predict_cipher_weights(ev, encoder, enc, feats, cw, nw, scale, gk, rk)
+        pred = alg.predict_cipher_weights(ev, encoder, enc, feats, cw, nw, scale, gk, rk, log_sum=LOG_SUM)
         eng.sync(); walls.append(time.perf_counter() - t)
     got = encoder.decode(dec.decrypt(pred))[:rows].real
     c = alg.SIGMOID_COEFFS[3]; z = X @ w
