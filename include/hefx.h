@@ -195,6 +195,14 @@ int hefx_linear_transform_plain_hoisted2(hefx_context *ctx, int L, const uint64_
                                          const uint64_t *const *d_diag_pts_keylevel, int nkeys,
                                          const uint32_t *key_elts, const uint64_t *const *d_keys, uint64_t *d_out,
                                          void *stream);
+/* Double hoisting over a SUBSET of the diagonals (the permutation matrices of the matrix product have 2n-1 or n
+ * non-zero diagonals out of n^2, matrix_multiplication.cpp:239-297): term i multiplies rotate(ct_new, steps[i]) by
+ * d_diag_pts_keylevel[i]; steps[0] must be 0, every other step non-zero with a direct Galois key; d only fixes the
+ * duplication rotate(ct, -d) of helper.h:244. */
+int hefx_linear_transform_plain_hoisted2_sparse(hefx_context *ctx, int L, const uint64_t *d_ct, int d, int nterms,
+                                                const int *steps, const uint64_t *const *d_diag_pts_keylevel,
+                                                int nkeys, const uint32_t *key_elts, const uint64_t *const *d_keys,
+                                                uint64_t *d_out, void *stream);
 
 /* Baby-step / giant-step form of Linear_Transform_Plain (helper.h:237-262).  With n2 = ceil(d/n1)
  * and l = j*n1 + i:  sum_l diag_l (.) rot_l(ct_new) = sum_j rot_(j*n1)( sum_i diag'_l (.) rot_i(ct_new) ), where

@@ -496,8 +496,48 @@ def linear_transform_plain_sparse(ev: Evaluator, ct: Ciphertext, d: int, diagona
     """Linear_Transform_Plain (helper.h:237-262) of a d x d matrix given by its non-zero diagonals {l: Plaintext}"""
     if not diagonals:
         raise ValueError("encrypteds cannot be empty")
+    if hoisted == 2:
+        return _linear_transform_plain_sparse_hoisted2(ev, ct, d, diagonals, gal_keys)
     ct_new = _duplicate(ev, ct, d, gal_keys)
     return ev.add_many(_sparse_products(ev, ct_new, sorted(diagonals.items()), gal_keys, hoisted))   # :259
+
+
+def _linear_transform_plain_sparse_hoisted2(ev: Evaluator, ct: Ciphertext, d: int, diagonals: dict,
+                                            gal_keys: KSwitchKeys) -> Ciphertext:
+    """double hoisting (one mod-down for the whole transform, see _linear_transform_plain_hoisted2) over the non-zero
+    diagonals: KEY-LEVEL plaintexts, ct at the top data level, diagonal 0 present, direct keys for the other steps"""
+    ctx, be, L = ev.ctx, ev.be, ct.parms_id()
+    if ct.size() != 2:
+        raise ValueError("encrypted size must be 2")
+    if L != ctx.first_parms_id():
+        raise ValueError("double hoisting is built for the top data level")
+    if 0 not in diagonals:
+        raise ValueError("double hoisting over a subset of diagonals needs diagonal 0")
+    steps = [0] + sorted(l for l in diagonals if l)
+    pts = [diagonals[l] for l in steps]
+    if any(p.parms_id() != ctx.k for p in pts):
+        raise ValueError("double hoisting needs key-level plaintexts (encode with parms_id = key level)")
+    scale = None
+    for p in pts:
+        s = ct.scale * p.scale
+        ev._check_scale(s, L)
+        if scale is not None and not ev._close(scale, s):
+            raise ValueError("scale mismatch")
+        scale = s if scale is None else scale
+        if p.is_zero:
+            raise RuntimeError("result ciphertext is transparent")
+    native = getattr(be, "linear_transform_plain_hoisted2_sparse", None)
+    if native is not None:
+        elts = sorted(gal_keys.keys)
+        data = native(L, ct.data, d, steps, [p.data for p in pts], elts, [gal_keys.key(e) for e in elts])
+    else:  # the oracle twin: regular -d rotation, then the oracle's statement of the double-hoisted core
+        plans = [ev.rotation_plan(l, gal_keys) for l in steps[1:]]
+        if any(len(p) != 1 for p in plans):
+            raise ValueError("hoisted linear transform needs a direct Galois key for every step")
+        ct_new = _duplicate(ev, ct, d, gal_keys)
+        elts = [p[0] for p in plans]
+        data = be.lt_double_hoisted_core(ct_new.data, [p.data for p in pts], elts, [gal_keys.key(e) for e in elts])
+    return Ciphertext()._set(data, 2, L, scale)
 
 
 def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int, U_sigma: dict,
@@ -506,7 +546,8 @@ def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphert
     """CC_Matrix_Multiplication (matrix_multiplication.cpp:11-132) over the non-zero diagonals only.  The 2(n-1)
     Step-2 transforms read the same two duplicated ciphertexts, so all their rotations go out as two batches.
     hoisted=True (direct Galois keys for every step) runs the 2n-1 / n rotations of the sigma / tau transforms on one
-    shared digit decomposition each."""
+    shared digit decomposition each; hoisted=2 additionally mods them down once per transform (U_sigma / U_tau then
+    hold KEY-LEVEL plaintexts, see _linear_transform_plain_sparse_hoisted2; Step 2 stays single-hoisted)."""
     d = dimension * dimension
     ctA0 = linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys, hoisted)   # :22
     ctB0 = linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys, hoisted)     # :25

@@ -72,6 +72,8 @@ _SIGS = {
     "hefx_rotate_hoisted_batch": (_i, [_vp, _i, _vp, _i, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_linear_transform_plain_hoisted": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_linear_transform_plain_hoisted2": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
+    "hefx_linear_transform_plain_hoisted2_sparse": (_i, [_vp, _i, _vp, _i, _i, C.POINTER(C.c_int), _pp, _i, C.POINTER(_u32),
+                                                       _pp, _vp, _vp]),
     "hefx_linear_transform_plain_bsgs": (_i, [_vp, _i, _vp, _i, _i, _pp, _i, C.POINTER(_u32), _pp, _i, _vp, _vp]),
     "hefx_ckks_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp]),
     "hefx_sample_uniform": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),

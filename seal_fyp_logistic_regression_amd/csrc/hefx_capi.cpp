@@ -1436,17 +1436,19 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
 
 // Double-hoisted Linear_Transform_Plain (see lt2_mac_kernel): top data level, direct keys for 1..d-1, diagonals
 // encoded at the KEY level ([k][N]: data primes then the special prime).
-extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, const uint64_t *ct, int d,
-                                                    const uint64_t *const *diag_pts_keylevel, int nkeys,
-                                                    const uint32_t *key_elts, const uint64_t *const *keys,
-                                                    uint64_t *out, void *stream)
+// terms: term 0 is the unrotated one (steps[0] == 0), term i >= 1 rotates ct_new by steps[i]; d only enters through
+// the duplication rotate(ct, -d).  The dense transform is steps = 0, 1, .., d-1.
+static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterms, const int *steps,
+                    const uint64_t *const *diag_pts_keylevel, int nkeys, const uint32_t *key_elts,
+                    const uint64_t *const *keys, uint64_t *out, void *stream)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
     if (L != c->k - 1) return fail(HEFX_ERR_UNSUPPORTED, "double hoisting is built for the top data level");
-    if (!ct || !out || d < 1 || !diag_pts_keylevel || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+    if (!ct || !out || d < 1 || nterms < 1 || !steps || steps[0] != 0 || !diag_pts_keylevel || nkeys < 0 ||
+        (nkeys && (!key_elts || !keys)))
         return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
-    for (int i = 0; i < d; ++i)
+    for (int i = 0; i < nterms; ++i)
         if (!diag_pts_keylevel[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
     LtKeys K;
     for (int i = 0; i < nkeys; ++i) {
@@ -1454,10 +1456,10 @@ extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, cons
         K.m[key_elts[i]] = keys[i];
     }
     const size_t N = c->n, ctw = 2 * (size_t)L * N;
-    const int k = c->k, nrot = d - 1, chunks = nrot > 0 ? (nrot + lt2_chunk() - 1) / lt2_chunk() : 0;
+    const int k = c->k, nrot = nterms - 1, chunks = nrot > 0 ? (nrot + lt2_chunk() - 1) / lt2_chunk() : 0;
     std::vector<uint32_t> first, plan;
     if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
-    std::vector<KsItem> items((size_t)d + 1);  // [0]: source (ct_new); [1..d-1]: rotations; [d]: the mod-down
+    std::vector<KsItem> items((size_t)nterms + 1);  // [0]: source (ct_new); [1..nterms-1]: rotations; last: the mod-down
     // ---- workspace
     const size_t ws_words = 4 * ctw + (size_t)chunks * (2 * (size_t)k + L) * N + (items.size() * sizeof(KsItem) + 7) / 8;
     if (c->lt_cap < ws_words) {
@@ -1471,9 +1473,10 @@ extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, cons
     uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw, *cbuf = ct_new + ctw;
     u64 *partial_s = reinterpret_cast<u64 *>(cbuf + ctw), *partial_c0 = partial_s + (size_t)chunks * 2 * k * N;
     KsItem *d_items = reinterpret_cast<KsItem *>(partial_c0 + (size_t)chunks * L * N);
-    for (int l = 1; l < d; ++l) {
+    for (int l = 1; l < nterms; ++l) {
         plan.clear();
-        if (const char *err = lt_plan(l, N, K, plan)) return fail(HEFX_ERR_INVALID, err);
+        if (steps[l] == 0) return fail(HEFX_ERR_INVALID, "only term 0 may be unrotated");
+        if (const char *err = lt_plan(steps[l], N, K, plan)) return fail(HEFX_ERR_INVALID, err);
         if (plan.size() != 1)
             return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
         KsItem &it = items[l];
@@ -1484,7 +1487,7 @@ extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, cons
         if (int rc = get_perm(c, plan[0], &it.perm)) return rc;
     }
     items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr};
-    items[d] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out};
+    items[nterms] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out};
     // ---- ct_new = ct + rotate(ct, -d); cbuf = ct_new * diag_0
     const uint64_t *src = ct;
     for (size_t t = 0; t < first.size(); ++t) {
@@ -1514,8 +1517,28 @@ extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, cons
     HIPCHK(hipStreamSynchronize(s));  // `items` is a local
     HIPCHK(launch_lt2_decompose(c->T, L, d_items, d_items + 1, nrot, S, (const u64 *)ct_new, partial_s, partial_c0,
                                 (u64 *)cbuf, s));
-    HIPCHK(launch_lt2_moddown(c->T, L, d_items + d, S, s));
+    HIPCHK(launch_lt2_moddown(c->T, L, d_items + nterms, S, s));
     return HEFX_OK;
+}
+
+extern "C" int hefx_linear_transform_plain_hoisted2(hefx_context *c, int L, const uint64_t *ct, int d,
+                                                    const uint64_t *const *diag_pts_keylevel, int nkeys,
+                                                    const uint32_t *key_elts, const uint64_t *const *keys,
+                                                    uint64_t *out, void *stream)
+{
+    if (d < 1) return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    std::vector<int> steps(d);
+    for (int l = 0; l < d; ++l) steps[l] = l;
+    return lt2_impl(c, L, ct, d, d, steps.data(), diag_pts_keylevel, nkeys, key_elts, keys, out, stream);
+}
+// The same over a subset of the diagonals: term i multiplies rotate(ct_new, steps[i]) by d_diag_pts_keylevel[i];
+// steps[0] must be 0 (the unrotated term), the others non-zero with a direct Galois key each.
+extern "C" int hefx_linear_transform_plain_hoisted2_sparse(hefx_context *c, int L, const uint64_t *ct, int d, int nterms,
+                                                           const int *steps, const uint64_t *const *diag_pts_keylevel,
+                                                           int nkeys, const uint32_t *key_elts,
+                                                           const uint64_t *const *keys, uint64_t *out, void *stream)
+{
+    return lt2_impl(c, L, ct, d, nterms, steps, diag_pts_keylevel, nkeys, key_elts, keys, out, stream);
 }
 
 extern "C" int hefx_rotate_hoisted_batch(hefx_context *c, int L, const uint64_t *ct_in, int n, const uint32_t *elts,

@@ -308,6 +308,16 @@ class Engine:
             capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
         return out
 
+    def linear_transform_plain_hoisted2_sparse(self, L, ct, d, steps, diag_pts_keylevel, key_elts, keys, out=None,
+                                               stream=None):
+        """double-hoisted transform over a subset of the diagonals (steps[0] == 0)"""
+        out = out if out is not None else DeviceArray(self, (2, L, self.N))
+        arr = (C.c_int * len(steps))(*[int(x) for x in steps])
+        capi.check(capi.lib().hefx_linear_transform_plain_hoisted2_sparse(
+            self._h, L, ct.ptr, int(d), len(steps), arr, capi.ptr_array([p.ptr for p in diag_pts_keylevel]), len(keys),
+            capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
+        return out
+
     def linear_transform_plain_bsgs(self, L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted=True, out=None,
                                     stream=None):
         """baby-step / giant-step Linear_Transform_Plain in one native call (hefx_linear_transform_plain_bsgs)"""

@@ -186,6 +186,9 @@ class GpuBackend:
     def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None):
         return self.engine.rotate_hoisted_batch(L, ct, elts, keys, pts)
 
+    def linear_transform_plain_hoisted2_sparse(self, L, ct, d, steps, diag_pts_keylevel, key_elts, keys):
+        return self.engine.linear_transform_plain_hoisted2_sparse(L, ct, d, steps, diag_pts_keylevel, key_elts, keys)
+
     def linear_transform_plain_bsgs(self, L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted=True):
         return self.engine.linear_transform_plain_bsgs(L, ct, shifted_diag_pts, n1, key_elts, keys, hoisted)
 

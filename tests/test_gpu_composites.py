@@ -196,6 +196,20 @@ def test_sparse_matrix_product_bit_exact_and_at_config5_size():
     (eg, hg), (eo, ho) = r["gpu"], r["oracle"]
     assert (bits(eg, hg) == bits(eo, ho)).all()
     assert np.allclose(decode(eg, hg, n * n).reshape(n, n), A @ B, atol=1e-4)
+
+    def run_hoisted2(e):  # sigma / tau double-hoisted: key-level diagonals, one mod-down per transform
+        scale = 2.0 ** 40
+        enc = lambda dd, lvl=None: {l: e["encoder"].encode(v, scale, parms_id=lvl) for l, v in dd.items()}
+        ctA = e["enc"].encrypt(e["encoder"].encode(A.reshape(-1), scale))
+        ctB = e["enc"].encrypt(e["encoder"].encode(B.reshape(-1), scale))
+        k = e["ctx"].k
+        return alg.cc_matrix_multiplication_sparse(e["ev"], ctA, ctB, n, enc(sig, k), enc(tau, k),
+                                                   [enc(x) for x in phi], [enc(x) for x in psi], e["gk"], hoisted=2)
+
+    r = both(16384, [60, 40, 40, 40, 40, 60], run_hoisted2, galois_steps=steps)
+    (eg, h2g), (eo, h2o) = r["gpu"], r["oracle"]
+    assert (bits(eg, h2g) == bits(eo, h2o)).all()
+    assert np.allclose(decode(eg, h2g, n * n).reshape(n, n), A @ B, atol=1e-4)
     # config 5 at full size, GPU only
     n, N = 64, 32768
     parms = S.EncryptionParameters("ckks")

@@ -5,7 +5,8 @@ encoded / encrypted, keys generated beforehand), median of 5 calls incl. the hos
   sparse  algorithms.cc_matrix_multiplication_sparse: the non-zero diagonals only (fast mode), the reference's keys
   sparse_direct  the same with a direct Galois key for every step it uses (one key switch per rotation)
   sparse_hoisted direct keys + the sigma / tau rotations on a shared digit decomposition
-usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct|sparse_hoisted ...]"""
+  sparse_hoisted2 the sigma / tau transforms double-hoisted (key-level diagonals, one mod-down each)
+usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct|sparse_hoisted|sparse_hoisted2 ...]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -37,10 +38,14 @@ for mode in modes:
         e_ = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale)))
         args = (e_(sig), e_(tau), [e_(x) for x in phi], [e_(x) for x in psi])
         keys = gk
-        if mode in ("sparse_direct", "sparse_hoisted"):
+        if mode in ("sparse_direct", "sparse_hoisted", "sparse_hoisted2"):
             steps = sorted({-n * n} | {l for dd in [sig, tau] + phi + psi for l in dd if l})
             keys = kg.galois_keys(steps)
-        run = lambda keys=keys, h=(mode == "sparse_hoisted"): alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, keys, hoisted=h)
+        h = {"sparse_hoisted": True, "sparse_hoisted2": 2}.get(mode, False)
+        if h == 2:  # sigma / tau diagonals at the key level
+            ek = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale, parms_id=ctx.k)))
+            args = (ek(sig), ek(tau)) + args[2:]
+        run = lambda keys=keys, h=h, args=args: alg.cc_matrix_multiplication_sparse(ev, ctA, ctB, n, *args, keys, hoisted=h)
         rotations = len(sig) + len(tau) + sum(len(x) for x in phi) + sum(len(x) for x in psi) + 4
     eng.sync()
     encode_s = time.perf_counter() - t0
