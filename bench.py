@@ -97,7 +97,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=576, help="independent ciphertexts per step per GPU")
+    ap.add_argument("--batch", type=int, default=1152, help="independent ciphertexts per step per GPU")
     ap.add_argument("--set", default="C3", choices=sorted(SETS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     args = ap.parse_args()
