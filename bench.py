@@ -2,11 +2,24 @@
 """bench.py -- CKKS rotate + multiply_plain throughput on MI355X (BASELINE.json metric).
 
 One "step" = one pass of the hot path over one batch of B independent synthetic ciphertexts:
-out_i = multiply_plain(rotate_vector(ct_i, 1), pt_i) with a directly keyed step (exactly one key switch),
-at the top data level of configs[2]'s parameter set C3 (N=16384, primes {60,40,40,40,40,60}, L=5) -- the
-configuration the metric is quoted on.  Inputs (ciphertexts, plaintexts, the Galois key) are resident in
-HBM before the timed region.  With N>1 ranks each rank owns its own batch (independent units, no data-path
-collective) -> weak scaling; value is the whole-job aggregate.
+out_i = multiply_plain(rotate_vector(ct_i, 1), pt_i) with a directly keyed step (exactly one key switch), at the top
+data level of configs[2]'s parameter set C3 (N=16384, primes {60,40,40,40,40,60}, L=5) -- the configuration the
+metric is quoted on.  Inputs (ciphertexts, plaintexts, the Galois key) are resident in HBM before the timed region.
+With N>1 ranks each rank owns its own batch (independent units, no data-path collective) -> weak
+scaling; `value` is the whole-job aggregate.
+
+Launch: `python bench.py --gpus N` starts N ranks ITSELF (child processes, created before this process touches the
+GPU) when it is not already running under a launcher; under `python -m torch.distributed.run --nproc-per-node N`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment) it is one of the ranks.  One rank per GPU, RCCL ("nccl").
+`HEFX_BENCH_BACKEND=gloo` (development only) lets several ranks share the GPUs that exist.
+
+Besides the headline, the same JSON line carries:
+  verified      outs[0] and outs[B-1] of the timed loop compared word for word with the CPU oracle
+  variants      the same batch with 16 distinct steps / Galois keys round-robin (the headline shares one key)
+  lt_sharded    Linear_Transform_Plain (helper.h:237-262) at C3, d = 16 and 512, diagonals sharded over the ranks with one
+                RCCL SUM(uint64) all-reduce per transform (parallel.linear_transform_plain_sharded); the sharded bits are
+                asserted equal to the serial ones in the run
+  roofline.valu the integer / FP64 butterfly issue-cycle bound next to the HBM one
 
 Prints ONE JSON line on rank 0.
 """
@@ -15,6 +28,8 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import threading
 import time
@@ -32,6 +47,11 @@ SETS = {
     "C5": (32768, [0xfffffffff840001, 0xffff940001, 0xffffb20001, 0xffffc40001, 0xffffe80001, 0xffffffffffc0001]),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+# VALU issue model (profiles/r01_valu_issue_rates.txt, tools/ubench_valu.hip): cycles one SIMD
+# spends per wave-butterfly (64 butterflies) -- Harvey/Shoup on 60-bit primes vs the exact-FMA FP64 butterfly on
+# primes < 2^41 -- and the machine: 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
+VALU_CYC_INT, VALU_CYC_F64 = 105.0, 40.0
+SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 
 def algorithmic_bytes_per_op(N: int, L: int) -> int:
@@ -39,18 +59,32 @@ def algorithmic_bytes_per_op(N: int, L: int) -> int:
     return 8 * N * L * (2 * L + 7)
 
 
-def synth(rng, primes, N, *shape):
-    import numpy as np
-    out = np.empty(shape + (N,), dtype=np.uint64)
-    for idx in np.ndindex(*shape):
-        out[idx] = rng.integers(0, primes[idx[-1]], N, dtype=np.uint64)
-    return out
+def valu_bound_ops_per_s(N: int, primes, L: int) -> dict:
+    """Butterfly-only VALU ceiling of one rotate+multiply_plain: (L+1)(L+2) transforms of (N/2) log2 N butterflies,
+    each priced by the arithmetic policy of the modulus it runs in (digit INTT: q_i; digit NTT: target modulus;
+    mod-down INTT: P; mod-down NTT: q_j)."""
+    k = len(primes)
+    f64 = [p < (1 << 41) for p in primes]
+    n_int = n_f64 = 0
+    for i in range(L):                       # inverse transform of digit i
+        n_f64, n_int = (n_f64 + 1, n_int) if f64[i] else (n_f64, n_int + 1)
+    for i in range(L):                       # digit i -> every other modulus of the extended basis
+        for m in list(range(L)) + [k - 1]:
+            if m == i:
+                continue
+            n_f64, n_int = (n_f64 + 1, n_int) if f64[m] else (n_f64, n_int + 1)
+    n_f64, n_int = (n_f64 + 2, n_int) if f64[k - 1] else (n_f64, n_int + 2)      # INTT_P of both accumulators
+    for j in range(L):                       # remainder -> data prime j, both polys
+        n_f64, n_int = (n_f64 + 2, n_int) if f64[j] else (n_f64, n_int + 2)
+    wave_bf = (N // 2) * (N.bit_length() - 1) / 64.0
+    cycles = wave_bf * (n_int * VALU_CYC_INT + n_f64 * VALU_CYC_F64)
+    return {"int_transforms": n_int, "f64_transforms": n_f64, "simd_cycles_per_op": cycles,
+            "peak_ops_per_s": SIMDS * CLOCK_HZ / cycles}
 
 
 def cpu_baseline(name: str, budget_s: float):
     """Times the CPU oracle (SEAL-3.4.5-algorithm restatement, kind "port") on a bounded sample of the same
     workload: every host core runs independent rotate+multiply_plain ops for ~budget_s seconds."""
-    import numpy as np
     from oracle import oracle as O
     N, primes = SETS[name]
     k = len(primes)
@@ -62,8 +96,11 @@ def cpu_baseline(name: str, budget_s: float):
     key = o.uniform(k, 2 * L, 0x6A1015).reshape(L, 2, k, N)
     o.rotate_mulplain(ct, 3, key, pt)  # warm-up
     t0 = time.perf_counter()
-    o.rotate_mulplain(ct, 3, key, pt)
-    one = time.perf_counter() - t0
+    reps = 0
+    while time.perf_counter() - t0 < min(1.0, budget_s / 4):
+        o.rotate_mulplain(ct, 3, key, pt)
+        reps += 1
+    one = (time.perf_counter() - t0) / reps
     counts = [0] * cores
     deadline = [0.0]
 
@@ -87,24 +124,140 @@ def cpu_baseline(name: str, budget_s: float):
         "kind": "port",
         "single_thread_value": 1.0 / one,
         "sample": f"{sum(counts)} ops of the bench workload ({name}: N={N}, L={L}) on {cores} threads in "
-                  f"{dt:.1f} s (time-bounded); SEAL-3.4.5-algorithm CPU restatement (oracle/ckks_oracle.c), "
-                  "real SEAL is not installable offline",
+                  f"{dt:.1f} s (time-bounded) + {reps} ops on one thread; SEAL-3.4.5-algorithm CPU restatement "
+                  "(oracle/ckks_oracle.c), real SEAL is not installable offline",
     }
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# launcher: --gpus N outside a distributed launcher starts the N ranks itself
+# ------------------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args) -> int:
+    """Parent of a self-launched multi-rank run.  It never initialises the GPU (device_count() only counts, per the
+    image notes) and never replaces itself: the ranks are ordinary child processes and their exit codes are relayed."""
+    import torch
+    n = args.gpus
+    have = torch.cuda.device_count()
+    backend = os.environ.get("HEFX_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and have < n:
+        print(f"bench.py: --gpus {n} needs {n} HIP devices, this machine shows {have} "
+              "(RCCL wants one device per rank; HEFX_BENCH_BACKEND=gloo shares devices for development)",
+              file=sys.stderr, flush=True)
+        return 2
+    if have < 1:
+        print("bench.py needs a HIP device: the engine has no CPU fallback", file=sys.stderr, flush=True)
+        return 2
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the sharded linear transform (SURVEY 8d "Scaling runs", 8e-i)
+# ------------------------------------------------------------------------------------------------------------------
+def lt_sharded_bench(local_rank: int, world: int, dims, reps: int):
+    """Linear_Transform_Plain at C3 with the reference's default (power-of-two, NAF-expanded) Galois keys: the serial
+    one-call form on this rank, and -- with more than one rank -- the diagonal-sharded form with its one all-reduce.
+    Same seeds on every rank => same keys, ciphertext and diagonals everywhere (what a broadcast at setup would give)."""
+    import numpy as np
+    import torch.distributed as dist
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from seal_fyp_logistic_regression_amd import parallel as par
+    from seal_fyp_logistic_regression_amd import seal as S
+    N, primes = SETS["C3"]
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(primes)
+    ctx = S.SEALContext.Create(parms, device=local_rank)
+    kg = S.KeyGenerator(ctx, 0xC3)
+    enc, dec = S.Encryptor(ctx, kg.public_key(), 0xC4), S.Decryptor(ctx, kg.secret_key())
+    encoder, ev, gk = S.CKKSEncoder(ctx), S.Evaluator(ctx), kg.galois_keys()
+    eng = ctx.backend.engine
+    bits = lambda c: ctx.backend.to_host(c.data)
+    scale = 2.0 ** 40
+    out = {}
+    for d in dims:
+        rng = np.random.default_rng(1000 + d)
+        M, v = rng.uniform(-1, 1, (d, d)), rng.uniform(-1, 1, d)
+        diags = encoder.encode_many(list(alg.get_all_diagonals(M)), scale)
+        ct = enc.encrypt(encoder.encode(v, scale))
+
+        def timed(fn):
+            r = fn()  # warm-up (scratch growth, Galois tables, pool slabs)
+            eng.sync()
+            if world > 1:
+                dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                r = fn()
+            eng.sync()
+            return r, (time.perf_counter() - t0) / reps * 1e3
+
+        serial, serial_ms = timed(lambda: alg.linear_transform_plain(ev, ct, diags, gk))
+        ok = bool(np.allclose(encoder.decode(dec.decrypt(serial))[:d].real, M @ v, atol=1e-3 * d))
+        rec = {"serial_ms": serial_ms, "decrypts_to_Mv": ok, "key_switches_serial": alg_key_switches(ev, d, gk)}
+        if world > 1:
+            sharded, sharded_ms = timed(lambda: par.linear_transform_plain_sharded(ev, ct, diags, gk))
+            same = bool((bits(serial) == bits(sharded)).all())
+            t = [sharded_ms, 1.0 if same else 0.0]
+            import torch
+            tt = torch.tensor(t, dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                tt = tt.cuda()
+            mx, mn = tt.clone(), tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            rec.update({"sharded_ms": float(mx[0].item()), "speedup_vs_1": serial_ms / float(mx[0].item()),
+                        "bits_equal_serial": bool(mn[1].item() == 1.0),
+                        "allreduce_bytes": 2 * (len(primes) - 1) * N * 8})
+            assert rec["bits_equal_serial"], f"sharded linear transform (d={d}) differs from the serial one"
+        out[f"d{d}"] = rec
+    return out
+
+
+def alg_key_switches(ev, d, gk) -> int:
+    """key switches of one Linear_Transform_Plain with these keys (NAF rule)"""
+    return sum(len(ev.rotation_plan(s, gk)) for s in [-d] + list(range(1, d)))
+
+
+# ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=1152, help="independent ciphertexts per step per GPU")
+    ap.add_argument("--batch", type=int, default=4608, help="independent ciphertexts per step per GPU")
     ap.add_argument("--set", default="C3", choices=sorted(SETS))
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
+    ap.add_argument("--lt", default="16,512", help="dimensions of the (sharded) linear-transform leg; '' disables")
+    ap.add_argument("--variant-keys", type=int, default=16, help="distinct Galois keys of the secondary pass; 0 disables")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args))  # nothing in this process has touched the GPU
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; reporting n_gpus={world}",
+              file=sys.stderr, flush=True)
 
     import numpy as np
     import torch
@@ -115,8 +268,11 @@ def main():
     # one rank per GPU.  HEFX_BENCH_BACKEND=gloo (development only) lets several ranks share the GPUs that exist, to
     # exercise the multi-rank code path on a one-GPU box; the driver's runs use RCCL ("nccl").
     backend = os.environ.get("HEFX_BENCH_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    if backend == "nccl" and world > ndev:
+        raise SystemExit(f"bench.py: {world} ranks need {world} HIP devices, this machine shows {ndev}")
     if backend != "nccl":
-        local_rank %= max(torch.cuda.device_count(), 1)
+        local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -132,22 +288,22 @@ def main():
     L = k - 1
     B = args.batch
     e = Engine(N, primes, device=local_rank)
-    rng = np.random.default_rng(0x5EA1C0DE + rank)
-    # slabs: one allocation per tensor class, items are views (what a pooling allocator hands out)
-    big_ct = e.empty(B, 2, L, N)
-    big_pt = e.empty(B, L, N)
+    # Synthetic inputs: uniform residues drawn ON the device by the engine's counter-mode sampler (ChaCha20 keyed by the
+    # seed; hefx_sample_uniform) -- no host generation / PCIe leg, so the batch can be sized for the HBM.
+    import hashlib
+    key32 = lambda tag: hashlib.sha256(f"hefx-bench:{tag}:{rank}".encode()).digest()
+    big_ct = e.sample("uniform", key32("ct"), 1, 2 * B, L, 0)            # [B][2][L][N]
+    big_pt = e.sample("uniform", key32("pt"), 2, B, L, 0)                # [B][L][N]
     big_out = e.empty(B, 2, L, N)
-    GEN = 32  # generate/upload in groups to bound host memory
-    for base in range(0, B, GEN):
-        cnt = min(GEN, B - base)
-        big_ct.view(base * 2 * L * N, (cnt, 2, L, N)).upload(synth(rng, primes, N, cnt, 2, L))
-        big_pt.view(base * L * N, (cnt, L, N)).upload(synth(rng, primes, N, cnt, L))
-    key = e.to_device(synth(np.random.default_rng(0x6A1015), primes, N, L, 2, k))
+    nk = max(1, args.variant_keys)
+    big_key = e.sample("uniform", hashlib.sha256(b"hefx-bench:key").digest(), 3, 2 * L * nk, k, 0)   # nk x [L][2][k][N]
+    key_words = L * 2 * k * N
+    keyv = [big_key.view(i * key_words, (L, 2, k, N)) for i in range(nk)]
     cts = [big_ct.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
     pts = [big_pt.view(i * L * N, (L, N)) for i in range(B)]
     outs = [big_out.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
     elts = [3] * B  # galois_elt_from_step(1) = 3
-    keys = [key] * B
+    keys = [keyv[0]] * B
 
     def step():
         e.rotate_multiply_plain_batch(L, cts, elts, keys, pts, outs)
@@ -157,27 +313,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    ev0, ev1 = e.event(), e.event()
-    barrier()
-    t0 = time.perf_counter()
-    e.event_record(ev0)
-    for _ in range(args.steps):
-        step()
-    e.event_record(ev1)
-    barrier()
-    dt = time.perf_counter() - t0
-    gpu_ms = e.event_elapsed_ms(ev0, ev1)  # HIP events on the stream the launches are issued on
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        ev0, ev1 = e.event(), e.event()
+        barrier()
+        t0 = time.perf_counter()
+        e.event_record(ev0)
+        for _ in range(steps):
+            fn()
+        e.event_record(ev1)
+        barrier()
+        dt = time.perf_counter() - t0
+        gpu_ms = e.event_elapsed_ms(ev0, ev1)  # HIP events on the stream the launches are issued on
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, gpu_ms
 
-    # per-launch-kind durations: a short profiled pass (serial, HIP events between the five launches)
+    dt, gpu_ms = timed(step, args.steps, args.warmup)
+
+    # what was timed is checked: first and last item of the batch against the CPU oracle (rank 0)
+    verified = None
+    if rank == 0:
+        try:
+            from oracle import oracle as O
+            o = O.Oracle(N, primes)
+            hk = keyv[0].download()
+            verified = all(bool((outs[i].download() == o.rotate_mulplain(cts[i].download(), 3, hk, pts[i].download())).all())
+                           for i in (0, B - 1))
+        except Exception as ex:  # the oracle is the checker only; its absence must not hide the GPU number
+            verified = f"not checked: {ex!r}"
+
+    # per-launch-kind durations: a short profiled pass (serial, HIP events between the launches)
     e.profile_begin()
     step()
     stage_ms, nchunks = e.profile_end()
+
+    # secondary pass: the same batch with `nk` distinct steps / keys round-robin (a linear transform rotates by distinct
+    # steps with distinct keys: no key sharing between neighbouring items, nk keys competing for the caches)
+    variants = {}
+    if args.variant_keys > 1:
+        from oracle import oracle as O
+        velts = [O.galois_elt_from_step(N, 1 + (i % nk)) for i in range(B)]
+        vkeys = [keyv[i % nk] for i in range(B)]
+        vsteps = max(3, args.steps // 10)
+        vdt, _ = timed(lambda: e.rotate_multiply_plain_batch(L, cts, velts, vkeys, pts, outs), vsteps, 1)
+        variants[f"distinct_keys_{nk}"] = {"value": B * vsteps * world / vdt, "steps": vsteps,
+                                           "note": f"steps 1..{nk} round-robin, one uniform-random key each"}
+
+    lt = None
+    if args.lt and args.set == "C3":
+        dims = [int(x) for x in args.lt.split(",") if x]
+        del big_ct, big_pt, big_out, cts, pts, outs
+        lt = lt_sharded_bench(local_rank, world, dims, reps=3)
 
     if rank == 0:
         bytes_op = algorithmic_bytes_per_op(N, L)
@@ -189,16 +379,21 @@ def main():
         # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_bench_pmc_traffic.json")
-        if args.set == "C3" and os.path.exists(pmc):
-            try:
-                pb = json.load(open(pmc))["per_op_bytes"]
-                traffic = (pb["fetch_x2"] + pb["write"]) * B / 1e9  # GB per step, same unit basis as achieved*time
-                traffic_src = "profiles/r01_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes); GB per step"
-            except Exception:
-                pass
+        for rnd in ("r02", "r01"):
+            pmc = os.path.join(ROOT, "profiles", f"{rnd}_bench_pmc_traffic.json")
+            if args.set == "C3" and os.path.exists(pmc):
+                try:
+                    pb = json.load(open(pmc))["per_op_bytes"]
+                    traffic = (pb["fetch_x2"] + pb["write"]) * B / 1e9  # GB per step, same unit basis as achieved*time
+                    traffic_src = (f"profiles/{rnd}_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
+                                   "separate passes); GB per step")
+                    break
+                except Exception:
+                    pass
         dom = max(stage_ms, key=stage_ms.get)
         tot = sum(stage_ms.values())
+        valu = valu_bound_ops_per_s(N, primes, L)
+        per_gpu = value / world
         line = {
             "metric": "CKKS ciphertext rotate+plain-mult ops/sec at N=16384; HBM GB/s vs roofline",
             "value": value,
@@ -212,11 +407,12 @@ def main():
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
+            "verified": verified,
             "config": {
                 "workload": f"{args.set}: N={N}, coeff_modulus bits "
                             f"{[p.bit_length() for p in primes]}, level L={L} (k={k}); per step and per GPU "
                             f"{B} independent rotate_vector(step=1, direct Galois key)+multiply_plain, "
-                            "uniform random residues, inputs resident in HBM",
+                            "uniform random residues drawn on the device, inputs resident in HBM",
                 "batch_per_gpu": B,
                 "parallelism": f"{world} x independent ciphertext batches (no data-path collective)",
                 "algorithmic_bytes_per_op": bytes_op,
@@ -230,13 +426,29 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_GB_per_step": B * bytes_op / 1e9,  # same basis as `traffic` (one step = one launch sequence)
-                "launch": "one step = the 6-kernel key-switch sequence over the whole batch "
+                "launch": "one step = the key-switch launch sequence over the whole batch "
                           f"({nchunks} chunks); achieved = {B} ops x {bytes_op} B / {step_ms:.3f} ms (HIP events)",
                 "dominant_kernel": dom,
                 "kernel_avg_us": {kname: ms / max(nchunks, 1) * 1e3 for kname, ms in stage_ms.items()},
                 "kernel_share": {kname: ms / tot for kname, ms in stage_ms.items()},
-                "expected_first_limiter": "integer VALU (64-bit modmul emulated with v_mad_u64_u32)",
+                "note": "frac prices the ALGORITHMIC bytes (SURVEY 8d), 70 % of which are the Galois key; in the "
+                        "headline run every item shares one key, which then lives in L2 / Infinity Cache -- an "
+                        "algorithmic-bytes equivalent, not measured HBM traffic (that is `traffic`); see "
+                        "variants.distinct_keys_* for the run without key sharing",
+                "valu": {
+                    "bound": "valu",
+                    "unit": "rotate+multiply_plain ops/s per GPU",
+                    "achieved": per_gpu,
+                    "peak": valu["peak_ops_per_s"],
+                    "frac": per_gpu / valu["peak_ops_per_s"],
+                    "model": f"{valu['int_transforms']} integer-policy + {valu['f64_transforms']} FP64-policy transforms "
+                             f"x (N/2) log2 N butterflies, {VALU_CYC_INT:.0f} / {VALU_CYC_F64:.0f} SIMD cycles per "
+                             f"wave-butterfly (profiles/r01_valu_issue_rates.txt), {SIMDS} SIMDs at {CLOCK_HZ / 1e9:.1f} "
+                             "GHz; butterflies only (no loads, exchanges, MAC, epilogues)",
+                },
             },
+            "variants": variants,
+            "lt_sharded": lt,
         }
         if args.cpu_seconds > 0 and world == 1:
             try:

@@ -145,10 +145,24 @@ int hefx_relinearize(hefx_context *ctx, int L, const uint64_t *d_ct3, const uint
 int hefx_relinearize_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct3,
                            const uint64_t *d_relin_key, uint64_t *const *d_ct2, void *stream);
 
-/* ---- K8: Evaluator::rescale_to_next_inplace (matrix_multiplication.cpp:71-72; helper.h:441,543):
- *      L rows -> L-1 rows per poly, SEAL 3.4.x floor variant (App. A.9).  `count` contiguous cts. */
+/* ---- K8: Evaluator::rescale_to_next_inplace (matrix_multiplication.cpp:71-72; helper.h:441,543; polynomial.cpp:93,
+ *      195,333; logistic_regression_ckks.cpp:119,189,239,321): L rows -> L-1 rows per poly, `count` contiguous cts.
+ *      The division by the dropped prime q_l exists in two forms and which one SEAL 3.4.5 uses is the one item of
+ *      SURVEY App. A.9 that could not be verified offline, so both are built (and both are bit-exact against the
+ *      oracle's orc_rescale(rounded = 0 / 1)):
+ *        HEFX_RESCALE_FLOOR  out_j = (c_j - [c_l]_(q_j)) * q_l^-1  -- App. A.9's statement of 3.4.x; the default.
+ *        HEFX_RESCALE_ROUND  out_j = (c_j - ([c_l + q_l/2]_(q_l) mod q_j - (q_l/2 mod q_j))) * q_l^-1 -- round to
+ *                            nearest, SEAL >= 3.5's RNSTool::divide_and_round_q_last_inplace.
+ *      hefx_rescale_to_next uses the context's mode (hefx_set_rescale_mode; environment HEFX_RESCALE=round|floor
+ *      presets it at hefx_context_create); hefx_rescale_to_next_mode names it per call. */
+#define HEFX_RESCALE_FLOOR 0
+#define HEFX_RESCALE_ROUND 1
 int hefx_rescale_to_next(hefx_context *ctx, int L, int size, int count, const uint64_t *d_in, uint64_t *d_out,
                          void *stream);
+int hefx_rescale_to_next_mode(hefx_context *ctx, int L, int size, int count, const uint64_t *d_in, uint64_t *d_out,
+                              int mode, void *stream);
+int hefx_set_rescale_mode(hefx_context *ctx, int mode);
+int hefx_get_rescale_mode(const hefx_context *ctx);
 /* ---- K9: Evaluator::mod_switch_to_next / mod_switch_to for CKKS ct and pt (matrix_multiplication.cpp:112):
  *      drop trailing RNS rows, L_in -> L_out, npoly polys. */
 int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint64_t *d_in, uint64_t *d_out,

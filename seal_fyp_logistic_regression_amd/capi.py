@@ -66,6 +66,9 @@ _SIGS = {
     "hefx_relinearize": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "hefx_relinearize_batch": (_i, [_vp, _i, _i, _pp, _vp, _pp, _vp]),
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "hefx_rescale_to_next_mode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hefx_set_rescale_mode": (_i, [_vp, _i]),
+    "hefx_get_rescale_mode": (_i, [_vp]),
     "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
     "hefx_linear_transform_plain": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),

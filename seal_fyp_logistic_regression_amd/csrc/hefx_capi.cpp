@@ -35,6 +35,31 @@ static int hipfail(hipError_t e, const char *what)
         if (_e != hipSuccess) return hipfail(_e, #expr); \
     } while (0)
 
+// Scoped device selection: every entry point runs with the context's device current and puts the caller's device
+// back on return -- a process may hold contexts on several GPUs, and torch (or any other HIP user of the thread) may
+// have switched the current device since hefx_context_create.  hipGetDevice is a thread-local read; hipSetDevice is
+// only called when the devices differ.
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuard()
+    {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+    DevGuard(const DevGuard &) = delete;
+    DevGuard &operator=(const DevGuard &) = delete;
+};
+#define CTXCHK(c)                                                \
+    do {                                                         \
+        if (!(c)) return fail(HEFX_ERR_INVALID, "null context"); \
+    } while (0);                                                 \
+    DevGuard _devguard((c)->device)
+
 // ---------------------------------------------------------------------------------------------
 // host number theory (context creation only; independent of oracle/)
 // ---------------------------------------------------------------------------------------------
@@ -119,7 +144,9 @@ struct hefx_context {
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
     int chunk = 0;  // items per launch sequence; 0 = sized from the scratch budget (HEFX_CHUNK overrides)
-    int *d_flag = nullptr;  // [0] transparent count, [1] per-call "non-zero seen"
+    int *d_flag = nullptr;  // [0] transparent count, [1 + i] "non-zero seen beyond c0" of ciphertext i of the call
+    int flag_cap = 1 + 4096;
+    int rescale_mode = HEFX_RESCALE_FLOOR;  // default of hefx_rescale_to_next (HEFX_RESCALE=round|floor presets it)
     static constexpr int MAX_STREAMS = 4;
     hipStream_t streams[MAX_STREAMS] = {};  // internal streams for chunk pipelining
     hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {};
@@ -223,7 +250,11 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(HEFX_ERR_HIP, "no HIP device available (this library has no CPU fallback)");
     if (device < 0 || device >= ndev) return fail(HEFX_ERR_INVALID, "bad device index");
-    HIPCHK(hipSetDevice(device));
+    DevGuard devguard(device);  // tables, streams and events are created on `device`; the caller's device is restored
+    {
+        int cur = -1;
+        if (hipGetDevice(&cur) != hipSuccess || cur != device) return fail(HEFX_ERR_HIP, "hipSetDevice failed");
+    }
 
     hefx_context *c = new hefx_context();
     c->device = device;
@@ -333,8 +364,8 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     }
     hipError_t e = hipMalloc(&c->d_tables, total);
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, 2 * sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, 2 * sizeof(int));
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, c->flag_cap * sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_flag, 0, c->flag_cap * sizeof(int));
     for (int s = 0; s < hefx_context::MAX_STREAMS && e == hipSuccess; ++s) {
         e = hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[s], hipEventDisableTiming);
@@ -346,6 +377,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
+    if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "round") ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR;
     if (const char *ev = getenv("HEFX_STREAMS")) {
         const int v = atoi(ev);
         c->use_streams = v != 0;
@@ -383,7 +415,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
 extern "C" void hefx_context_destroy(hefx_context *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->device);
+    DevGuard devguard(c->device);
     (void)hipDeviceSynchronize();
     for (auto &sl : c->pool_slabs)  // every slab, parked or not: the context's memory ends with the context
         if (sl.base) (void)hipFree(sl.base);
@@ -418,10 +450,6 @@ extern "C" uint64_t hefx_psi(const hefx_context *c, int j) { return (c && j >= 0
 // ---------------------------------------------------------------------------------------------
 // memory helpers
 // ---------------------------------------------------------------------------------------------
-#define CTXCHK(c)                                                \
-    do {                                                         \
-        if (!(c)) return fail(HEFX_ERR_INVALID, "null context"); \
-    } while (0)
 
 // Pooled device memory.  Every evaluator call of the shim / seal.py allocates its result; hipMalloc costs ~4 us (a
 // NAF-expanded 1000-diagonal transform allocates 3800 intermediate ciphertexts: 13 ms of hipMalloc around 4.5 ms of
@@ -461,7 +489,6 @@ extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
     if (!d_ptr) return fail(HEFX_ERR_INVALID, "null out pointer");
     const size_t rounded = ((bytes ? bytes : 8) + 255) & ~(size_t)255;
     if (!c->pool_cap) {
-        HIPCHK(hipSetDevice(c->device));
         HIPCHK(hipMalloc(d_ptr, rounded));
         return HEFX_OK;
     }
@@ -472,7 +499,6 @@ extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
         if (next < 1) next = 1;
         int n = next;
         while (n > 1 && (size_t)n * rounded > ((size_t)256 << 20)) n >>= 1;
-        HIPCHK(hipSetDevice(c->device));
         void *base = nullptr;
         hipError_t e = hipMalloc(&base, (size_t)n * rounded);
         if (e != hipSuccess) {  // out of memory: give back what is parked, then ask for a single block
@@ -634,20 +660,36 @@ extern "C" int hefx_reduce_canonical(hefx_context *c, int L, int size, uint64_t 
     return ew_common(c, EW_REDUCE, L, size, 1, d, nullptr, d, stream);
 }
 
-// flag[1] == 0 after a multiply_plain means nothing beyond c0 was non-zero: count it in flag[0]
-__global__ void transparent_finalize_kernel(int *flag)
+// flag[1 + i] == 0 after a multiply_plain over `count` ciphertexts means nothing beyond c0 of ciphertext i was
+// non-zero: count it in flag[0]; the per-ciphertext marks are cleared for the next call
+__global__ void transparent_finalize_kernel(int *flag, int count)
 {
-    if (flag[1] == 0) flag[0] += 1;
-    flag[1] = 0;
+    int zeros = 0;
+    for (int i = threadIdx.x; i < count; i += blockDim.x) {
+        if (flag[1 + i] == 0) ++zeros;
+        flag[1 + i] = 0;
+    }
+    if (zeros) atomicAdd(&flag[0], zeros);
 }
 
 extern "C" int hefx_multiply_plain(hefx_context *c, int L, int size, int count, const uint64_t *ct,
                                    const uint64_t *pt, uint64_t *out, void *stream)
 {
+    CTXCHK(c);
+    if (count >= 1 && size > 1 && c->flag_cap < 1 + count) {  // [0] transparent count, [1..] one mark per ciphertext
+        int *nf = nullptr;
+        HIPCHK(hipMalloc((void **)&nf, sizeof(int) * (size_t)(1 + count)));
+        HIPCHK(hipMemsetAsync(nf, 0, sizeof(int) * (size_t)(1 + count), (hipStream_t)stream));
+        HIPCHK(hipMemcpyAsync(nf, c->d_flag, sizeof(int), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIPCHK(hipStreamSynchronize((hipStream_t)stream));
+        HIPCHK(hipFree(c->d_flag));
+        c->d_flag = nf;
+        c->flag_cap = 1 + count;
+    }
     int rc = ew_common(c, EW_MULPLAIN, L, size, count, ct, pt, out, stream);
     if (rc) return rc;
     if (size > 1) {
-        hipLaunchKernelGGL(transparent_finalize_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, c->d_flag);
+        hipLaunchKernelGGL(transparent_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, c->d_flag, count);
         HIPCHK(hipGetLastError());
     }
     return HEFX_OK;
@@ -657,10 +699,10 @@ extern "C" int hefx_check_transparent(hefx_context *c, void *stream)
 {
     CTXCHK(c);
     int h[2] = {0, 0};
-    HIPCHK(hipMemcpyAsync(h, c->d_flag, sizeof h, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    HIPCHK(hipMemcpyAsync(h, c->d_flag, sizeof(int), hipMemcpyDeviceToHost, (hipStream_t)stream));
     HIPCHK(hipStreamSynchronize((hipStream_t)stream));
     if (h[0]) {
-        HIPCHK(hipMemsetAsync(c->d_flag, 0, 2 * sizeof(int), (hipStream_t)stream));
+        HIPCHK(hipMemsetAsync(c->d_flag, 0, sizeof(int), (hipStream_t)stream));
         return fail(HEFX_ERR_TRANSPARENT, "result ciphertext is transparent");
     }
     return HEFX_OK;
@@ -881,6 +923,18 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             if (ct_in[i] != ct_in[0] || ct_out[i] == ct_in[0])
                 return fail(HEFX_ERR_INVALID, "hoisted batch: one shared source, never overwritten");
     }
+    // Validate the WHOLE batch and resolve every gather table before anything is submitted: an argument error must
+    // leave no chunk in flight, no forked stream unjoined and no ring slot marked busy.
+    std::vector<const uint32_t *> perms(relin ? 0 : (size_t)n);
+    for (int i = 0; i < n; ++i) {
+        if (!ct_in[i] || !ct_out[i]) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
+        if (relin) {
+            if (ct_in[i] == ct_out[i]) return fail(HEFX_ERR_INVALID, "relinearize input and output must not alias");
+        } else {
+            if (!keys[i]) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
+            if (int rc = get_perm(c, elts[i], &perms[i])) return rc;
+        }
+    }
     const int cmax = n < chunk ? n : chunk;
     const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax));
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
@@ -891,28 +945,31 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         for (int s = 0; s < ns; ++s) HIPCHK(hipStreamWaitEvent(c->streams[s], c->ev_fork, 0));
     }
     const size_t N = c->n;
+    // from here on only HIP runtime failures can occur; they stop the submission, and the internal streams are still
+    // joined to the caller's stream below so that whatever was launched stays ordered before the caller's next work
+    hipError_t herr = hipSuccess;
+    const char *hwhat = "";
+#define KS_TRY(expr)                       \
+    if (herr == hipSuccess) {              \
+        herr = (expr);                     \
+        if (herr != hipSuccess) hwhat = #expr; \
+    }
     int ci = 0;
-    for (int base = 0; base < n; base += chunk, ++ci) {
+    for (int base = 0; base < n && herr == hipSuccess; base += chunk, ++ci) {
         const int cnt = (n - base < chunk) ? n - base : chunk;
         const unsigned slot = c->ring_next++ % KS_RING;
-        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));  // its previous chunk has drained
+        if (c->ring_busy[slot]) {  // its previous chunk has drained
+            KS_TRY(hipEventSynchronize(c->ring_ev[slot]));
+            c->ring_busy[slot] = false;
+        }
         KsItem *hb = c->h_items + (size_t)slot * KS_MAX_CHUNK, *db = c->d_items + (size_t)slot * KS_MAX_CHUNK;
         for (int i = 0; i < cnt; ++i) {
             KsItem &it = hb[i];
             it.c_in = (const u64 *)ct_in[base + i];
             it.c_out = (u64 *)ct_out[base + i];
-            if (!it.c_in || !it.c_out) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
             it.pt = pts ? (const u64 *)pts[base + i] : nullptr;
-            if (relin) {
-                if (it.c_in == it.c_out)
-                    return fail(HEFX_ERR_INVALID, "relinearize input and output must not alias");
-                it.key = (const u64 *)single_key;
-                it.perm = nullptr;
-            } else {
-                it.key = (const u64 *)keys[base + i];
-                if (!it.key) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
-                if (int rc = get_perm(c, elts[base + i], &it.perm)) return rc;
-            }
+            it.key = relin ? (const u64 *)single_key : (const u64 *)keys[base + i];
+            it.perm = relin ? nullptr : perms[base + i];
         }
         KsScratch S;
         S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
@@ -924,11 +981,12 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         KsProf *prof = nullptr;
         if (c->profiling) {
             const size_t need = (size_t)c->prof.used + 8 + 2 * ((size_t)cnt / sub + 1);
-            while (c->prof_events.size() < need) {
+            while (c->prof_events.size() < need && herr == hipSuccess) {
                 hipEvent_t e;
-                HIPCHK(hipEventCreate(&e));
-                c->prof_events.push_back(e);
+                KS_TRY(hipEventCreate(&e));
+                if (herr == hipSuccess) c->prof_events.push_back(e);
             }
+            if (herr != hipSuccess) break;
             c->prof_stage.resize(c->prof_events.size());
             c->prof.ev = c->prof_events.data();
             c->prof.stage = c->prof_stage.data();
@@ -937,17 +995,19 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             ++c->prof_chunks;
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
-        HIPCHK(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        HIPCHK(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, cs, prof));
-        HIPCHK(hipEventRecord(c->ring_ev[slot], cs));
-        c->ring_busy[slot] = true;
+        KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
+        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, cs, prof));
+        if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
+#undef KS_TRY
     if (two) {
         for (int s = 0; s < ns; ++s) {
-            HIPCHK(hipEventRecord(c->ev_join[s], c->streams[s]));
-            HIPCHK(hipStreamWaitEvent(user, c->ev_join[s], 0));
+            hipError_t e = hipEventRecord(c->ev_join[s], c->streams[s]);
+            if (e == hipSuccess) e = hipStreamWaitEvent(user, c->ev_join[s], 0);
+            if (e != hipSuccess && herr == hipSuccess) herr = e, hwhat = "join of the internal streams";
         }
     }
+    if (herr != hipSuccess) return hipfail(herr, hwhat);
     return HEFX_OK;
 }
 
@@ -985,19 +1045,40 @@ extern "C" int hefx_relinearize_batch(hefx_context *c, int L, int n, const uint6
 // ---------------------------------------------------------------------------------------------
 // rescale / mod drop
 // ---------------------------------------------------------------------------------------------
-extern "C" int hefx_rescale_to_next(hefx_context *c, int L, int size, int count, const uint64_t *in, uint64_t *out,
-                                    void *stream)
+static int rescale_common(hefx_context *c, int L, int size, int count, const uint64_t *in, uint64_t *out, int mode,
+                          void *stream)
 {
     CTXCHK(c);
     if (int rc = check_level(c, L)) return rc;
     if (L < 2) return fail(HEFX_ERR_INVALID, "cannot rescale at the last level");
     if (size < 1 || count < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad rescale arguments");
     if (in == out) return fail(HEFX_ERR_INVALID, "rescale input and output must not alias");
+    if (mode != HEFX_RESCALE_FLOOR && mode != HEFX_RESCALE_ROUND) return fail(HEFX_ERR_INVALID, "bad rescale mode");
     if (c->logn < 11) return fail(HEFX_ERR_UNSUPPORTED, "key switching / rescale need poly_degree >= 2048");
     if (int rc = ensure_scratch(c, (size_t)c->n * size * count)) return rc;
-    HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, c->scratch, (hipStream_t)stream));
+    HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, c->scratch, mode == HEFX_RESCALE_ROUND,
+                          (hipStream_t)stream));
     return HEFX_OK;
 }
+extern "C" int hefx_rescale_to_next(hefx_context *c, int L, int size, int count, const uint64_t *in, uint64_t *out,
+                                    void *stream)
+{
+    CTXCHK(c);
+    return rescale_common(c, L, size, count, in, out, c->rescale_mode, stream);
+}
+extern "C" int hefx_rescale_to_next_mode(hefx_context *c, int L, int size, int count, const uint64_t *in,
+                                         uint64_t *out, int mode, void *stream)
+{
+    return rescale_common(c, L, size, count, in, out, mode, stream);
+}
+extern "C" int hefx_set_rescale_mode(hefx_context *c, int mode)
+{
+    CTXCHK(c);
+    if (mode != HEFX_RESCALE_FLOOR && mode != HEFX_RESCALE_ROUND) return fail(HEFX_ERR_INVALID, "bad rescale mode");
+    c->rescale_mode = mode;
+    return HEFX_OK;
+}
+extern "C" int hefx_get_rescale_mode(const hefx_context *c) { return c ? c->rescale_mode : HEFX_ERR_INVALID; }
 
 extern "C" int hefx_mod_drop(hefx_context *c, int L_in, int L_out, int npoly, const uint64_t *in, uint64_t *out,
                              void *stream)

@@ -8,6 +8,21 @@
 
 namespace hefx {
 
+// hipFuncSetAttribute (the > 64 KiB dynamic-LDS opt-in) is per device: launchers keep one of these per kernel family
+// and apply the attributes the first time they run on each device of the process.
+struct PerDeviceOnce {
+    static constexpr int MAX_DEV = 64;
+    bool done[MAX_DEV] = {};
+    bool first()
+    {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) return true;  // unknown: just re-apply
+        if (done[dev]) return false;
+        done[dev] = true;
+        return true;
+    }
+};
+
 // Device-resident constant tables of one context (all pointers are device pointers).
 struct DevTables {
     const ulonglong2 *tw;      // [k][N]  forward twiddles {w, floor(w*2^64/q)}, w[bitrev(i)] = psi^i
@@ -136,6 +151,6 @@ hipError_t warm_keyswitch(hipStream_t s);
 hipError_t warm_encode(hipStream_t s);
 hipError_t warm_sample(hipStream_t s);
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
-                          hipStream_t s);
+                          bool rounded, hipStream_t s);
 
 }  // namespace hefx

@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256) void elementwise_kernel(DevTables T, int L, in
 {
     const int logn = T.logn;
     const size_t pairs_per_row = (size_t)1 << (logn - 1);
-    bool nonzero_beyond_c0 = false;
+    long long flagged_ct = -1;  // last ciphertext this wave has already marked as not transparent
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
          w += (size_t)gridDim.x * blockDim.x) {
         const size_t row = w >> (logn - 1);
@@ -115,7 +115,17 @@ __global__ __launch_bounds__(256) void elementwise_kernel(DevTables T, int L, in
             if (OP == EW_MULPLAIN) {
                 r.x = mulmod(x.x, y.x, mc);
                 r.y = mulmod(x.y, y.y, mc);
-                if (poly > 0 && (r.x | r.y)) nonzero_beyond_c0 = true;
+                // transparent-ciphertext detection (SEAL is_transparent), PER CIPHERTEXT: flag[1 + ct] is set when any
+                // word of a poly beyond c0 is non-zero.  A wave's 64 pairs lie in one row (rows are multiples of 64
+                // pairs and the stride is a multiple of the block), so the vote and `ct` are wave-uniform; all writers
+                // store the same value.
+                if (poly > 0) {
+                    const long long ct = (long long)(row / ((size_t)L * size));
+                    if (ct != flagged_ct && __any((r.x | r.y) != 0)) {
+                        if ((threadIdx.x & 63) == 0) flag[1 + ct] = 1;
+                        flagged_ct = ct;
+                    }
+                }
             } else {  // EW_ADDPLAIN: only c0 gets the plaintext
                 if (poly == 0) {
                     r.x = addmod(x.x, y.x, mc.q);
@@ -126,11 +136,6 @@ __global__ __launch_bounds__(256) void elementwise_kernel(DevTables T, int L, in
             }
         }
         out[w] = r;
-    }
-    if (OP == EW_MULPLAIN) {
-        // transparent-ciphertext detection (SEAL is_transparent): flag[1] is set if ANY word of a poly
-        // beyond c0 is non-zero; all writers store the same value.
-        if (__any(nonzero_beyond_c0) && (threadIdx.x & 63) == 0) flag[1] = 1;
     }
 }
 

@@ -271,12 +271,16 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
 
 // ------------------------------------------------------------------------------------------------
 // (3h) hoisted MAC: all items of the chunk rotate the SAME source ciphertext (the d-1 rotations of a linear
-// transform with direct Galois keys).  The digit decomposition commutes with the Galois permutation --
-// [perm_g(c1)]_(q_i) = perm_g([c1]_(q_i)) coefficient-wise, and NTT_m(a(X^g)) = perm_g(NTT_m(a)) -- so the digit x
-// modulus products x[i][jj] of the UNPERMUTED source are computed once ((1),(2) with one item) and every item
-// reads them through its gather table:  acc[b][c][jj][w] = sum_i x[i][jj][perm_b[w]] * key_b[i][c][m][w].
-// Same integers as the per-item path, hence the same bits; per item only the MAC and the mod-down remain
-// ((L+1)(L+2) -> 2 + 2L transforms).  The gathered rows are L2-resident (one source), the keys stream from HBM.
+// transform with direct Galois keys).  NTT_m(a(X^g)) = perm_g(NTT_m(a)), so the digit x modulus products x[i][jj] of
+// the UNPERMUTED source are computed once ((1),(2) with one item) and every item reads them through its gather table:
+//   acc[b][c][jj][w] = sum_i x[i][jj][perm_b[w]] * key_b[i][c][m][w].
+// This is a DIFFERENT (equally valid) lift than the per-item path, NOT the same bits: where the automorphism negates a
+// coefficient a of digit i, SEAL decomposes the rotated polynomial and lifts q_i - a (a positive integer) to modulus
+// m, whereas permuting the transformed digit carries -(a mod m); the two differ by q_i mod m.  Both are exact key
+// switches of the same rotated ciphertext with the same noise bound (DESIGN.md "Hoisted rotations"); parity for this
+// mode is against the oracle's statement of THIS algorithm (orc_apply_galois_hoisted).  Per item only the MAC and the
+// mod-down remain ((L+1)(L+2) -> 2 + 2L transforms).  The gathered rows are L2-resident (one source), the keys stream
+// from HBM.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const KsItem *__restrict__ items, int L,
                                                              KsScratch S)
@@ -618,8 +622,8 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         set_lds(ks_intt_digits_kernel<LOGN>, lds);
         set_lds(ks_ntt_digits_kernel<LOGN>, lds);
         set_lds(ks_moddown_intt_kernel<LOGN>, lds);
@@ -630,7 +634,6 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             fprintf(stderr, "[hefx] ks_ntt_digits_kernel<%d>: %d threads, %zu B LDS -> %d workgroups/CU\n", LOGN, SC::T,
                     lds, nb);
         }
-        attr_done = true;
     }
     const int rl = relin ? 1 : 0;
     // optional profiling (hefx_profile_*): an event before every launch, tagged with its stage
@@ -666,11 +669,8 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
     if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
         if constexpr (LOGN <= 14) {
-            static bool fattr = false;
-            if (!fattr) {
-                set_lds(ks_ntt_mac_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
-                fattr = true;
-            }
+            static PerDeviceOnce fattr;
+            if (fattr.first()) set_lds(ks_ntt_mac_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
             mark(6);
             hipLaunchKernelGGL((ks_ntt_mac_kernel<LOGN>), dim3(group_grid(n, L + 1)), dim3(FusedCfg<LOGN>::T),
                                FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, n, scr);
@@ -730,13 +730,12 @@ static hipError_t launch_lt2_decompose_t(const DevTables &T, int L, const KsItem
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         set_lds(ks_intt_digits_kernel<LOGN>, lds);
         set_lds(ks_ntt_digits_kernel<LOGN>, lds);
         set_lds(ks_moddown_intt_kernel<LOGN>, lds);
         set_lds(ks_moddown_finish_kernel<LOGN>, lds);
-        attr_done = true;
     }
     const int chunks = (nrot + LT2_CHUNK - 1) / LT2_CHUNK;
     hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, src_item, L, 0, 0, 1, scr);
@@ -800,11 +799,14 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 }
 
 // ------------------------------------------------------------------------------------------------
-// K8: rescale_to_next, SEAL 3.4.x floor variant (App. A.9): per poly 1 INTT + (L-1) NTT.
+// K8: rescale_to_next (App. A.9): per poly 1 INTT + (L-1) NTT.  Two divisions by the dropped prime q_l, selected per
+// call: rounded == 0  floor, out_j = (c_j - [c_l]_(q_j)) * q_l^-1          (SEAL 3.4.x as SURVEY App. A.9 states it)
+//       rounded != 0  round, out_j = (c_j - ([c_l + q_l/2]_(q_l) mod q_j - (q_l/2 mod q_j))) * q_l^-1   (SEAL >= 3.5,
+//                     divide_and_round_q_last) -- the same plumbing as the key-switch mod-down by P.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt_kernel(DevTables T, int L, int rows, const u64 *in,
-                                                                       u64 *d)
+                                                                       u64 *d, int rounded)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -818,13 +820,14 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt
     u64 v[16];
     split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, L - 1), T.mods[L - 1], T.modsf[L - 1], t, h);
     u64 *__restrict__ dd = d + (size_t)p * SC::N + (size_t)h * SC::H;
+    const u64 ql = T.mods[L - 1].q, half = rounded ? ql >> 1 : 0;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
+    for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = csub(v[r] + half, ql);
 }
 
 template <int LOGN>
 __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_finish_kernel(DevTables T, int L, int rows, const u64 *in,
-                                                                         const u64 *d, u64 *out)
+                                                                         const u64 *d, u64 *out, int rounded)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -839,7 +842,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     const ulonglong2 qinv = T.invmod[(size_t)(L - 1) * T.k + j];
     const u64 *__restrict__ dd = d + (size_t)poly * SC::N;
     u64 v[16];
-    const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, false, 0};
+    // rounded: subtract (q_l/2 mod q_j) from the reduced remainder, in the row's arithmetic policy
+    const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, rounded != 0, T.halfmod[(size_t)(L - 1) * T.k + j]};
     auto ld = [&](int r, u64 &x, u64 &y) {
         const int e = eo(C::idx_nat(t, r), SC::H);
         x = dd[e];
@@ -861,28 +865,27 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
 
 template <int LOGN>
 static hipError_t launch_rescale_t(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out,
-                                   u64 *scratch_d, hipStream_t s)
+                                   u64 *scratch_d, bool rounded, hipStream_t s)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         set_lds(rs_intt_kernel<LOGN>, lds);
         set_lds(rs_finish_kernel<LOGN>, lds);
-        attr_done = true;
     }
     const int polys = size * count;
     hipLaunchKernelGGL((rs_intt_kernel<LOGN>), dim3(split_grid(polys)), dim3(SC::T), lds, s, T, L, polys, in,
-                       scratch_d);
+                       scratch_d, rounded ? 1 : 0);
     hipLaunchKernelGGL((rs_finish_kernel<LOGN>), dim3(split_grid(polys * (L - 1))), dim3(SC::T), lds, s, T, L,
-                       polys * (L - 1), in, scratch_d, out);
+                       polys * (L - 1), in, scratch_d, out, rounded ? 1 : 0);
     return hipGetLastError();
 }
 
 hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
-                          hipStream_t s)
+                          bool rounded, hipStream_t s)
 {
-#define CALL(LN) launch_rescale_t<LN>(T, L, size, count, in, out, scratch_d, s)
+#define CALL(LN) launch_rescale_t<LN>(T, L, size, count, in, out, scratch_d, rounded, s)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }
@@ -927,11 +930,10 @@ hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, 
                               int mod_first, hipStream_t s)
 {
     using SC = SplitCfg<15>;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_once;
+    if (attr_once.first()) {
         set_lds(ntt_split_rows_kernel<15, false>, SC::LDS_BYTES);
         set_lds(ntt_split_rows_kernel<15, true>, SC::LDS_BYTES);
-        attr_done = true;
     }
     const int rows = npoly * nrows;
     if (inverse)

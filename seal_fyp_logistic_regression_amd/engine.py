@@ -272,12 +272,25 @@ class Engine:
             capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
-    def rescale_to_next(self, L, size, ct, out=None, count=1, stream=None):
+    def rescale_to_next(self, L, size, ct, out=None, count=1, stream=None, rounded=None):
+        """rounded=None: the context's mode (set_rescale_rounded / HEFX_RESCALE); True / False: hefx_rescale_to_next_mode"""
         if out is None:
             shape = (size, L - 1, self.N) if count == 1 else (count, size, L - 1, self.N)
             out = DeviceArray(self, shape)
-        capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, count, ct.ptr, out.ptr, stream))
+        if rounded is None:
+            capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, count, ct.ptr, out.ptr, stream))
+        else:
+            capi.check(capi.lib().hefx_rescale_to_next_mode(self._h, L, size, count, ct.ptr, out.ptr,
+                                                            1 if rounded else 0, stream))
         return out
+
+    def set_rescale_rounded(self, rounded: bool):
+        """context default of rescale_to_next: False = floor (SEAL 3.4.x per SURVEY App. A.9), True = round (>= 3.5)"""
+        capi.check(capi.lib().hefx_set_rescale_mode(self._h, 1 if rounded else 0))
+
+    @property
+    def rescale_rounded(self) -> bool:
+        return capi.lib().hefx_get_rescale_mode(self._h) == 1
 
     def mod_drop(self, L_in, L_out, npoly, x, out=None, stream=None):
         out = out if out is not None else DeviceArray(self, (npoly, L_out, self.N))

@@ -67,6 +67,20 @@ class CoeffModulus:
         return [table[b].pop() for b in bit_sizes]
 
     @staticmethod
+    def BFVDefault(poly_modulus_degree: int) -> List[int]:
+        """SEAL's hard-coded 128-bit-security defaults (util/globals.cpp) for the degrees the
+        reference uses -- /root/reference/vector_ops.cpp:208 builds its CKKS context (BASELINE config 1) on this chain."""
+        table = {
+            4096: [0xffffee001, 0xffffc4001, 0x1ffffe0001],
+            8192: [0x7fffffd8001, 0x7fffffc8001, 0xfffffffc001, 0xffffff6c001, 0xfffffebc001],
+            16384: [0xfffffffd8001, 0xfffffffa0001, 0xfffffff00001, 0x1fffffff68001, 0x1fffffff50001,
+                    0x1ffffffee8001, 0x1ffffffea0001, 0x1ffffffe88001, 0x1ffffffe48001],
+        }
+        if poly_modulus_degree not in table:
+            raise ValueError("poly_modulus_degree is not supported by BFVDefault")
+        return list(table[poly_modulus_degree])
+
+    @staticmethod
     def MaxBitCount(poly_modulus_degree: int) -> int:
         return {1024: 27, 2048: 54, 4096: 109, 8192: 218, 16384: 438, 32768: 881}[poly_modulus_degree]
 
@@ -173,6 +187,16 @@ class GpuBackend:
 
     def rescale(self, L, size, ct):
         return self.engine.rescale_to_next(L, size, ct)
+
+    # floor (SEAL 3.4.x as SURVEY App. A.9 states it, default) or round-to-nearest (SEAL >= 3.5) division in
+    # rescale_to_next: the one [M]-confidence semantic of the bit-exact path, switchable per context
+    @property
+    def rescale_rounded(self) -> bool:
+        return self.engine.rescale_rounded
+
+    @rescale_rounded.setter
+    def rescale_rounded(self, v: bool):
+        self.engine.set_rescale_rounded(bool(v))
 
     def mod_drop(self, L_in, L_out, npoly, x):
         return self.engine.mod_drop(L_in, L_out, npoly, x)
@@ -379,9 +403,10 @@ def _key32(seed) -> bytes:
 class KeyGenerator:
     """Randomness from the backend's counter-mode sampler (hefx_sample_*: ChaCha20 keystream, SEAL 3.4.5's
     distributions; SEAL seeds from random_device, so keys are inputs to parity, never outputs); all modular
-    arithmetic on the backend (App. A.11).  seed=None draws the sampler key from the OS."""
+    arithmetic on the backend (App. A.11).  The default seed=None draws the sampler key from the OS (os.urandom);
+    an integer seed is for tests and tools only -- it makes the secret key publicly derivable."""
 
-    def __init__(self, context: SEALContext, seed: Optional[int] = 1):
+    def __init__(self, context: SEALContext, seed: Optional[int] = None):
         self.ctx = context
         self._key32, self._stream = _key32(seed), 0
         be, k = context.backend, context.k
@@ -476,9 +501,10 @@ class KeyGenerator:
 
 class Encryptor:
     """(pk0*u + e0 + m, pk1*u + e1) over the plaintext's level in ONE engine call (hefx_encrypt: sampling, NTT and
-    the dyadic arithmetic all on the GPU).  seed=None draws the sampler key from the OS."""
+    the dyadic arithmetic all on the GPU; SURVEY 8f rank 2).  The default seed=None draws the sampler key from the OS;
+    an integer seed (tests only) replays the same (u, e0, e1) for the i-th ciphertext of every such instance."""
 
-    def __init__(self, context: SEALContext, public_key: np.ndarray, seed: Optional[int] = 2):
+    def __init__(self, context: SEALContext, public_key: np.ndarray, seed: Optional[int] = None):
         self.ctx, self.pk = context, public_key
         self._pk_dev = context.backend.from_host(np.ascontiguousarray(public_key))  # [2][k][N]
         self._key32, self._stream = _key32(seed), 0

@@ -120,8 +120,10 @@ class OracleBackend:
     def relinearize(self, L, ct3, key):
         return self.o.relinearize(self._ct(ct3, 3, L), key)
 
+    rescale_rounded = False  # floor (3.4.x per App. A.9) unless a test switches the twin to the rounded variant
+
     def rescale(self, L, size, ct):
-        return self.o.rescale(self._ct(ct, size, L))
+        return self.o.rescale(self._ct(ct, size, L), rounded=self.rescale_rounded)
 
     def mod_drop(self, L_in, L_out, npoly, x):
         return np.ascontiguousarray(np.ascontiguousarray(x).reshape(npoly, L_in, self.N)[:, :L_out, :])

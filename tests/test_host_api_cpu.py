@@ -20,7 +20,7 @@ def make(N, bits, seed=1):
     parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
     ctx = S.SEALContext.Create(parms, backend=OracleBackend(N, parms.coeff_modulus()))
     kg = S.KeyGenerator(ctx, seed)
-    return dict(ctx=ctx, kg=kg, enc=S.Encryptor(ctx, kg.public_key()), dec=S.Decryptor(ctx, kg.secret_key()),
+    return dict(ctx=ctx, kg=kg, enc=S.Encryptor(ctx, kg.public_key(), seed + 1), dec=S.Decryptor(ctx, kg.secret_key()),
                 encoder=S.CKKSEncoder(ctx), ev=S.Evaluator(ctx), rk=kg.relin_keys(), gk=kg.galois_keys())
 
 
@@ -353,3 +353,27 @@ def test_log_depth_window_sum_gives_the_same_dot_products(size):
         assert fast[i].parms_id() == ref[i].parms_id() and fast[i].scale == ref[i].scale
         a, b = dec(e, ref[i], size).real, dec(e, fast[i], size).real
         assert np.abs(a - X[i] @ w).max() < 1e-3 and np.abs(b - X[i] @ w).max() < 1e-3
+
+
+def test_default_keygenerator_and_encryptor_draw_fresh_os_randomness():
+    """seed=None must be the default -- two default KeyGenerators give different secret keys, two
+    default Encryptors (and two calls of one) give different ciphertexts of the same plaintext; explicit seeds stay
+    reproducible (tests / tools only)."""
+    N, bits = 2048, [50, 30, 50]
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
+    ctx = S.SEALContext.Create(parms, backend=OracleBackend(N, parms.coeff_modulus()))
+    kg1, kg2 = S.KeyGenerator(ctx), S.KeyGenerator(ctx)
+    assert kg1._key32 != kg2._key32
+    assert not np.array_equal(kg1.secret_key().host, kg2.secret_key().host)
+    pt = S.CKKSEncoder(ctx).encode(np.arange(4.0), 2.0 ** 30)
+    pk = kg1.public_key()
+    e1, e2 = S.Encryptor(ctx, pk), S.Encryptor(ctx, pk)
+    be = ctx.backend
+    c1, c2, c3 = (be.to_host(e.encrypt(pt).data) for e in (e1, e2, e1))
+    assert not np.array_equal(c1, c2) and not np.array_equal(c1, c3)
+    assert np.array_equal(S.KeyGenerator(ctx, 7).secret_key().host, S.KeyGenerator(ctx, 7).secret_key().host)
+    dec = S.Decryptor(ctx, kg1.secret_key())
+    got = S.CKKSEncoder(ctx).decode(dec.decrypt(e2.encrypt(pt)))[:4]
+    assert np.allclose(got.real, np.arange(4.0), atol=1e-4)

@@ -14,7 +14,7 @@ N, bits, scale, nw = 16384, [60] + [40] * 7 + [60], 2.0 ** 40, 8
 parms = S.EncryptionParameters("ckks"); parms.set_poly_modulus_degree(N); parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
 ctx = S.SEALContext.Create(parms)
 kg = S.KeyGenerator(ctx, 1); gk = kg.galois_keys(); rk = kg.relin_keys()
-enc, dec = S.Encryptor(ctx, kg.public_key()), S.Decryptor(ctx, kg.secret_key())
+enc, dec = S.Encryptor(ctx, kg.public_key(), 2), S.Decryptor(ctx, kg.secret_key())
 encoder, ev, eng = S.CKKSEncoder(ctx), S.Evaluator(ctx), ctx.backend.engine
 rng = np.random.default_rng(0)
 out = {"params": f"N={N} {bits} scale 2^40, {nw} weights", "window_sum": "doubling (fast mode)" if LOG_SUM else "rotate-by-1 chain (reference, bit-exact)", "runs": []}

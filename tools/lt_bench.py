@@ -18,7 +18,7 @@ if os.environ.get("LT_SET") == "C3":  # the headline parameter set instead of th
     N, bits = 16384, [60, 40, 40, 40, 40, 60]
 parms = S.EncryptionParameters("ckks"); parms.set_poly_modulus_degree(N); parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
 ctx = S.SEALContext.Create(parms)
-kg = S.KeyGenerator(ctx, 1); gk_default = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key()); dec = S.Decryptor(ctx, kg.secret_key())
+kg = S.KeyGenerator(ctx, 1); gk_default = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key(), 2); dec = S.Decryptor(ctx, kg.secret_key())
 encoder, ev = S.CKKSEncoder(ctx), S.Evaluator(ctx)
 rng = np.random.default_rng(0)
 out = {"params": f"N={N} {bits} scale 2^40", "published_us": {"10": 1.4e5, "100": 1.3e6, "1000": 1.8e7}, "runs": []}

@@ -19,7 +19,7 @@ N = {"C3": 16384, "C5": 32768}[setname]
 bits, scale = [60, 40, 40, 40, 40, 60], 2.0 ** 40
 parms = S.EncryptionParameters("ckks"); parms.set_poly_modulus_degree(N); parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
 ctx = S.SEALContext.Create(parms)
-kg = S.KeyGenerator(ctx, 1); gk = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key()); dec = S.Decryptor(ctx, kg.secret_key())
+kg = S.KeyGenerator(ctx, 1); gk = kg.galois_keys(); enc = S.Encryptor(ctx, kg.public_key(), 2); dec = S.Decryptor(ctx, kg.secret_key())
 encoder, ev, eng = S.CKKSEncoder(ctx), S.Evaluator(ctx), ctx.backend.engine
 rng = np.random.default_rng(0)
 A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
