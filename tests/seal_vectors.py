@@ -1,0 +1,180 @@
+"""Reader / writer / checker of the "HEFXKAT1" known-answer files that tools/gen_seal_vectors.cpp produces with REAL
+Microsoft SEAL (format documented there and in tests/golden/seal/README.md).
+
+`check(vec, impl)` recomputes every known answer of a file from the file's own inputs with `impl` -- the CPU oracle
+(oracle.Oracle) or the HIP engine behind the C-ABI (EngineImpl below) -- and compares uint64 words.  Keys and
+ciphertexts are inputs (SEAL's PRNG), evaluator outputs are the answers."""
+from __future__ import annotations
+
+import glob
+import os
+import struct
+from typing import Dict, List
+
+import numpy as np
+
+MAGIC = b"HEFXKAT1"
+KIND_CT, KIND_PT, KIND_KEY = 1, 2, 3
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seal")
+
+
+class Record:
+    def __init__(self, tag, kind, size, rows, aux, scale, words):
+        self.tag, self.kind, self.size, self.rows, self.aux, self.scale, self.words = tag, kind, size, rows, aux, scale, words
+
+
+class VectorFile:
+    def __init__(self, path, N, primes, producer, records: List[Record]):
+        self.path, self.N, self.primes, self.producer, self.records = path, N, primes, producer, records
+        self.k = len(primes)
+
+    def get(self, tag) -> Record:
+        for r in self.records:
+            if r.tag == tag:
+                return r
+        raise KeyError(tag)
+
+    def has(self, tag) -> bool:
+        return any(r.tag == tag for r in self.records)
+
+    def ct(self, tag) -> np.ndarray:
+        r = self.get(tag)
+        assert r.kind == KIND_CT
+        return r.words.reshape(r.size, r.rows, self.N)
+
+    def pt(self, tag) -> np.ndarray:
+        r = self.get(tag)
+        assert r.kind == KIND_PT
+        return r.words.reshape(r.rows, self.N)
+
+    def key(self, tag, elt) -> np.ndarray:
+        for r in self.records:
+            if r.tag == tag and r.kind == KIND_KEY and r.aux == elt:
+                assert r.size == self.k - 1 and r.rows == self.k, "key layout is not [k-1][2][k][N]"
+                return r.words.reshape(self.k - 1, 2, self.k, self.N)
+        raise KeyError((tag, elt))
+
+    @property
+    def from_real_seal(self) -> bool:
+        return self.producer.startswith("Microsoft SEAL")
+
+
+def load(path: str) -> VectorFile:
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:8] != MAGIC:
+        raise ValueError(f"{path}: not a HEFXKAT1 file")
+    version, N, k, _ = struct.unpack_from("<IIII", data, 8)
+    if version != 1:
+        raise ValueError(f"{path}: unsupported version {version}")
+    off = 24
+    primes = list(struct.unpack_from(f"<{k}Q", data, off))
+    off += 8 * k
+    producer = data[off:off + 64].split(b"\0")[0].decode()
+    off += 64
+    recs = []
+    while off < len(data):
+        tag = data[off:off + 24].split(b"\0")[0].decode()
+        kind, size, rows, aux, scale, nwords = struct.unpack_from("<IIIIdQ", data, off + 24)
+        off += 24 + 16 + 8 + 8
+        words = np.frombuffer(data, dtype="<u8", count=nwords, offset=off).astype(np.uint64)
+        off += 8 * nwords
+        recs.append(Record(tag, kind, size, rows, aux, scale, words))
+    return VectorFile(path, N, primes, producer, recs)
+
+
+def write(path: str, N: int, primes, producer: str, records: List[Record]):
+    """Same byte layout as tools/gen_seal_vectors.cpp (used by the self-check test and by anyone converting vectors)."""
+    with open(path, "wb") as f:
+        f.write(MAGIC + struct.pack("<IIII", 1, N, len(primes), 0) + struct.pack(f"<{len(primes)}Q", *primes))
+        f.write(producer.encode()[:63].ljust(64, b"\0"))
+        for r in records:
+            w = np.ascontiguousarray(r.words, dtype="<u8").reshape(-1)
+            f.write(r.tag.encode()[:23].ljust(24, b"\0") + struct.pack("<IIIIdQ", r.kind, r.size, r.rows, r.aux, r.scale, w.size))
+            f.write(w.tobytes())
+
+
+def golden_files() -> List[str]:
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.bin")))
+
+
+def elt_from_step(step: int, N: int) -> int:
+    pos = step if step > 0 else N // 2 + step
+    return pow(3, pos, 2 * N)
+
+
+class EngineImpl:
+    """The oracle's method names over the HIP engine (every call goes through the C-ABI)."""
+
+    def __init__(self, N, primes):
+        from seal_fyp_logistic_regression_amd import Engine
+        self.e, self.N = Engine(N, primes), N
+
+    def _L(self, ct):
+        return ct.shape[-2]
+
+    def apply_galois(self, ct, elt, key):
+        return self.e.apply_galois(self._L(ct), self.e.to_device(ct), elt, self.e.to_device(key)).download()
+
+    def rotate_mulplain(self, ct, elt, key, pt):
+        e = self.e
+        return e.rotate_multiply_plain_batch(self._L(ct), [e.to_device(ct)], [elt], [e.to_device(key)], [e.to_device(pt)])[0].download()
+
+    def multiply_plain(self, ct, pt):
+        return self.e.multiply_plain(self._L(ct), ct.shape[0], self.e.to_device(ct), self.e.to_device(pt)).download()
+
+    def add_plain(self, ct, pt):
+        return self.e.add_plain(self._L(ct), ct.shape[0], self.e.to_device(ct), self.e.to_device(pt)).download()
+
+    def add(self, a, b):
+        return self.e.add(self._L(a), a.shape[0], self.e.to_device(a), self.e.to_device(b)).download()
+
+    def multiply(self, a, b):
+        return self.e.multiply(self._L(a), self.e.to_device(a), self.e.to_device(b)).download()
+
+    def relinearize(self, ct3, key):
+        return self.e.relinearize(self._L(ct3), self.e.to_device(ct3), self.e.to_device(key)).download()
+
+    def rescale(self, ct, rounded=False):
+        return self.e.rescale_to_next(self._L(ct), ct.shape[0], self.e.to_device(ct), rounded=rounded).download()
+
+    def mod_drop(self, x, L_out):
+        return self.e.mod_drop(self._L(x), L_out, x.shape[0], self.e.to_device(x)).download()
+
+
+def check(vec: VectorFile, impl) -> Dict[str, object]:
+    """-> {answer tag: True / False} plus "rescale_mode": "floor" | "round" | None (which division reproduces the file's
+    rescale answers).  Missing optional records are skipped."""
+    N = vec.N
+    ct, ct_b, pt = vec.ct("ct"), vec.ct("ct_b"), vec.pt("pt")
+    e1, em1, e4, econj = elt_from_step(1, N), elt_from_step(-1, N), elt_from_step(4, N), 2 * N - 1
+    res: Dict[str, object] = {}
+    eq = lambda a, b: bool(a.shape == b.shape and (a == b).all())
+    rot1 = impl.apply_galois(ct, e1, vec.key("gk", e1))
+    res["rot1"] = eq(rot1, vec.ct("rot1"))
+    res["rot1_mulpt"] = eq(impl.multiply_plain(vec.ct("rot1"), pt), vec.ct("rot1_mulpt"))
+    if hasattr(impl, "rotate_mulplain"):  # the fused hot-loop body (the metric's unit)
+        res["rot1_mulpt_fused"] = eq(impl.rotate_mulplain(ct, e1, vec.key("gk", e1), pt), vec.ct("rot1_mulpt"))
+    res["rotm1"] = eq(impl.apply_galois(ct, em1, vec.key("gk", em1)), vec.ct("rotm1"))
+    # rotate_vector(ct, 3) with power-of-two keys: NAF(3) = [-1, 4], least significant term first
+    naf = impl.apply_galois(impl.apply_galois(ct, em1, vec.key("gk", em1)), e4, vec.key("gk", e4))
+    res["rot3_naf"] = eq(naf, vec.ct("rot3_naf"))
+    res["conj"] = eq(impl.apply_galois(ct, econj, vec.key("gk", econj)), vec.ct("conj"))
+    res["mulpt"] = eq(impl.multiply_plain(ct, pt), vec.ct("mulpt"))
+    res["add"] = eq(impl.add(ct, ct_b), vec.ct("add"))
+    res["addpl"] = eq(impl.add_plain(ct, pt), vec.ct("addpl"))
+    res["mul"] = eq(impl.multiply(ct, ct_b), vec.ct("mul"))
+    res["sq"] = eq(impl.multiply(ct, ct), vec.ct("sq"))
+    res["relin"] = eq(impl.relinearize(vec.ct("mul"), vec.key("rk", 0)), vec.ct("relin"))
+    res["rescale_mode"] = None
+    if vec.has("rescale"):
+        modes = {}
+        for name, rounded in (("floor", False), ("round", True)):
+            modes[name] = eq(impl.rescale(vec.ct("relin"), rounded=rounded), vec.ct("rescale")) and \
+                eq(impl.rescale(vec.ct("mul"), rounded=rounded), vec.ct("rescale3"))
+        res["rescale"] = modes["floor"] or modes["round"]
+        res["rescale_mode"] = "floor" if modes["floor"] else ("round" if modes["round"] else None)
+        low = impl.mod_drop(ct, ct.shape[1] - 1)
+        res["modsw"] = eq(low, vec.ct("modsw"))
+        res["rot1_low"] = eq(impl.apply_galois(vec.ct("modsw"), e1, vec.key("gk", e1)), vec.ct("rot1_low"))
+    return res
