@@ -884,8 +884,8 @@ static int get_perm(hefx_context *c, uint32_t elt, const uint32_t **out)
 // ---------------------------------------------------------------------------------------------
 static size_t ks_words_per_item(const hefx_context *c, int L)
 {
-    // d: L, xd: L, acc: 2(L+1), u: 2, p0: L   (units of N words); x is per sub-chunk, see ks_x_words
-    return (size_t)c->n * (3 * (size_t)L + 2 * (size_t)(L + 1) + 2);
+    // d: L, acc: 2(L+1), u: 2   (units of N words); x is per sub-chunk (ks_x_words), alias copies only when needed
+    return (size_t)c->n * ((size_t)L + 2 * (size_t)(L + 1) + 2);
 }
 static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t)c->n * sub * L * (L + 1); }
 
@@ -926,6 +926,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // Validate the WHOLE batch and resolve every gather table before anything is submitted: an argument error must
     // leave no chunk in flight, no forked stream unjoined and no ring slot marked busy.
     std::vector<const uint32_t *> perms(relin ? 0 : (size_t)n);
+    bool any_alias = false;  // rotate_vector_inplace (helper.h:474): the input is copied to scratch before it is overwritten
     for (int i = 0; i < n; ++i) {
         if (!ct_in[i] || !ct_out[i]) return fail(HEFX_ERR_INVALID, "null ciphertext pointer in batch");
         if (relin) {
@@ -933,10 +934,12 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         } else {
             if (!keys[i]) return fail(HEFX_ERR_INVALID, "null key pointer in batch");
             if (int rc = get_perm(c, elts[i], &perms[i])) return rc;
+            any_alias |= ct_in[i] == ct_out[i];
         }
     }
     const int cmax = n < chunk ? n : chunk;
-    const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax));
+    const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax)) +
+                              (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
@@ -963,6 +966,13 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             c->ring_busy[slot] = false;
         }
         KsItem *hb = c->h_items + (size_t)slot * KS_MAX_CHUNK, *db = c->d_items + (size_t)slot * KS_MAX_CHUNK;
+        KsScratch S;
+        S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
+        S.acc = S.d + (size_t)cnt * L * N;
+        S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
+        S.x = S.u + (size_t)cnt * 2 * N;
+        S.alias = S.x + (fused ? 0 : ks_x_words(c, L, sub < cnt ? sub : cnt));
+        bool chunk_alias = false;
         for (int i = 0; i < cnt; ++i) {
             KsItem &it = hb[i];
             it.c_in = (const u64 *)ct_in[base + i];
@@ -970,14 +980,14 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.pt = pts ? (const u64 *)pts[base + i] : nullptr;
             it.key = relin ? (const u64 *)single_key : (const u64 *)keys[base + i];
             it.perm = relin ? nullptr : perms[base + i];
+            it.elt = relin ? 1u : elts[base + i];
+            it.flags = 0;
+            if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
+                it.c_in = S.alias + (size_t)i * 2 * L * N;
+                it.flags = KS_ALIASED;
+                chunk_alias = true;
+            }
         }
-        KsScratch S;
-        S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
-        S.xd = S.d + (size_t)cnt * L * N;
-        S.acc = S.xd + (size_t)cnt * L * N;
-        S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
-        S.p0 = S.u + (size_t)cnt * 2 * N;
-        S.x = S.p0 + (size_t)cnt * L * N;
         KsProf *prof = nullptr;
         if (c->profiling) {
             const size_t need = (size_t)c->prof.used + 8 + 2 * ((size_t)cnt / sub + 1);
@@ -996,7 +1006,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
         KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, cs, prof));
+        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, chunk_alias, cs, prof));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
 #undef KS_TRY
@@ -1154,7 +1164,7 @@ extern "C" int hefx_profile_end(hefx_context *c, double *stage_ms, uint64_t *lau
 }
 extern "C" const char *hefx_profile_stage_name(int k)
 {
-    static const char *names[KS_STAGES] = {"ks_prepare_kernel",      "ks_intt_digits_kernel",
+    static const char *names[KS_STAGES] = {"ks_alias_copy_kernel",   "ks_intt_digits_kernel",
                                            "ks_ntt_digits_kernel",   "ks_mac_kernel",
                                            "ks_moddown_intt_kernel", "ks_moddown_finish_kernel",
                                            "ks_ntt_mac_kernel"};
@@ -1565,10 +1575,12 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
         it.c_out = nullptr;
         it.key = (const u64 *)K.m[plan[0]];
         it.pt = (const u64 *)diag_pts_keylevel[l];
+        it.elt = plan[0];
+        it.flags = 0;
         if (int rc = get_perm(c, plan[0], &it.perm)) return rc;
     }
-    items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr};
-    items[nterms] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out};
+    items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr, 1u, 0u};
+    items[nterms] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out, 1u, 0u};
     // ---- ct_new = ct + rotate(ct, -d); cbuf = ct_new * diag_0
     const uint64_t *src = ct;
     for (size_t t = 0; t < first.size(); ++t) {
@@ -1588,11 +1600,10 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     if (int rc = ensure_scratch(c, per)) return rc;
     KsScratch S;
     S.d = c->scratch;
-    S.xd = S.d + (size_t)L * N;
-    S.acc = S.xd + (size_t)L * N;
+    S.acc = S.d + (size_t)L * N;
     S.u = S.acc + (size_t)2 * (L + 1) * N;
-    S.p0 = S.u + (size_t)2 * N;
-    S.x = S.p0 + (size_t)L * N;
+    S.x = S.u + (size_t)2 * N;
+    S.alias = nullptr;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(d_items, items.data(), sizeof(KsItem) * items.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));  // `items` is a local

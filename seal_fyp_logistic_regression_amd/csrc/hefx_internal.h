@@ -56,22 +56,38 @@ struct KsItem {
     const uint32_t *perm;  // gather table of the Galois element (out[i] = in[perm[i]]), or nullptr for relin
     const u64 *pt;     // optional plaintext [L][N] multiplied into the result (fused multiply_plain)
     u64 *c_out;        // [2][L][N]
+    uint32_t elt;      // Galois element of a rotation (the kernels compute the gather index from it); 0 / 1: identity
+    uint32_t flags;    // KS_ALIASED: c_out is the caller's input as well -- c_in points at a scratch copy of it
 };
+constexpr uint32_t KS_ALIASED = 1;
+
+// NTT-domain index map of the automorphism X -> X^elt: out[i] = in[galois_index(i)], with
+// galois_index(i) = bitrev(((elt * (2 bitrev(i) + 1)) mod 2N - 1) / 2).  Two v_bfrev, one 24-bit multiply: cheaper
+// than a table lookup and no table to keep cache-resident.  Structure the kernels rely on: positions 2j and 2j+1 map
+// to a pair (2m, 2m+1) in either order (elt is odd), and more generally every aligned block of 2^s positions maps onto
+// an aligned block of 2^s positions -- a gathered row touches exactly the cache lines of a straight read.
+__device__ __forceinline__ uint32_t galois_index(uint32_t i, uint32_t elt, int logn)
+{
+    const uint32_t br = __brev(i) >> (32 - logn);
+    const uint32_t raw = __umul24(elt, 2u * br + 1u) & ((2u << logn) - 1u);  // elt < 2N <= 2^16, 2 br + 1 < 2^16
+    return __brev((raw - 1u) >> 1) >> (32 - logn);
+}
 
 // Items of one chunk live in a device-side descriptor ring (filled through a pinned host mirror with one async
 // copy per chunk), so a chunk is not limited by the 4 KiB kernel-argument segment.
 constexpr int KS_MAX_CHUNK = 256;
 constexpr int KS_RING = 8;
 
-// Scratch layout for one chunk of key-switch items, in units of N words per item.
+// Scratch layout for one chunk of key-switch items, in units of N words per item.  The Galois-permuted inputs are
+// never materialised: the inverse transform of the digits, the own-prime term of the key MAC and the add-in of the
+// mod-down epilogue gather them from the source ciphertext (galois_index).
 struct KsScratch {
     u64 *d;    // [chunk][L][N]        digits in coefficient form
-    u64 *xd;   // [chunk][L][N]        digit i in NTT form mod its own prime (Galois-permuted c1 / c2)
     u64 *x;    // [sub][L][L+1][N]     digit i transformed to modulus slot jj != i (jj==L: special prime); only a
                //                      SUB-chunk of items at a time, so this largest scratch array stays cache-resident
     u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
     u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
-    u64 *p0;   // [chunk][L][N]        perm_g(c0) of a rotation (added in by the mod-down epilogue)
+    u64 *alias;  // [chunk][2][L][N]   copies of the inputs of in-place rotations (c_in == c_out), else unused
 };
 
 constexpr int ADD_MANY_GROUP = 48;
@@ -105,7 +121,7 @@ struct KsProf {
     int cap, used;
 };
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
-                                  const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof);
+                                  const KsScratch &scr, int sub, bool hoist, bool alias, hipStream_t s, KsProf *prof);
 // double-hoisted linear transform (hefx_keyswitch.hip): see lt2_mac_kernel
 hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,
                                 const KsScratch &scr, const u64 *ct_new, u64 *partial_s, u64 *partial_c0, u64 *cbuf,

@@ -79,45 +79,39 @@ __device__ static __forceinline__ void group_decode(int bid, int fan, int &g, in
 __device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j >> 1); }
 
 // ------------------------------------------------------------------------------------------------
-// (0) preparation: x[b][i][i] = perm_g(c1[i]) (or c2[i] for relinearisation), p0[b][j] = perm_g(c0[j]).
-// Plain gather at full occupancy; two outputs (16 B store) per lane.
+// Galois-gathered reads.  The rotated inputs perm_g(c0), perm_g(c1) are never written out: their three readers --
+// the inverse transform of the digits, the own-prime term of the key MAC, the add-in of the mod-down epilogue --
+// gather them from the source ciphertext through galois_index().  Pairs stay pairs (positions 2j, 2j+1 of the
+// rotated row are positions 2m, 2m+1 of the source, possibly swapped), so the 16-byte record loads survive.
 // ------------------------------------------------------------------------------------------------
-// row0 / noperm: the hoisted path prepares the shared source once (rows [0,L) of item 0, copied unpermuted) and
-// perm_g(c0) per item (rows [L,2L)).
-__global__ __launch_bounds__(256) void ks_prepare_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
-                                                         int row0, int noperm, KsScratch S)
+// record j = (value[2j], value[2j+1]) of the row perm_elt(src)
+__device__ __forceinline__ ulonglong2 gather_pair(const u64 *__restrict__ src, uint32_t j, uint32_t elt, int logn)
 {
-    const int logn = T.logn;
-    const size_t n = (size_t)1 << logn;
-    const int row = blockIdx.y + row0, b = blockIdx.z;
-    KsItem it = items[b];
-    if (noperm) it.perm = nullptr;
-    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
-    const u64 *__restrict__ src;
-    u64 *__restrict__ dst;
-    if (row < L) {
-        src = it.c_in + ((size_t)(relin ? 2 * L : L) + row) * n;
-        dst = S.xd + ((size_t)b * L + row) * n;
-    } else {
-        src = it.c_in + (size_t)(row - L) * n;
-        dst = S.p0 + ((size_t)b * L + (row - L)) * n;
-    }
-    ulonglong2 o;
-    if (it.perm) {
-        const uint2 pi = *reinterpret_cast<const uint2 *>(it.perm + w);
-        o.x = src[pi.x];
-        o.y = src[pi.y];
-    } else {
-        o = *reinterpret_cast<const ulonglong2 *>(src + w);
-    }
-    *reinterpret_cast<ulonglong2 *>(dst + w) = o;
+    const uint32_t p = galois_index(2u * j, elt, logn);
+    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(src)[p >> 1];
+    return (p & 1u) ? make_ulonglong2(v.y, v.x) : v;
+}
+__device__ __forceinline__ uint32_t item_elt(const KsItem &it) { return it.elt ? it.elt : 1u; }
+
+// (0) in-place rotations only (c_in == c_out at the ABI, e.g. rotate_vector_inplace, helper.h:474): the epilogue of the
+// last kernel writes c_out while it still gathers from c0, so the host points such an item's c_in at a scratch copy
+// and this kernel fills it from c_out.  Items without KS_ALIASED exit at once; no launch when a chunk has none.
+__global__ __launch_bounds__(256) void ks_alias_copy_kernel(DevTables T, const KsItem *__restrict__ items, int L)
+{
+    const KsItem it = items[blockIdx.z];
+    if (!(it.flags & KS_ALIASED)) return;
+    const size_t n = (size_t)1 << T.logn;
+    const size_t w = (size_t)blockIdx.y * n + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;  // row = blockIdx.y < 2L
+    *reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(it.c_in) + w) = *reinterpret_cast<const ulonglong2 *>(it.c_out + w);
 }
 
 // ------------------------------------------------------------------------------------------------
-// (1) digit i of item b: d[b][i] (EO) = INTT_{q_i}(x[b][i][i])
+// (1) digit i of item b: d[b][i] (EO) = INTT_{q_i}(perm_g(c1)[i])   (c2[i] for a relinearisation)
+// noperm: the hoisted paths decompose the UNROTATED shared source (item 0).
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_kernel(DevTables T, int L, int rows,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_kernel(DevTables T, const KsItem *__restrict__ items,
+                                                                              int L, int relin, int noperm, int rows,
                                                                               KsScratch S)
 {
     using SC = SplitCfg<LOGN>;
@@ -128,10 +122,17 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
     if (p >= rows) return;
     const int t = threadIdx.x;
     const int b = p / L, i = p % L;
-    const ulonglong2 *__restrict__ src =
-        reinterpret_cast<const ulonglong2 *>(S.xd + ((size_t)b * L + i) * SC::N);
+    const KsItem it = items[b];
+    const u64 *__restrict__ src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * SC::N;
     u64 v[16];
-    split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
+    if (relin || noperm || item_elt(it) == 1u) {
+        split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, reinterpret_cast<const ulonglong2 *>(src), lds, ntt_tables(T, i),
+                                               T.mods[i], T.modsf[i], t, h);
+    } else {
+        const uint32_t elt = it.elt;
+        split_inv_ld<LOGN, KsWaves<LOGN>::NB_INV>(v, [src, elt](int j) { return gather_pair(src, (uint32_t)j, elt, LOGN); },
+                                                  lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, h);
+    }
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
@@ -216,25 +217,17 @@ struct MacAcc {
     }
 };
 
-// NI consecutive items (bl .. bl+NI-1) that share `key`
-template <int NI, bool STREAM, class XR, class AR>
+// NI consecutive items (bl .. bl+NI-1) that share `key`; xload(bl, i, w) = record w of digit i's row for this modulus
+template <int NI, bool STREAM, class XL, class AR>
 __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, int L, int m, size_t n, size_t w, int bl,
-                                          const ModConst &mc, const XR &xrow, const AR &accrow)
+                                          const ModConst &mc, const XL &xload, const AR &accrow)
 {
     MacAcc A[NI];
     for (int i = 0; i < L; ++i) {
         const u64 *kbase = key + ((size_t)i * 2 * T.k + m) * n;
         ulonglong2 x[NI];
 #pragma unroll
-        for (int e = 0; e < NI; ++e) {
-            const ulonglong2 *xp = xrow(bl + e, i) + w;
-            if (STREAM) {  // read exactly once
-                x[e].x = __builtin_nontemporal_load(&xp->x);
-                x[e].y = __builtin_nontemporal_load(&xp->y);
-            } else {
-                x[e] = *xp;
-            }
-        }
+        for (int e = 0; e < NI; ++e) x[e] = xload(bl + e, i, w);
         const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
         const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
 #pragma unroll
@@ -245,8 +238,8 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
 }
 
 template <bool STREAM>
-__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int item0,
-                                                     int count, KsScratch S)
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+                                                     int item0, int count, KsScratch S)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
@@ -254,18 +247,31 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
-    auto xrow = [&](int bl, int i) {
-        return reinterpret_cast<const ulonglong2 *>(i == jj ? S.xd + ((size_t)(item0 + bl) * L + i) * n
-                                                            : S.x + (((size_t)bl * L + i) * (L + 1) + jj) * n);
+    // digit i in slot jj: its transform to that modulus from scratch x -- or, for its own prime (i == jj), the
+    // Galois-permuted input row itself, gathered from the source ciphertext
+    auto xload = [&](int bl, int i, size_t ww) -> ulonglong2 {
+        if (i == jj) {
+            const KsItem it = items[item0 + bl];
+            const u64 *src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * n;
+            return relin ? reinterpret_cast<const ulonglong2 *>(src)[ww] : gather_pair(src, (uint32_t)ww, item_elt(it), logn);
+        }
+        const ulonglong2 *xp = reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)bl * L + i) * (L + 1) + jj) * n) + ww;
+        if (STREAM) {  // read exactly once
+            ulonglong2 v;
+            v.x = __builtin_nontemporal_load(&xp->x);
+            v.y = __builtin_nontemporal_load(&xp->y);
+            return v;
+        }
+        return *xp;
     };
     auto accrow = [&](int bl, int c) { return S.acc + (((size_t)(item0 + bl) * 2 + c) * (L + 1) + jj) * n; };
     const u64 *k0 = items[item0 + bl0].key;
     const u64 *k1 = bl0 + 1 < count ? items[item0 + bl0 + 1].key : nullptr;
     if (k1 == k0) {
-        mac_items<2, STREAM>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
+        mac_items<2, STREAM>(T, k0, L, m, n, w, bl0, mc, xload, accrow);
     } else {
-        mac_items<1, STREAM>(T, k0, L, m, n, w, bl0, mc, xrow, accrow);
-        if (k1) mac_items<1, STREAM>(T, k1, L, m, n, w, bl0 + 1, mc, xrow, accrow);
+        mac_items<1, STREAM>(T, k0, L, m, n, w, bl0, mc, xload, accrow);
+        if (k1) mac_items<1, STREAM>(T, k1, L, m, n, w, bl0 + 1, mc, xload, accrow);
     }
 }
 
@@ -293,9 +299,10 @@ __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const 
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
     const KsItem it = items[b];
     const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
+    const u64 *__restrict__ c1 = it.c_in + (size_t)L * n;  // the shared source's c1: digit i in NTT form mod its own prime
     MacAcc A;
     for (int i = 0; i < L; ++i) {
-        const u64 *__restrict__ xrow = i == jj ? S.xd + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
+        const u64 *__restrict__ xrow = i == jj ? c1 + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
         ulonglong2 x;
         x.x = xrow[pi.x];
         x.y = xrow[pi.y];
@@ -322,7 +329,8 @@ __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const 
 constexpr int LT2_CHUNK = 8;
 
 __global__ __launch_bounds__(256) void lt2_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int nrot,
-                                                      KsScratch S, u64 *__restrict__ partial /* [chunks][2][L+1][N] */)
+                                                      KsScratch S, const u64 *__restrict__ src_c1 /* [L][N] */,
+                                                      u64 *__restrict__ partial /* [chunks][2][L+1][N] */)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
@@ -337,7 +345,7 @@ __global__ __launch_bounds__(256) void lt2_mac_kernel(DevTables T, const KsItem 
         const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
         MacAcc A;
         for (int i = 0; i < L; ++i) {
-            const u64 *__restrict__ xrow = i == jj ? S.xd + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
+            const u64 *__restrict__ xrow = i == jj ? src_c1 + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
             ulonglong2 x;
             x.x = xrow[pi.x];
             x.y = xrow[pi.y];
@@ -401,7 +409,7 @@ struct FusedCfg {
 
 template <int LOGN>
 __global__ __launch_bounds__(FusedCfg<LOGN>::T, (FusedCfg<LOGN>::T >= 1024 ? 4 : 2)) void ks_ntt_mac_kernel(
-    DevTables T, const KsItem *__restrict__ items, int L, int groups, KsScratch S)
+    DevTables T, const KsItem *__restrict__ items, int L, int relin, int groups, KsScratch S)
 {
     using FC = FusedCfg<LOGN>;
     using C = typename FC::C;
@@ -421,10 +429,11 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, (FusedCfg<LOGN>::T >= 1024 ? 4 :
     for (int r = 0; r < 8; ++r) a0l[r] = a0h[r] = a1l[r] = a1h[r] = 0;
     for (int i = 0; i < L; ++i) {
         u64 xv[8];
-        if (i == jj) {  // the digit is already in NTT form modulo its own prime
-            const u64 *__restrict__ xr = S.xd + ((size_t)b * L + i) * FC::N + off;
+        if (i == jj) {  // the digit is already in NTT form modulo its own prime: the (rotated) input row itself
+            const u64 *__restrict__ xr = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * FC::N;
+            const uint32_t elt = relin ? 1u : item_elt(it);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) xv[r] = xr[C::idx_out(t, r)];
+            for (int r = 0; r < 8; ++r) xv[r] = xr[galois_index((uint32_t)(off + C::idx_out(t, r)), elt, LOGN)];
         } else {
             const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * FC::N;
             const bool reduce = mf.q != 0.0 ? T.modsf[i].q == 0.0 : T.mods[i].q > mc.q;
@@ -533,12 +542,16 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         x = ud[e];
         y = ud[e + SC::H / 2];
     };
-    // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), which kernel (0) left in S.p0.
+    // relinearisation adds (c0,c1) of the input; a rotation adds perm(c0), gathered from the source's c0
     const size_t off = (size_t)h * SC::H;
     const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * SC::N + off;
-    const u64 *__restrict__ addsrc =
-        (relin ? it.c_in + ((size_t)c * L + j) * SC::N : S.p0 + ((size_t)b * L + j) * SC::N) + off;
+    const u64 *__restrict__ addrow = it.c_in + ((size_t)(relin ? c : 0) * L + j) * SC::N;
     const bool has_add = relin || c == 0;
+    const uint32_t elt = relin ? 1u : item_elt(it);
+    auto addin = [&](int idx) -> u64 {
+        if (!has_add) return 0;
+        return addrow[elt == 1u ? (uint32_t)(off + idx) : galois_index((uint32_t)(off + idx), elt, LOGN)];
+    };
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
@@ -553,7 +566,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             for (int r = 0; r < 4; ++r) {
                 const int idx = C::idx_out(t, 4 * hh + r);
                 a[bufi][r] = acc[idx];
-                sadd[bufi][r] = has_add ? addsrc[idx] : 0;
+                sadd[bufi][r] = addin(idx);
                 pp[bufi][r] = pt ? pt[idx] : 0;
             }
         };
@@ -577,7 +590,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             for (int r = 0; r < 4; ++r) {
                 const int idx = C::idx_out(t, 4 * hh + r);
                 a[r] = acc[idx];
-                sadd[r] = has_add ? addsrc[idx] : 0;
+                sadd[r] = addin(idx);
                 pp[r] = pt ? pt[idx] : 0;
             }
 #pragma unroll
@@ -618,7 +631,8 @@ static void set_lds(K kernel, size_t bytes)
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                           const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof)
+                                           const KsScratch &scr, int sub, bool hoist, bool alias, hipStream_t s,
+                                           KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -643,12 +657,10 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             prof->stage[prof->used++] = stage;
         }
     };
-    if (hoist) {  // one shared source (item 0's ciphertext, unpermuted); per item only perm(c0), MAC, mod-down
-        mark(0);
-        hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, batch, L, 0, 0, 1, scr);
-        hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, n), dim3(256), 0, s, T, batch, L, 0, L, 0, scr);
+    if (hoist) {  // one shared source (item 0's ciphertext, unrotated); per item only the gathered MAC and the mod-down
         mark(1);
-        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, batch, L, 0, 1, L,
+                           scr);
         mark(2);
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, 0, scr);
         mark(3);
@@ -662,18 +674,20 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(-1);
         return hipGetLastError();
     }
-    mark(0);
-    hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, relin ? L : 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
-                       0, 0, scr);
+    if (alias) {  // in-place rotations: their inputs move to scratch first (see ks_alias_copy_kernel)
+        mark(0);
+        hipLaunchKernelGGL(ks_alias_copy_kernel, dim3(SC::N / 2 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L);
+    }
     mark(1);
-    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, L, n * L, scr);
+    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, batch, L, rl, 0,
+                       n * L, scr);
     if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
         if constexpr (LOGN <= 14) {
             static PerDeviceOnce fattr;
             if (fattr.first()) set_lds(ks_ntt_mac_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
             mark(6);
             hipLaunchKernelGGL((ks_ntt_mac_kernel<LOGN>), dim3(group_grid(n, L + 1)), dim3(FusedCfg<LOGN>::T),
-                               FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, n, scr);
+                               FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, rl, n, scr);
         }
     } else
     // digit x modulus products only ever exist for `sub` items: K2 writes them, the MAC consumes them right away
@@ -688,10 +702,10 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(3);
         if (stream_x)
             hipLaunchKernelGGL(ks_mac_kernel<true>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
-                               L, item0, m, scr);
+                               L, rl, item0, m, scr);
         else
             hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
-                               L, item0, m, scr);
+                               L, rl, item0, m, scr);
     }
     mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
@@ -738,11 +752,11 @@ static hipError_t launch_lt2_decompose_t(const DevTables &T, int L, const KsItem
         set_lds(ks_moddown_finish_kernel<LOGN>, lds);
     }
     const int chunks = (nrot + LT2_CHUNK - 1) / LT2_CHUNK;
-    hipLaunchKernelGGL(ks_prepare_kernel, dim3(SC::N / 2 / 256, L, 1), dim3(256), 0, s, T, src_item, L, 0, 0, 1, scr);
-    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, L, L, scr);
+    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, src_item, L, 0, 1, L,
+                       scr);
     hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, 0, scr);
     hipLaunchKernelGGL(lt2_mac_kernel, dim3(SC::N / 2 / 256, L + 1, chunks), dim3(256), 0, s, T, rot_items, L, nrot, scr,
-                       partial_s);
+                       ct_new + (size_t)L * SC::N, partial_s);
     hipLaunchKernelGGL(lt2_c0_kernel, dim3(SC::N / 2 / 256, L, chunks), dim3(256), 0, s, T, rot_items, L, nrot, ct_new,
                        partial_c0);
     // S -> scr.acc [2][L+1][N];  C0 += partials, in place on poly 0 of cbuf
@@ -791,9 +805,9 @@ hipError_t launch_lt2_moddown(const DevTables &T, int L, const KsItem *item, con
 int lt2_chunk() { return LT2_CHUNK; }
 
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                  const KsScratch &scr, int sub, bool hoist, hipStream_t s, KsProf *prof)
+                                  const KsScratch &scr, int sub, bool hoist, bool alias, hipStream_t s, KsProf *prof)
 {
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, s, prof)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

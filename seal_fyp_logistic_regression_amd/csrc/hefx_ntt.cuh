@@ -533,11 +533,12 @@ __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMo
 
 // Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the
 // sub-transform; on return v[r] = coefficient 2*idx_nat(t,r) + h, canonical.
-// `pairs` points at the row viewed as (value[2j], value[2j+1]) records.  The first stage is done in two batches
-// of eight pairs (+ eight twiddles for the odd half) with a scheduling fence between them: issuing all 16 pair
-// loads and 16 twiddle loads at once needs ~250 VGPRs in the FP64 policy and spilled heavily at the 128 cap.
-template <int LOGN, class A, int NB = 2>
-__device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
+// `ldp(j)` delivers the row's (value[2j], value[2j+1]) record -- a plain 16-byte load, or a Galois-gathered one
+// (hefx_keyswitch.hip).  The first stage is done in two batches of eight pairs (+ eight twiddles for the odd half) with
+// a scheduling fence between them: issuing all 16 pair loads and 16 twiddle loads at once needs ~250 VGPRs in the FP64
+// policy and spilled heavily at the 128 cap.
+template <int LOGN, class A, int NB = 2, class LDP>
+__device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *lds,
                                             const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t,
                                             int h)
 {
@@ -548,7 +549,7 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__re
     for (int g = 0; g < NB; ++g) {
         ulonglong2 pr[BS];
 #pragma unroll
-        for (int r = 0; r < BS; ++r) pr[r] = pairs[C::idx_out(t, BS * g + r)];
+        for (int r = 0; r < BS; ++r) pr[r] = ldp(C::idx_out(t, BS * g + r));
         if (h == 0) {
 #pragma unroll
             for (int r = 0; r < BS; ++r)
@@ -568,14 +569,22 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const ulonglong2 *__re
     for (int r = 0; r < 16; ++r) v[r] = A::inv_finish(f[r], cx);
 }
 
+template <int LOGN, int NB = 2, class LDP>
+__device__ __forceinline__ void split_inv_ld(u64 (&v)[16], const LDP &ldp, u64 *lds, const NttTables &nt,
+                                             const ModConst &mc, const ModConstF &mf, int t, int h)
+{
+    if (mf.q != 0.0)
+        split_inv_a<LOGN, ArithF64, NB>(v, ldp, lds, nt.itwf, ArithF64::make(mf), t, h);
+    else
+        split_inv_a<LOGN, ArithU64, NB>(v, ldp, lds, nt.itw, ArithU64::make(mc), t, h);
+}
+
+// `pairs` points at the row viewed as (value[2j], value[2j+1]) records
 template <int LOGN, int NB = 2>
 __device__ __forceinline__ void split_inv(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
-    if (mf.q != 0.0)
-        split_inv_a<LOGN, ArithF64, NB>(v, pairs, lds, nt.itwf, ArithF64::make(mf), t, h);
-    else
-        split_inv_a<LOGN, ArithU64, NB>(v, pairs, lds, nt.itw, ArithU64::make(mc), t, h);
+    split_inv_ld<LOGN, NB>(v, [pairs](int j) { return pairs[j]; }, lds, nt, mc, mf, t, h);
 }
 
 }  // namespace hefx
