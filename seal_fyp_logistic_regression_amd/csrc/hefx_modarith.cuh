@@ -39,7 +39,25 @@ __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); 
 // x*w mod q in [0,2q), ws = floor(w*2^64/q); valid for ANY 64-bit x (Harvey/Shoup).
 __device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) * q; }
 
-__device__ __forceinline__ u64 csub(u64 x, u64 q) { return x >= q ? x - q : x; }
+// floor(x*ws / 2^64) UNDER-estimated by at most 2: only the three partial products that reach bit 64, no carry chain
+// between them.  With x = x1 2^32 + x0, ws = w1 2^32 + w0 the exact value is
+//   x1 w1 + floor(((x0 w1 + x1 w0) 2^32 + x0 w0) / 2^64) = x1 w1 + hi32(x0 w1) + hi32(x1 w0) + e,
+// e = floor(((lo32(x0 w1) + lo32(x1 w0)) 2^32 + x0 w0) / 2^64) in {0,1,2}.  Five instructions (two v_mul_hi_u32, a
+// 33-bit add, one v_mad_u64_u32) against eleven for the exact high word; the sum cannot wrap (it is <= the exact value).
+__device__ __forceinline__ u64 mulhi64_under2(u64 x, u64 ws)
+{
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)ws, w1 = (uint32_t)(ws >> 32);
+    return (u64)x1 * w1 + ((u64)__umulhi(x0, w1) + (u64)__umulhi(x1, w0));
+}
+// x*w mod q in [0,4q) for ANY 64-bit x: Shoup with the under-estimated quotient (each missing unit adds one q)
+__device__ __forceinline__ u64 shoup_lazy4(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64_under2(x, ws) * q; }
+
+// x in [0,2m) -> [0,m).  Written on the borrow of x - m (sub, subb, two selects) rather than compare-then-subtract.
+__device__ __forceinline__ u64 csub(u64 x, u64 q)
+{
+    u64 d;
+    return __builtin_usubll_overflow(x, q, &d) ? x : d;
+}
 
 __device__ __forceinline__ u64 addmod(u64 a, u64 b, u64 q) { return csub(a + b, q); }
 __device__ __forceinline__ u64 submod(u64 a, u64 b, u64 q) { return a >= b ? a - b : a + q - b; }

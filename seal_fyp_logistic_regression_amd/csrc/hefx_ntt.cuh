@@ -12,9 +12,9 @@
 //
 // Two arithmetic policies, chosen per RNS prime (all results are canonical residues, so both give the same
 // bits as SEAL's CPU path):
-//   ArithU64  any prime < 2^61: Harvey lazy butterflies ([0,4q) forward, [0,2q) inverse) with Shoup twiddles
-//             {w, floor(w*2^64/q)}; 10 integer multiplies (v_mad_u64_u32 / v_mul_*_u32, ~6 cycles each per
-//             wave and SIMD) per butterfly, ~105 cycles.
+//   ArithU64  any prime < 2^61: Harvey-style lazy butterflies ([0,8q) forward, [0,4q) inverse) with Shoup twiddles
+//             {w, floor(w*2^64/q)} and an under-estimated quotient (no carry chain in the 64x64 high word):
+//             9 integer multiplies + ~15 other instructions per butterfly, every one a 4-6 cycle issue slot.
 //   ArithF64  primes < 2^41 (SEAL's 30..40-bit data primes): coefficients are kept as exact integers in
 //             doubles and x*w mod q is computed EXACTLY with FMA: h = x*w, l = fma(x,w,-h) (exact product),
 //             c = rint(h * (1/q)), t = fma(-c,q,h) + l, |t| < 0.52q; 6 fp64 instructions (~32 cycles measured),
@@ -68,8 +68,13 @@ struct NttCfg {
 struct ArithU64 {
     typedef u64 V;
     typedef ulonglong2 TW;  // {w, floor(w*2^64/q)}
+    // Lazy ranges (q < 2^61, so 8q < 2^64): forward values live in [0,8q), inverse values in [0,4q).  The twiddle
+    // product is shoup_lazy4 -- Shoup's multiplication with the quotient under-estimated by up to 2 (result in [0,4q)
+    // instead of [0,2q)), which drops the carry chain of the exact 64x64 high word: ~24 instead of ~31 instructions per
+    // butterfly, each of which costs a 4-6 cycle issue slot on gfx950.  All stored results are
+    // canonical, so the bits are those of any exact arithmetic.
     struct Ctx {
-        u64 q, two_q;
+        u64 q, two_q, four_q;
         u64 ninv, ninv_s, ilw, ilw_s;
     };
     __device__ static __forceinline__ Ctx make(const ModConst &mc)
@@ -77,38 +82,40 @@ struct ArithU64 {
         Ctx c;
         c.q = mc.q;
         c.two_q = mc.q << 1;
+        c.four_q = mc.q << 2;
         c.ninv = mc.ninv;
         c.ninv_s = mc.ninv_s;
         c.ilw = mc.ilw;
         c.ilw_s = mc.ilw_s;
         return c;
     }
-    // forward butterfly, inputs/outputs in [0,4q)
+    // forward butterfly, inputs/outputs in [0,8q)
     __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
     {
-        u64 a = csub(x, c.two_q);
-        u64 t = shoup_lazy(y, w.x, w.y, c.q);
+        u64 a = csub(x, c.four_q);                      // [0,4q)
+        u64 t = shoup_lazy4(y, w.x, w.y, c.q);          // [0,4q), y any 64-bit word
         x = a + t;
-        y = a + c.two_q - t;
+        y = a + c.four_q - t;
     }
     // first stage of a split forward transform: keep X (h=0) or Y (h=1); x,y canonical
     __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
     {
-        const u64 t = shoup_lazy(y, w.x, w.y, c.q);
-        return h ? x + c.two_q - t : x + t;
+        const u64 t = shoup_lazy4(y, w.x, w.y, c.q);
+        return h ? x + c.four_q - t : x + t;            // < 5q
     }
-    // inverse butterfly, inputs/outputs in [0,2q)
+    // inverse butterfly, inputs/outputs in [0,4q)
     __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
     {
-        u64 s = csub(x + y, c.two_q);
-        u64 d = x + c.two_q - y;
+        u64 s = csub(x + y, c.four_q);
+        u64 d = x + c.four_q - y;                       // (0,8q)
         x = s;
-        y = shoup_lazy(d, w.x, w.y, c.q);
+        y = shoup_lazy4(d, w.x, w.y, c.q);
     }
+    // last inverse stage: exact Shoup products (outputs in [0,2q), what inv_finish expects)
     __device__ static __forceinline__ void gs_last(V &x, V &y, const Ctx &c)
     {
-        u64 s = csub(x + y, c.two_q);
-        u64 d = x + c.two_q - y;
+        u64 s = x + y;                                  // < 8q: fine for Shoup (any 64-bit word)
+        u64 d = x + c.four_q - y;
         x = shoup_lazy(s, c.ninv, c.ninv_s, c.q);
         y = shoup_lazy(d, c.ilw, c.ilw_s, c.q);
     }
@@ -116,7 +123,7 @@ struct ArithU64 {
     __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
     __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
     {
-        return shoup_lazy(a0 + c.two_q - a1, w.x, w.y, c.q);
+        return shoup_lazy4(a0 + c.q - a1, w.x, w.y, c.q);
     }
     __device__ static __forceinline__ void inv_pass_begin(V (&)[16], const Ctx &) {}
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
@@ -128,13 +135,16 @@ struct ArithU64 {
         if (m.has_sub) x = submod(x, m.sub, c.q);
         return x;
     }
-    __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return csub(csub(x, c.two_q), c.q); }
-    // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 4q):
+    __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c)
+    {
+        return csub(csub(csub(x, c.four_q), c.two_q), c.q);
+    }
+    // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 8q):
     // ((acc - f) * P^-1 + sadd) [* pt] mod q, canonical
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const ulonglong2 &pinv, const ModConst &mc)
     {
-        u64 z = acc + (c.two_q << 1) - f;                // < 5q
+        u64 z = acc + c.four_q - csub(f, c.four_q);      // < 5q (no 9q intermediate: primes may reach 2^61)
         z = shoup_lazy(z, pinv.x, pinv.y, c.q) + sadd;   // < 3q
         if (has_pt) return mulmod(z, pt, mc);            // product < 3q*q < q*2^64: Barrett128 gives [0,q)
         return csub(csub(z, c.two_q), c.q);
@@ -289,7 +299,7 @@ __device__ __forceinline__ void load_rem_tw(typename A::TW (&w)[15], const typen
     }
 }
 
-// v[r] holds coefficient idx_nat(t,r) on entry (U64: any value < 4q; F64: |v| <= ~2q) and the NTT value
+// v[r] holds coefficient idx_nat(t,r) on entry (U64: any value < 8q; F64: |v| <= ~2q) and the NTT value
 // idx_out(t,r) on exit, NOT yet canonical (apply A::fwd_finish).
 // `pre` is the twiddle-index prefix: 1 for a whole transform of size 2^LOGN; 2+h when this call is half h of a
 // transform of size 2^(LOGN+1) whose first stage was applied by the caller (stage s uses tw[(pre << s) + i]).
@@ -353,7 +363,7 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
     }
 }
 
-// v[r] holds NTT value idx_out(t,r) on entry (U64: [0,2q); F64: |v| < 2^45) and coefficient idx_nat(t,r) on exit,
+// v[r] holds NTT value idx_out(t,r) on entry (U64: [0,4q); F64: |v| < 2^45) and coefficient idx_nat(t,r) on exit,
 // NOT yet canonical (apply A::inv_finish).  itw[idx] = tw[idx]^-1 (same indexing); N^-1 folded in the last stage.
 template <int LOGN, class A>
 __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A::V *lds,
