@@ -230,6 +230,63 @@ int main()
         CHECK(fabs(dec(r)[0] - 3.0) < 1e-5, "a recorded rotation is materialised by decrypt");
     }
 
+    // the recorder as a dependency graph: the LR loop of the reference (logistic_regression_ckks.cpp:217-229 calling
+    // helper.h:432-476 per observation row) -- multiply, relinearize, rescale, rotate(-size), add, then size-1 times
+    // rotate-by-1 + add_inplace, a plaintext mod_switch and a mask product per row, add_many at the end -- recorded for
+    // ALL rows and run in lockstep must give the bits of call-by-call execution; also with a tiny pending budget
+    // (SEAL_SHIM_PENDING_MB-style forced flushes in the middle of the chains)
+    {
+        const int rows = 5, size = 4;
+        auto run = [&](bool lazy, std::size_t budget) {
+            auto e = context->engine();
+            e->live();
+            e->lazy = lazy;
+            const std::size_t old_budget = e->pend_budget;
+            e->pend_budget = budget;
+            vector<Ciphertext> results(rows);
+            for (int i = 0; i < rows; i++) {
+                Ciphertext feat;
+                evaluator.rotate_vector(ca, i, gk, feat);  // stands in for features[i] (distinct ciphertexts)
+                Ciphertext mult;
+                evaluator.multiply(feat, cb, mult);
+                evaluator.relinearize_inplace(mult, rk);
+                evaluator.rescale_to_next_inplace(mult);
+                Ciphertext zero_filled, dup;
+                evaluator.rotate_vector(mult, -size, gk, zero_filled);
+                evaluator.add(mult, zero_filled, dup);
+                for (int j = 1; j < size; j++) {
+                    evaluator.rotate_vector_inplace(dup, 1, gk);
+                    evaluator.add_inplace(mult, dup);
+                }
+                mult.scale() = pow(2.0, (int)log2(mult.scale()));
+                vector<double> mask(rows, 0.0);
+                mask[i] = 1.0;
+                Plaintext mask_pt;
+                encoder.encode(mask, scale, mask_pt);                // eager: must not interrupt the recording
+                evaluator.mod_switch_to_next_inplace(mask_pt);
+                evaluator.multiply_plain_inplace(mult, mask_pt);
+                results[i] = mult;
+            }
+            const std::size_t recorded = e->pend.size();
+            Ciphertext sum;
+            evaluator.add_many(results, sum);
+            Ciphertext diff;
+            evaluator.sub(results[0], results[1], diff);
+            e->lazy = true;
+            e->pend_budget = old_budget;
+            return std::make_tuple(shim::download(sum.buf), shim::download(diff.buf), recorded, sum.scale());
+        };
+        const auto lazy = run(true, (std::size_t)8192 << 20), eager = run(false, (std::size_t)8192 << 20),
+                   tiny = run(true, (std::size_t)3 << 20);
+        CHECK(std::get<0>(lazy) == std::get<0>(eager) && std::get<1>(lazy) == std::get<1>(eager) &&
+                  std::get<3>(lazy) == std::get<3>(eager),
+              "LR loop recorded for all rows == call-by-call execution, bit for bit");
+        CHECK(std::get<0>(tiny) == std::get<0>(eager) && std::get<1>(tiny) == std::get<1>(eager),
+              "LR loop with forced mid-chain flushes (3 MB pending budget) == call-by-call execution");
+        CHECK(std::get<2>(lazy) >= (std::size_t)rows * (3 + 2 * size) && std::get<2>(eager) == 0,
+              "the whole loop stays recorded until add_many (encode / plaintext mod_switch do not flush)");
+    }
+
     // SEAL's error behaviour at the boundary
     Ciphertext low = ca;
     evaluator.mod_switch_to_next_inplace(low);

@@ -91,6 +91,12 @@ int hefx_negate(hefx_context *ctx, int L, int size, int count, const uint64_t *d
                 void *stream);
 int hefx_add_plain(hefx_context *ctx, int L, int size, const uint64_t *d_ct, const uint64_t *d_pt,
                    uint64_t *d_out, void *stream);
+/* n independent pairs in one launch: d_out[i] = d_a[i] +/- d_b[i] (the add / add_inplace of n dot-product chains in
+ * lockstep, helper.h:464,475).  Host arrays of device pointers; d_out[i] may alias d_a[i] or d_b[i]. */
+int hefx_add_batch(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_a, const uint64_t *const *d_b,
+                   uint64_t *const *d_out, void *stream);
+int hefx_sub_batch(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_a, const uint64_t *const *d_b,
+                   uint64_t *const *d_out, void *stream);
 /* Evaluator::add_many (helper.h:231,259,275,319): out = sum of n ciphertexts (one n-way reduction). */
 int hefx_add_many(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_in, uint64_t *d_out,
                   void *stream);
@@ -103,6 +109,11 @@ int hefx_add_many(hefx_context *ctx, int L, int size, int n, const uint64_t *con
 int hefx_multiply_plain(hefx_context *ctx, int L, int size, int count, const uint64_t *d_ct,
                         const uint64_t *d_pt, uint64_t *d_out, void *stream);
 int hefx_check_transparent(hefx_context *ctx, void *stream);
+/* n independent products in one launch: d_outs[i] = d_cts[i] (.) d_pts[i] (the mask products of
+ * logistic_regression_ckks.cpp:229 over all rows).  Host arrays of device pointers; no output may alias its input;
+ * transparency is the caller's check (the plaintexts' zero flags), as for hefx_multiply_plain_sum. */
+int hefx_multiply_plain_batch(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_cts,
+                              const uint64_t *const *d_pts, uint64_t *const *d_outs, void *stream);
 /* Linear_Transform_CipherMatrix_PlainVector (helper.h:265-278: add_many of multiply_plain results, :271,:275) and the
  * inner sums of a baby-step/giant-step transform, in one pass: for g in [0, ceil(n/group)):
  *   d_outs[g] = sum_{i in [g*group, min(n,(g+1)*group))} d_cts[i] (.) d_pts[i]   (mod q_j per row)
@@ -161,6 +172,10 @@ int hefx_rescale_to_next(hefx_context *ctx, int L, int size, int count, const ui
                          void *stream);
 int hefx_rescale_to_next_mode(hefx_context *ctx, int L, int size, int count, const uint64_t *d_in, uint64_t *d_out,
                               int mode, void *stream);
+/* n independent ciphertexts through host arrays of device pointers (the rescales of n dot products advancing in
+ * lockstep, helper.h:441 over logistic_regression_ckks.cpp:217); uses the context's mode; d_out[i] != d_in[i]. */
+int hefx_rescale_to_next_batch(hefx_context *ctx, int L, int size, int n, const uint64_t *const *d_in,
+                               uint64_t *const *d_out, void *stream);
 int hefx_set_rescale_mode(hefx_context *ctx, int mode);
 int hefx_get_rescale_mode(const hefx_context *ctx);
 /* ---- K9: Evaluator::mod_switch_to_next / mod_switch_to for CKKS ct and pt (matrix_multiplication.cpp:112):

@@ -67,6 +67,10 @@ _SIGS = {
     "hefx_relinearize_batch": (_i, [_vp, _i, _i, _pp, _vp, _pp, _vp]),
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_rescale_to_next_mode": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "hefx_rescale_to_next_batch": (_i, [_vp, _i, _i, _i, _pp, _pp, _vp]),
+    "hefx_add_batch": (_i, [_vp, _i, _i, _i, _pp, _pp, _pp, _vp]),
+    "hefx_sub_batch": (_i, [_vp, _i, _i, _i, _pp, _pp, _pp, _vp]),
+    "hefx_multiply_plain_batch": (_i, [_vp, _i, _i, _i, _pp, _pp, _pp, _vp]),
     "hefx_set_rescale_mode": (_i, [_vp, _i]),
     "hefx_get_rescale_mode": (_i, [_vp]),
     "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

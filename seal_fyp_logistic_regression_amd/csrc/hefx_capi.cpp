@@ -1066,9 +1066,88 @@ static int rescale_common(hefx_context *c, int L, int size, int count, const uin
     if (mode != HEFX_RESCALE_FLOOR && mode != HEFX_RESCALE_ROUND) return fail(HEFX_ERR_INVALID, "bad rescale mode");
     if (c->logn < 11) return fail(HEFX_ERR_UNSUPPORTED, "key switching / rescale need poly_degree >= 2048");
     if (int rc = ensure_scratch(c, (size_t)c->n * size * count)) return rc;
-    HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, c->scratch, mode == HEFX_RESCALE_ROUND,
-                          (hipStream_t)stream));
+    HIPCHK(launch_rescale(c->T, L, size, count, (const u64 *)in, (u64 *)out, nullptr, c->scratch,
+                          mode == HEFX_RESCALE_ROUND, (hipStream_t)stream));
     return HEFX_OK;
+}
+
+// Pointer tables of the *_batch entries travel through a ring slot of the key-switch descriptors (pinned host mirror
+// -> device copy, one async copy per slice).  fill(hp, i0, cnt) writes the slice's table; run(dp, cnt) launches on it.
+template <class Fill, class Run>
+static int table_slices(hefx_context *c, int n, int ptrs_per_item, hipStream_t s, Fill fill, Run run)
+{
+    const int SLICE = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *)) / ptrs_per_item;
+    for (int i0 = 0; i0 < n; i0 += SLICE) {
+        const int cnt = n - i0 < SLICE ? n - i0 : SLICE;
+        const unsigned slot = c->ring_next++ % KS_RING;
+        if (c->ring_busy[slot]) HIPCHK(hipEventSynchronize(c->ring_ev[slot]));
+        const uint64_t **hp = reinterpret_cast<const uint64_t **>(c->h_items + (size_t)slot * KS_MAX_CHUNK);
+        const u64 *const *dp = reinterpret_cast<const u64 *const *>(c->d_items + (size_t)slot * KS_MAX_CHUNK);
+        fill(hp, i0, cnt);
+        HIPCHK(hipMemcpyAsync((void *)dp, hp, sizeof(void *) * (size_t)ptrs_per_item * cnt, hipMemcpyHostToDevice, s));
+        HIPCHK(run(dp, i0, cnt));
+        HIPCHK(hipEventRecord(c->ring_ev[slot], s));
+        c->ring_busy[slot] = true;
+    }
+    return HEFX_OK;
+}
+
+extern "C" int hefx_rescale_to_next_batch(hefx_context *c, int L, int size, int n, const uint64_t *const *in,
+                                          uint64_t *const *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (L < 2) return fail(HEFX_ERR_INVALID, "cannot rescale at the last level");
+    if (size < 1 || n < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad rescale arguments");
+    if (c->logn < 11) return fail(HEFX_ERR_UNSUPPORTED, "key switching / rescale need poly_degree >= 2048");
+    for (int i = 0; i < n; ++i)
+        if (!in[i] || !out[i] || in[i] == out[i])
+            return fail(HEFX_ERR_INVALID, "null or aliasing operand in rescale batch");
+    const int SLICE = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *)) / 2;
+    if (int rc = ensure_scratch(c, (size_t)c->n * size * (n < SLICE ? n : SLICE))) return rc;
+    const bool rounded = c->rescale_mode == HEFX_RESCALE_ROUND;
+    return table_slices(
+        c, n, 2, (hipStream_t)stream,
+        [&](const uint64_t **hp, int i0, int cnt) {
+            for (int i = 0; i < cnt; ++i) hp[i] = in[i0 + i], hp[cnt + i] = out[i0 + i];
+        },
+        [&](const u64 *const *dp, int, int cnt) {
+            return launch_rescale(c->T, L, size, cnt, nullptr, nullptr, dp, c->scratch, rounded, (hipStream_t)stream);
+        });
+}
+
+static int addsub_batch(hefx_context *c, bool sub, int L, int size, int n, const uint64_t *const *a,
+                        const uint64_t *const *b, uint64_t *const *out, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (n < 1 || size < 1 || !a || !b || !out) return fail(HEFX_ERR_INVALID, "bad element-wise batch arguments");
+    for (int i = 0; i < n; ++i)
+        if (!a[i] || !b[i] || !out[i]) return fail(HEFX_ERR_INVALID, "null operand in element-wise batch");
+    return table_slices(
+        c, n, 3, (hipStream_t)stream,
+        [&](const uint64_t **hp, int i0, int cnt) {
+            for (int i = 0; i < cnt; ++i) hp[i] = a[i0 + i], hp[cnt + i] = b[i0 + i], hp[2 * cnt + i] = out[i0 + i];
+        },
+        [&](const u64 *const *dp, int, int cnt) {
+            return launch_addsub_table(c->T, sub, L, size, dp, cnt, (hipStream_t)stream);
+        });
+}
+extern "C" int hefx_add_batch(hefx_context *c, int L, int size, int n, const uint64_t *const *a,
+                              const uint64_t *const *b, uint64_t *const *out, void *stream)
+{
+    return addsub_batch(c, false, L, size, n, a, b, out, stream);
+}
+extern "C" int hefx_sub_batch(hefx_context *c, int L, int size, int n, const uint64_t *const *a,
+                              const uint64_t *const *b, uint64_t *const *out, void *stream)
+{
+    return addsub_batch(c, true, L, size, n, a, b, out, stream);
+}
+extern "C" int hefx_multiply_plain_batch(hefx_context *c, int L, int size, int n, const uint64_t *const *cts,
+                                         const uint64_t *const *pts, uint64_t *const *outs, void *stream)
+{
+    // n one-term sums: the same kernel, the same canonical products (transparency is the caller's check, as there)
+    return hefx_multiply_plain_sum(c, L, size, n, 1, cts, pts, outs, stream);
 }
 extern "C" int hefx_rescale_to_next(hefx_context *c, int L, int size, int count, const uint64_t *in, uint64_t *out,
                                     void *stream)

@@ -113,6 +113,9 @@ hipError_t launch_mulplain_sum(const DevTables &T, int L, int size, const u64 *c
 // table: n a-pointers | n b-pointers | n output pointers (device memory)
 hipError_t launch_multiply_table(const DevTables &T, int L, const u64 *const *d_tab, int n, hipStream_t s);
 hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b, u64 *out3, hipStream_t s);
+// table: n a-pointers | n b-pointers | n output pointers (device memory); element-wise add / sub of size*L rows
+hipError_t launch_addsub_table(const DevTables &T, bool sub, int L, int size, const u64 *const *d_tab, int n,
+                               hipStream_t s);
 // profiling: an event is recorded before every launch (tagged with its stage) and one after the last
 constexpr int KS_STAGES = 7;
 struct KsProf {
@@ -166,7 +169,8 @@ hipError_t warm_kernels(hipStream_t s);
 hipError_t warm_keyswitch(hipStream_t s);
 hipError_t warm_encode(hipStream_t s);
 hipError_t warm_sample(hipStream_t s);
-hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
-                          bool rounded, hipStream_t s);
+// in / out: `count` contiguous ciphertexts, or (tab != nullptr) a device pointer table  in[0..count) | out[0..count)
+hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out,
+                          const u64 *const *tab, u64 *scratch_d, bool rounded, hipStream_t s);
 
 }  // namespace hefx

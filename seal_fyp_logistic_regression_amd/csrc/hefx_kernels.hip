@@ -379,6 +379,42 @@ hipError_t launch_multiply_table(const DevTables &T, int L, const u64 *const *d_
 }
 
 
+// n independent element-wise sums / differences through a DEVICE pointer table  a[0..n) | b[0..n) | out[0..n): the adds
+// of n dot-product chains advancing in lockstep (helper.h:464,475 over the rows of logistic_regression_ckks.cpp:217)
+// as one launch.  out[i] may alias a[i] or b[i] (element-wise).
+template <bool SUB>
+__global__ __launch_bounds__(256) void addsub_table_kernel(DevTables T, int L, size_t total_pairs,
+                                                           const u64 *const *__restrict__ tab, int n)
+{
+    const int logn = T.logn;
+    const int item = blockIdx.y;
+    const ulonglong2 *a = reinterpret_cast<const ulonglong2 *>(tab[item]);
+    const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(tab[n + item]);
+    ulonglong2 *out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + item]));
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
+         w += (size_t)gridDim.x * blockDim.x) {
+        const u64 q = T.mods[(int)((w >> (logn - 1)) % (size_t)L)].q;
+        const ulonglong2 x = a[w], y = b[w];
+        ulonglong2 r;
+        r.x = SUB ? submod(x.x, y.x, q) : addmod(x.x, y.x, q);
+        r.y = SUB ? submod(x.y, y.y, q) : addmod(x.y, y.y, q);
+        out[w] = r;
+    }
+}
+
+hipError_t launch_addsub_table(const DevTables &T, bool sub, int L, int size, const u64 *const *d_tab, int n,
+                               hipStream_t s)
+{
+    const size_t total_pairs = (size_t)size * L * ((size_t)1 << T.logn) / 2;
+    int blocks = (int)((total_pairs + 255) / 256);
+    if (blocks > 64) blocks = 64;  // n items in grid.y fill the chip
+    if (sub)
+        hipLaunchKernelGGL(addsub_table_kernel<true>, dim3(blocks, n), dim3(256), 0, s, T, L, total_pairs, d_tab, n);
+    else
+        hipLaunchKernelGGL(addsub_table_kernel<false>, dim3(blocks, n), dim3(256), 0, s, T, L, total_pairs, d_tab, n);
+    return hipGetLastError();
+}
+
 // HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
 // that once, up front, instead of the first encode / rotation / encryption of a program.
 __global__ void warm_kernels_kernel() {}

@@ -819,7 +819,8 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 //                     divide_and_round_q_last) -- the same plumbing as the key-switch mod-down by P.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt_kernel(DevTables T, int L, int rows, const u64 *in,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt_kernel(DevTables T, int L, int size, int rows,
+                                                                       const u64 *in, const u64 *const *__restrict__ tab,
                                                                        u64 *d, int rounded)
 {
     using SC = SplitCfg<LOGN>;
@@ -829,8 +830,9 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt
     split_decode(blockIdx.x, p, h);
     if (p >= rows) return;  // p runs over count*size polys
     const int t = threadIdx.x;
-    const ulonglong2 *__restrict__ src =
-        reinterpret_cast<const ulonglong2 *>(in + ((size_t)p * L + (L - 1)) * SC::N);
+    // poly p of the batch: contiguous ciphertexts, or ciphertext p / size of a pointer table
+    const u64 *__restrict__ base = tab ? tab[p / size] + (size_t)(p % size) * L * SC::N : in + (size_t)p * L * SC::N;
+    const ulonglong2 *__restrict__ src = reinterpret_cast<const ulonglong2 *>(base + (size_t)(L - 1) * SC::N);
     u64 v[16];
     split_inv<LOGN, KsWaves<LOGN>::NB_INV>(v, src, lds, ntt_tables(T, L - 1), T.mods[L - 1], T.modsf[L - 1], t, h);
     u64 *__restrict__ dd = d + (size_t)p * SC::N + (size_t)h * SC::H;
@@ -840,7 +842,9 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void rs_intt
 }
 
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_finish_kernel(DevTables T, int L, int rows, const u64 *in,
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_finish_kernel(DevTables T, int L, int size, int count,
+                                                                         int rows, const u64 *in,
+                                                                         const u64 *const *__restrict__ tab,
                                                                          const u64 *d, u64 *out, int rounded)
 {
     using SC = SplitCfg<LOGN>;
@@ -865,8 +869,10 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     };
     split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
     const size_t off = (size_t)h * SC::H;
-    const u64 *__restrict__ src = in + ((size_t)poly * L + j) * SC::N + off;
-    u64 *__restrict__ dst = out + ((size_t)poly * (L - 1) + j) * SC::N + off;
+    const int ci = poly / size, pi = poly % size;
+    const u64 *__restrict__ src = (tab ? tab[ci] + (size_t)pi * L * SC::N : in + (size_t)poly * L * SC::N) + (size_t)j * SC::N + off;
+    u64 *__restrict__ dst = (tab ? const_cast<u64 *>(tab[count + ci]) + (size_t)pi * (L - 1) * SC::N
+                                 : out + (size_t)poly * (L - 1) * SC::N) + (size_t)j * SC::N + off;
     u64 a[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) a[r] = src[C::idx_out(t, r)];
@@ -879,7 +885,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
 
 template <int LOGN>
 static hipError_t launch_rescale_t(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out,
-                                   u64 *scratch_d, bool rounded, hipStream_t s)
+                                   const u64 *const *tab, u64 *scratch_d, bool rounded, hipStream_t s)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -889,17 +895,17 @@ static hipError_t launch_rescale_t(const DevTables &T, int L, int size, int coun
         set_lds(rs_finish_kernel<LOGN>, lds);
     }
     const int polys = size * count;
-    hipLaunchKernelGGL((rs_intt_kernel<LOGN>), dim3(split_grid(polys)), dim3(SC::T), lds, s, T, L, polys, in,
+    hipLaunchKernelGGL((rs_intt_kernel<LOGN>), dim3(split_grid(polys)), dim3(SC::T), lds, s, T, L, size, polys, in, tab,
                        scratch_d, rounded ? 1 : 0);
-    hipLaunchKernelGGL((rs_finish_kernel<LOGN>), dim3(split_grid(polys * (L - 1))), dim3(SC::T), lds, s, T, L,
-                       polys * (L - 1), in, scratch_d, out, rounded ? 1 : 0);
+    hipLaunchKernelGGL((rs_finish_kernel<LOGN>), dim3(split_grid(polys * (L - 1))), dim3(SC::T), lds, s, T, L, size,
+                       count, polys * (L - 1), in, tab, scratch_d, out, rounded ? 1 : 0);
     return hipGetLastError();
 }
 
-hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out, u64 *scratch_d,
-                          bool rounded, hipStream_t s)
+hipError_t launch_rescale(const DevTables &T, int L, int size, int count, const u64 *in, u64 *out,
+                          const u64 *const *tab, u64 *scratch_d, bool rounded, hipStream_t s)
 {
-#define CALL(LN) launch_rescale_t<LN>(T, L, size, count, in, out, scratch_d, rounded, s)
+#define CALL(LN) launch_rescale_t<LN>(T, L, size, count, in, out, tab, scratch_d, rounded, s)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

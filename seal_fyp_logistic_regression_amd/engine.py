@@ -215,9 +215,10 @@ class Engine:
         outs = self.empty_many(n, (size, L, self.N))
         if n > 1 and self.contiguous(As) and self.contiguous(Bs):
             capi.check(capi.lib().hefx_add(self._h, L, size, n, As[0].ptr, Bs[0].ptr, outs[0].ptr, stream))
-        else:
-            for a, b, o in zip(As, Bs, outs):
-                capi.check(capi.lib().hefx_add(self._h, L, size, 1, a.ptr, b.ptr, o.ptr, stream))
+        else:  # scattered operands: one launch over a pointer table
+            capi.check(capi.lib().hefx_add_batch(self._h, L, size, n, capi.ptr_array([a.ptr for a in As]),
+                                                 capi.ptr_array([b.ptr for b in Bs]),
+                                                 capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
     def rescale_batch(self, L, size, cts, stream=None):
@@ -226,9 +227,9 @@ class Engine:
         outs = self.empty_many(n, (size, L - 1, self.N))
         if n > 1 and self.contiguous(cts):
             capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, n, cts[0].ptr, outs[0].ptr, stream))
-        else:
-            for c, o in zip(cts, outs):
-                capi.check(capi.lib().hefx_rescale_to_next(self._h, L, size, 1, c.ptr, o.ptr, stream))
+        else:  # scattered operands: one launch pair over a pointer table
+            capi.check(capi.lib().hefx_rescale_to_next_batch(self._h, L, size, n, capi.ptr_array([c.ptr for c in cts]),
+                                                             capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
     def square(self, L, a, out=None, stream=None):
