@@ -227,6 +227,26 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int):
                         "bits_equal_serial": bool(mn[1].item() == 1.0),
                         "allreduce_bytes": 2 * (len(primes) - 1) * N * 8})
             assert rec["bits_equal_serial"], f"sharded linear transform (d={d}) differs from the serial one"
+            if dist.get_backend() == "nccl" and os.environ.get("HEFX_BENCH_C_ABI_COMM") == "1":
+                # opt-in (a second communicator that could not be exercised on a one-GPU box must not be able to stall
+                # the scaling run): the same transform with the exchange behind the C-ABI (hefx_allreduce_sum: RCCL called by libhefx
+                # itself, in place on the payload) instead of torch.distributed; reported next to it, never fatal
+                try:
+                    par.init_engine_comm(ev)
+                    via, via_ms = timed(lambda: par.linear_transform_plain_sharded(ev, ct, diags, gk))
+                    tt = torch.tensor([via_ms, 1.0 if bool((bits(serial) == bits(via)).all()) else 0.0],
+                                      dtype=torch.float64).cuda()
+                    mx, mn = tt.clone(), tt.clone()
+                    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                    dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+                    rec["c_abi_allreduce"] = {"sharded_ms": float(mx[0].item()), "bits_equal_serial": bool(mn[1].item() == 1.0)}
+                except Exception as ex:
+                    rec["c_abi_allreduce"] = {"error": repr(ex)[:300]}
+                finally:
+                    try:
+                        eng.comm_destroy()
+                    except Exception:
+                        pass
         out[f"d{d}"] = rec
     return out
 

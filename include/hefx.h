@@ -183,8 +183,23 @@ int hefx_get_rescale_mode(const hefx_context *ctx);
 int hefx_mod_drop(hefx_context *ctx, int L_in, int L_out, int npoly, const uint64_t *d_in, uint64_t *d_out,
                   void *stream);
 
-/* ---- multi-GPU tail (no reference call site): after an RCCL sum all-reduce of uint64
- *      partial ciphertexts (<= `addends` canonical addends per word), bring every word back to [0,q_j). */
+/* ---- multi-GPU exchange (no reference call site; SURVEY.md 8b "hefx_allreduce_sum(ct, comm)", 8e).  The path shards
+ *      by independent units (diagonals of a transform, Step-2 transforms of a matrix product, LR rows) with every rank
+ *      holding the inputs and keys; the ONE exchange is the final ciphertext sum.
+ *      One process per GPU, one context per process, one communicator per context: rank 0 obtains 128 opaque bytes with
+ *      hefx_comm_unique_id and hands them to the other ranks out of band (file, environment, MPI, a torch store);
+ *      every rank then calls hefx_comm_init(world <= 8).  RCCL is loaded at run time (dlopen): none of this touches it
+ *      until hefx_comm_*; HEFX_ERR_UNSUPPORTED when librccl is absent.
+ *      hefx_allreduce_sum: in place, all ranks -- all-reduce(SUM) of the uint64 words over xGMI, then every word back
+ *      to [0,q_j): bit-identical to a serial add_many of the ranks' partials (helper.h:259).
+ *      hefx_reduce_canonical is the local half alone, for callers that run the collective themselves
+ *      (parallel.py over torch.distributed). */
+int hefx_comm_unique_id(uint8_t *id128);
+int hefx_comm_init(hefx_context *ctx, int world, int rank, const uint8_t *id128);
+int hefx_comm_destroy(hefx_context *ctx);
+int hefx_comm_world(const hefx_context *ctx); /* 0 = no communicator */
+int hefx_comm_rank(const hefx_context *ctx);
+int hefx_allreduce_sum(hefx_context *ctx, int L, int size, uint64_t *d_ct, void *stream);
 int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, int addends, void *stream);
 
 /* ---- Linear_Transform_Plain(ct, U_diagonals[d], gal_keys) (helper.h:237-262 = linear_transformation2.cpp:149-174)

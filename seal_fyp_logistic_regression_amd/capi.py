@@ -75,6 +75,12 @@ _SIGS = {
     "hefx_get_rescale_mode": (_i, [_vp]),
     "hefx_mod_drop": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
     "hefx_reduce_canonical": (_i, [_vp, _i, _i, _vp, _i, _vp]),
+    "hefx_comm_unique_id": (_i, [C.c_char_p]),
+    "hefx_comm_init": (_i, [_vp, _i, _i, C.c_char_p]),
+    "hefx_comm_destroy": (_i, [_vp]),
+    "hefx_comm_world": (_i, [_vp]),
+    "hefx_comm_rank": (_i, [_vp]),
+    "hefx_allreduce_sum": (_i, [_vp, _i, _i, _vp, _vp]),
     "hefx_linear_transform_plain": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_rotate_hoisted_batch": (_i, [_vp, _i, _vp, _i, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_linear_transform_plain_hoisted": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),

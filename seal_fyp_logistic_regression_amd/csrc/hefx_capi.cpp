@@ -14,6 +14,8 @@
 #include <unordered_map>
 #include <vector>
 
+#include <dlfcn.h>
+
 #include "hefx_internal.h"
 
 using namespace hefx;
@@ -146,6 +148,8 @@ struct hefx_context {
     int chunk = 0;  // items per launch sequence; 0 = sized from the scratch budget (HEFX_CHUNK overrides)
     int *d_flag = nullptr;  // [0] transparent count, [1 + i] "non-zero seen beyond c0" of ciphertext i of the call
     int flag_cap = 1 + 4096;
+    void *comm = nullptr;  // ncclComm_t of hefx_comm_init (RCCL, resolved at run time), one per context = per rank
+    int comm_world = 0, comm_rank = 0;
     int rescale_mode = HEFX_RESCALE_FLOOR;  // default of hefx_rescale_to_next (HEFX_RESCALE=round|floor presets it)
     static constexpr int MAX_STREAMS = 4;
     hipStream_t streams[MAX_STREAMS] = {};  // internal streams for chunk pipelining
@@ -412,11 +416,13 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     return HEFX_OK;
 }
 
+extern "C" int hefx_comm_destroy(hefx_context *c);
 extern "C" void hefx_context_destroy(hefx_context *c)
 {
     if (!c) return;
     DevGuard devguard(c->device);
     (void)hipDeviceSynchronize();
+    (void)hefx_comm_destroy(c);
     for (auto &sl : c->pool_slabs)  // every slab, parked or not: the context's memory ends with the context
         if (sl.base) (void)hipFree(sl.base);
     for (auto &kv : c->perm) (void)hipFree(kv.second);
@@ -1179,6 +1185,113 @@ extern "C" int hefx_mod_drop(hefx_context *c, int L_in, int L_out, int npoly, co
     HIPCHK(hipMemcpy2DAsync(out, row * L_out, in, row * L_in, row * L_out, npoly, hipMemcpyDeviceToDevice,
                             (hipStream_t)stream));
     return HEFX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// multi-GPU exchange behind the boundary (SURVEY 8b hefx_allreduce_sum, 8e): RCCL over xGMI, one communicator per
+// context (= per rank, one rank per GPU).  librccl is resolved at run time with dlopen -- libhefx.so has no link-time
+// dependency on it, single-GPU users never load it, and inside a torch process the SONAME resolves to the copy
+// torch.distributed already loaded.  Types and constants below are RCCL's public ABI (rccl.h: ncclUniqueId is 128
+// opaque bytes, ncclUint64 = 5, ncclSum = 0, ncclSuccess = 0).
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct RcclId {
+    char internal[128];
+};
+struct RcclApi {
+    int (*GetUniqueId)(RcclId *) = nullptr;
+    int (*CommInitRank)(void **, int, RcclId, int) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+    std::string why;
+};
+RcclApi &rccl()
+{
+    static RcclApi api = [] {
+        RcclApi a;
+        void *h = nullptr;
+        for (const char *name : {"librccl.so.1", "librccl.so"}) {
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // the copy the process already uses, if any
+            if (h) break;
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        }
+        if (!h) {
+            a.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");
+            return a;
+        }
+        a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
+        a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
+        a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+        a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
+        a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+        a.ok = a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString;
+        if (!a.ok) a.why = "librccl lacks the expected symbols";
+        return a;
+    }();
+    return api;
+}
+int rcclfail(int rc, const char *what)
+{
+    return fail(HEFX_ERR_HIP, std::string(what) + ": " + (rccl().GetErrorString ? rccl().GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+extern "C" int hefx_comm_unique_id(uint8_t *id128)
+{
+    if (!id128) return fail(HEFX_ERR_INVALID, "null id buffer");
+    if (!rccl().ok) return fail(HEFX_ERR_UNSUPPORTED, rccl().why);
+    RcclId id;
+    if (int rc = rccl().GetUniqueId(&id)) return rcclfail(rc, "ncclGetUniqueId");
+    memcpy(id128, id.internal, sizeof id.internal);
+    return HEFX_OK;
+}
+extern "C" int hefx_comm_init(hefx_context *c, int world, int rank, const uint8_t *id128)
+{
+    CTXCHK(c);
+    if (!id128 || world < 1 || rank < 0 || rank >= world) return fail(HEFX_ERR_INVALID, "bad communicator arguments");
+    if (world > 8) return fail(HEFX_ERR_INVALID, "the wrap-free uint64 sum holds for at most 8 ranks (residues < 2^61)");
+    if (c->comm) return fail(HEFX_ERR_INVALID, "the context already has a communicator");
+    if (!rccl().ok) return fail(HEFX_ERR_UNSUPPORTED, rccl().why);
+    RcclId id;
+    memcpy(id.internal, id128, sizeof id.internal);
+    void *comm = nullptr;
+    if (int rc = rccl().CommInitRank(&comm, world, id, rank)) return rcclfail(rc, "ncclCommInitRank");
+    c->comm = comm;
+    c->comm_world = world;
+    c->comm_rank = rank;
+    return HEFX_OK;
+}
+extern "C" int hefx_comm_destroy(hefx_context *c)
+{
+    CTXCHK(c);
+    if (c->comm) {
+        (void)rccl().CommDestroy(c->comm);
+        c->comm = nullptr;
+        c->comm_world = c->comm_rank = 0;
+    }
+    return HEFX_OK;
+}
+extern "C" int hefx_comm_world(const hefx_context *c) { return c ? c->comm_world : 0; }
+extern "C" int hefx_comm_rank(const hefx_context *c) { return c ? c->comm_rank : 0; }
+
+// sum of every rank's partial ciphertext, in place, canonical: one all-reduce(SUM, uint64) of size*L*N words -- exact,
+// at most 8 addends below 2^61 cannot wrap -- and the local reduction mod q_j.  Modular addition is associative, so
+// the bits equal a serial add_many over the ranks' partials (helper.h:259).
+extern "C" int hefx_allreduce_sum(hefx_context *c, int L, int size, uint64_t *d_ct, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (size < 1 || !d_ct) return fail(HEFX_ERR_INVALID, "bad all-reduce arguments");
+    if (!c->comm) return fail(HEFX_ERR_INVALID, "no communicator: call hefx_comm_init first");
+    const size_t words = (size_t)size * L * c->n;
+    if (int rc = rccl().AllReduce(d_ct, d_ct, words, /*ncclUint64*/ 5, /*ncclSum*/ 0, c->comm, (hipStream_t)stream))
+        return rcclfail(rc, "ncclAllReduce");
+    return hefx_reduce_canonical(c, L, size, d_ct, c->comm_world, stream);
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -221,6 +221,24 @@ class Engine:
                                                  capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
+    def sub_batch(self, L, size, As, Bs, outs=None, stream=None):
+        """[As[i] - Bs[i]] in one launch over a pointer table (hefx_sub_batch)"""
+        n = len(As)
+        outs = outs if outs is not None else self.empty_many(n, (size, L, self.N))
+        capi.check(capi.lib().hefx_sub_batch(self._h, L, size, n, capi.ptr_array([a.ptr for a in As]),
+                                             capi.ptr_array([b.ptr for b in Bs]), capi.ptr_array([o.ptr for o in outs]),
+                                             stream))
+        return outs
+
+    def multiply_plain_batch(self, L, size, cts, pts, outs=None, stream=None):
+        """[cts[i] (.) pts[i]] in one launch over a pointer table (hefx_multiply_plain_batch)"""
+        n = len(cts)
+        outs = outs if outs is not None else self.empty_many(n, (size, L, self.N))
+        capi.check(capi.lib().hefx_multiply_plain_batch(self._h, L, size, n, capi.ptr_array([c.ptr for c in cts]),
+                                                        capi.ptr_array([p.ptr for p in pts]),
+                                                        capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
     def rescale_batch(self, L, size, cts, stream=None):
         """[rescale_to_next(ct)]: one launch when the inputs are a slab"""
         n = len(cts)
@@ -300,6 +318,30 @@ class Engine:
 
     def reduce_canonical(self, L, size, buf, addends=8, stream=None):
         capi.check(capi.lib().hefx_reduce_canonical(self._h, L, size, buf.ptr, addends, stream))
+        return buf
+
+    # ---- multi-GPU exchange behind the C-ABI (RCCL, loaded at run time)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        capi.check(capi.lib().hefx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, world: int, rank: int, unique_id: bytes):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        capi.check(capi.lib().hefx_comm_init(self._h, world, rank, unique_id))
+
+    def comm_destroy(self):
+        capi.check(capi.lib().hefx_comm_destroy(self._h))
+
+    @property
+    def comm_world(self) -> int:
+        return int(capi.lib().hefx_comm_world(self._h))
+
+    def allreduce_sum(self, L, size, buf, stream=None):
+        """in place: sum over the ranks of the communicator, canonical (hefx_allreduce_sum)"""
+        capi.check(capi.lib().hefx_allreduce_sum(self._h, L, size, buf.ptr, stream))
         return buf
 
     def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None, outs=None, stream=None):

@@ -25,6 +25,20 @@ def shard(n: int, rank: int, world: int) -> range:
     return range(start, start + base + (1 if rank < rem else 0))
 
 
+def init_engine_comm(ev: Evaluator, group=None) -> None:
+    """Attach an RCCL communicator to the evaluator's HIP engine (hefx_comm_init): rank 0 draws the 128-byte id, the
+    torch.distributed group only carries it to the other ranks.  From then on allreduce_ciphertext runs entirely behind
+    the C-ABI (hefx_allreduce_sum: RCCL in place on the payload + local canonicalisation)."""
+    import torch.distributed as dist
+    eng = ev.be.engine
+    if eng.comm_world:
+        return
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    box = [eng.comm_unique_id() if rank == 0 else None]
+    dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    eng.comm_init(world, rank, box[0])
+
+
 def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertext:
     """sum of every rank's `ct` (same level/scale/size), bit-identical to a serial add_many"""
     import torch
@@ -33,6 +47,10 @@ def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertex
     world = dist.get_world_size(group)
     if world > 8:
         raise ValueError("the wrap-free uint64 sum argument holds for at most 8 addends of < 2^61")
+    if be.name == "hip" and be.engine.comm_world == world:  # communicator behind the C-ABI (init_engine_comm)
+        out = be.engine.copy(ct.data)
+        be.engine.allreduce_sum(L, size, out)
+        return Ciphertext()._set(out, size, L, ct.scale)
     if be.name == "hip":
         from .engine import DeviceArray
         eng = be.engine

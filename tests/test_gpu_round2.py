@@ -361,3 +361,82 @@ def test_two_contexts_with_the_current_device_switched_underneath():
             assert (e.rescale_to_next(3, 2, m).download() == o.rescale(o.relinearize(o.multiply(ct, ct), key))).all()
     if ndev > 1:
         torch.cuda.set_device(0)
+
+
+def test_pointer_table_batch_entries_bit_exact():
+    """hefx_add_batch / hefx_sub_batch / hefx_multiply_plain_batch / hefx_rescale_to_next_batch (the lockstep batches the
+    C++ shim's recorder submits): scattered operands, more items than one pointer-table slice, size 2 and 3, both
+    rescale modes, in-place add."""
+    o, e, primes = _mk("C2")
+    L = 3
+    n = 9
+    A = [o.uniform(L, 2, 700 + i) for i in range(n)]
+    B = [o.uniform(L, 2, 800 + i) for i in range(n)]
+    P = [o.uniform(L, 1, 900 + i)[0] for i in range(n)]
+    dA, dB, dP = [e.to_device(x) for x in A], [e.to_device(x) for x in B], [e.to_device(x) for x in P]
+    pad = e.empty(12345)                      # keeps the next allocations from being a slab in order
+    outs = e.add_batch(L, 2, dA[::-1], dB)     # reversed list: not contiguous -> pointer-table path
+    for i in range(n):
+        assert (outs[i].download() == o.add(A[n - 1 - i], B[i])).all()
+    outs = e.sub_batch(L, 2, dA, dB)
+    for i in range(n):
+        assert (outs[i].download() == o.sub(A[i], B[i])).all()
+    e.sub_batch(L, 2, dA, dB, outs=dA)         # in place on the first operand
+    for i in range(n):
+        assert (dA[i].download() == o.sub(A[i], B[i])).all()
+    outs = e.multiply_plain_batch(L, 2, dB, dP)
+    for i in range(n):
+        assert (outs[i].download() == o.multiply_plain(B[i], P[i])).all()
+    M = [o.multiply(B[i], B[(i + 1) % n]) for i in range(4)]     # size 3
+    dM = [e.to_device(m) for m in M]
+    for rounded in (False, True):
+        e.set_rescale_rounded(rounded)
+        r2 = e.rescale_batch(L, 2, dB[::-1])
+        for i in range(n):
+            assert (r2[i].download() == o.rescale(B[n - 1 - i], rounded=rounded)).all()
+        r3 = e.rescale_batch(L, 3, dM[::-1])
+        for i in range(4):
+            assert (r3[i].download() == o.rescale(M[3 - i], rounded=rounded)).all()
+    e.set_rescale_rounded(False)
+    # more items than one table slice (the ring slot holds 1536 pointers: 512 triples / 768 pairs)
+    big = 800
+    idx = [i % n for i in range(big)]
+    outs = e.add_batch(L, 2, [dB[i] for i in idx], [dB[(i + 1) % n] for i in idx])
+    for t in (0, 511, 512, 799):
+        assert (outs[t].download() == o.add(B[idx[t]], B[(idx[t] + 1) % n])).all()
+    outs = e.rescale_batch(L, 2, [dB[i] for i in idx])
+    for t in (0, 767, 768, 799):
+        assert (outs[t].download() == o.rescale(B[idx[t]])).all()
+    with pytest.raises(ValueError):
+        e.rescale_batch(1, 2, dB[::-1])
+    del pad
+
+
+def test_c_abi_allreduce_on_a_one_rank_communicator():
+    """hefx_comm_unique_id / hefx_comm_init / hefx_allreduce_sum (RCCL resolved with dlopen inside libhefx.so).  A one-GPU
+    box can only host a one-rank communicator (RCCL wants one device per rank): the sum over one rank is the input, and
+    the local canonicalisation must bring words >= q_j back into [0,q_j).  The N>1 arithmetic (wrap-free uint64 sum +
+    reduction == serial add_many) is covered on CPU by tests/test_parallel_cpu.py."""
+    from seal_fyp_logistic_regression_amd import Engine
+    o, e, primes = _mk("C2")
+    L = 3
+    assert e.comm_world == 0
+    with pytest.raises(ValueError):
+        e.allreduce_sum(L, 2, e.to_device(o.uniform(L, 2, 1)))     # no communicator yet
+    uid = Engine.comm_unique_id()
+    assert len(uid) == 128
+    e.comm_init(1, 0, uid)
+    assert e.comm_world == 1
+    parts = [o.uniform(L, 2, 50 + i) for i in range(8)]
+    raw = np.zeros_like(parts[0])
+    want = np.zeros_like(parts[0])
+    for p_ in parts:                      # what 8 ranks' partials add up to before the reduction
+        raw = raw + p_
+        want = o.add(want, p_)
+    d = e.to_device(raw)
+    e.allreduce_sum(L, 2, d)
+    assert (d.download() == want).all()
+    with pytest.raises(ValueError):
+        e.comm_init(1, 0, uid)            # one communicator per context
+    e.comm_destroy()
+    assert e.comm_world == 0
