@@ -551,26 +551,32 @@ def cc_matrix_multiplication_sparse(ev: Evaluator, ctA: Ciphertext, ctB: Ciphert
     d = dimension * dimension
     ctA0 = linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys, hoisted)   # :22
     ctB0 = linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys, hoisted)     # :25
-    out = []
-    for ct0, diags in ((ctA0, V_diagonals), (ctB0, W_diagonals)):        # :42-43
-        ct_new = _duplicate(ev, ct0, d, gal_keys)
-        terms = [(l, p) for k in range(dimension - 1) for l, p in sorted(diags[k].items())]
-        counts = {len(diags[k]) for k in range(dimension - 1)}
-        if len(counts) == 1:  # phi^k: 2 diagonals each, psi^k: 1 -- all sums in one pass, results in one slab
-            steps = sorted({l for l, _ in terms if l})
-            rot = dict(zip(steps, _rotations_batched(ev, ct_new, steps, gal_keys)))
-            rot[0] = ct_new
-            cts = ev.multiply_plain_sum([rot[l] for l, _ in terms], [p for _, p in terms], group=counts.pop())
-        else:
-            prods = _sparse_products(ev, ct_new, terms, gal_keys)
-            cts, pos = [], 0
-            for k in range(dimension - 1):
-                cnt = len(diags[k])
-                cts.append(ev.add_many(prods[pos:pos + cnt]))
-                pos += cnt
-        out.append(cts)
-    ctAk, ctBk = out
+    ctAk = _sparse_transforms_of_one_input(ev, ctA0, d, V_diagonals, gal_keys)     # :42
+    ctBk = _sparse_transforms_of_one_input(ev, ctB0, d, W_diagonals, gal_keys)     # :43
     return _matmul_step3(ev, ctA0, ctB0, ctAk, ctBk)
+
+
+def _sparse_transforms_of_one_input(ev: Evaluator, ct0: Ciphertext, d: int, diag_dicts: Sequence[dict],
+                                    gal_keys: KSwitchKeys) -> List[Ciphertext]:
+    """[linear_transform_plain_sparse(ct0, d, diags) for diags in diag_dicts] (matrix_multiplication.cpp:40-43 over the
+    non-zero diagonals): the transforms read the same duplicated ciphertext, so the rotations they need go out as one
+    batch and -- when every transform has the same number of diagonals (phi^k: 2, psi^k: 1) -- all sums in one pass."""
+    if not diag_dicts:
+        return []
+    ct_new = _duplicate(ev, ct0, d, gal_keys)
+    terms = [(l, p) for diags in diag_dicts for l, p in sorted(diags.items())]
+    counts = {len(diags) for diags in diag_dicts}
+    if len(counts) == 1:
+        steps = sorted({l for l, _ in terms if l})
+        rot = dict(zip(steps, _rotations_batched(ev, ct_new, steps, gal_keys)))
+        rot[0] = ct_new
+        return ev.multiply_plain_sum([rot[l] for l, _ in terms], [p for _, p in terms], group=counts.pop())
+    prods = _sparse_products(ev, ct_new, terms, gal_keys)
+    cts, pos = [], 0
+    for diags in diag_dicts:
+        cts.append(ev.add_many(prods[pos:pos + len(diags)]))
+        pos += len(diags)
+    return cts
 
 
 # ---- polynomial evaluation and encrypted logistic regression (logistic_regression_ckks.cpp) -------------------

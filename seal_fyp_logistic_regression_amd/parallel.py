@@ -124,6 +124,57 @@ def cc_matrix_multiplication_sharded(ev: Evaluator, ctA: Ciphertext, ctB: Cipher
     return allreduce_ciphertext(ev, partial, group)
 
 
+def linear_transform_plain_sparse_sharded(ev: Evaluator, ct: Ciphertext, d: int, diagonals: dict,
+                                          gal_keys: KSwitchKeys, group=None) -> Ciphertext:
+    """alg.linear_transform_plain_sparse with the NON-ZERO diagonals split over the ranks (one all-reduce)."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    ct_new = alg._duplicate(ev, ct, d, gal_keys)                                   # replicated
+    items = sorted(diagonals.items())
+    mine = [items[i] for i in shard(len(items), rank, world)]
+    if mine:
+        partial = ev.add_many(alg._sparse_products(ev, ct_new, mine, gal_keys))
+    else:
+        z = ev.multiply_plain(ct_new, items[0][1])
+        partial = ev.sub(z, z)
+    return allreduce_ciphertext(ev, partial, group)
+
+
+def cc_matrix_multiplication_sparse_sharded(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int,
+                                            U_sigma: dict, U_tau: dict, V_diagonals: Sequence[dict],
+                                            W_diagonals: Sequence[dict], gal_keys: KSwitchKeys, group=None,
+                                            shard_step1: bool = False) -> Ciphertext:
+    """BASELINE config 5 (/root/reference/matrix_mult_benchmark.cpp:13-71 at n = 64, N = 32768) in the form that can
+    exist there: alg.cc_matrix_multiplication_sparse (non-zero diagonals only) with the 2(n-1) Step-2 transforms
+    phi^k / psi^k and the products A_k (.) B_k split by k over the ranks and ONE all-reduce of the size-3 partial sum.
+    sigma / tau (Step 1) run replicated (shard_step1=False: a single exchange per product) or split by diagonal with one
+    all-reduce each (shard_step1=True: 3 exchanges, ~2x less replicated work at n = 64).  Modular addition is
+    associative and commutative: bit-identical to the serial sparse product either way."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    d = dimension * dimension
+    if shard_step1:
+        ctA0 = linear_transform_plain_sparse_sharded(ev, ctA, d, U_sigma, gal_keys, group)   # :22
+        ctB0 = linear_transform_plain_sparse_sharded(ev, ctB, d, U_tau, gal_keys, group)     # :25
+    else:
+        ctA0 = alg.linear_transform_plain_sparse(ev, ctA, d, U_sigma, gal_keys)
+        ctB0 = alg.linear_transform_plain_sparse(ev, ctB, d, U_tau, gal_keys)
+    mine = list(shard(dimension - 1, rank, world))
+    ctAk = alg._sparse_transforms_of_one_input(ev, ctA0, d, [V_diagonals[k] for k in mine], gal_keys)   # :42
+    ctBk = alg._sparse_transforms_of_one_input(ev, ctB0, d, [W_diagonals[k] for k in mine], gal_keys)   # :43
+    ev.rescale_to_next_many_inplace(ctAk)                                          # :69-73
+    ev.rescale_to_next_many_inplace(ctBk)
+    ctAB = ev.multiply(ctA0, ctB0)                                                 # :104
+    ev.mod_switch_to_next_inplace(ctAB)                                            # :112
+    for c in ctAk + ctBk:
+        c.scale = 2.0 ** int(np.log2(c.scale))                                     # :117-121
+    terms = ([ctAB] if rank == 0 else []) + (ev.multiply_many(ctAk, ctBk) if ctAk else [])   # A_0 (.) B_0 counted once
+    partial = ev.add_many(terms) if terms else _zero_like(ev, ctAB)                # :123-129 (this rank's share)
+    out = allreduce_ciphertext(ev, partial, group)
+    out.scale = ctAB.scale  # the serial sum carries its first addend's scale (A_0 (.) B_0) on every rank
+    return out
+
+
 def predict_cipher_weights_sharded(ev: Evaluator, encoder, encryptor, features: Sequence[Ciphertext],
                                    weights: Ciphertext, num_weights: int, scale: float, gal_keys: KSwitchKeys,
                                    relin_keys: KSwitchKeys, degree: int = 3, group=None) -> Ciphertext:

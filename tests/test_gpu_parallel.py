@@ -69,6 +69,7 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+@pytest.mark.timeout(600)
 def test_sharded_composites_on_the_hip_engine_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
@@ -77,11 +78,86 @@ def test_sharded_composites_on_the_hip_engine_world2():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    out = [q.get(timeout=600) for _ in procs]
+    out = []
+    for _ in procs:
+        try:
+            out.append(q.get(timeout=420))
+        except Exception:
+            break
     for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+        p.join(timeout=20)
+        if p.is_alive():   # a rank that raised leaves its peer blocked in the collective: never wait for gloo's timeout
+            p.terminate()
+    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed or hung (see its traceback above)"
     for rank, lt_same, lt_val, lr_same, mm_ok in sorted(out):
         assert lt_same and lt_val, f"rank {rank}: sharded linear transform differs from the serial one"
         assert lr_same, f"rank {rank}: sharded LR prediction differs from the serial one"
         assert mm_ok, f"rank {rank}: sharded matrix product differs from the serial one"
+
+
+def _worker_config5(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seal_fyp_logistic_regression_amd import algorithms as alg
+        from seal_fyp_logistic_regression_amd import parallel as par
+        from seal_fyp_logistic_regression_amd import seal as S
+        rng = np.random.default_rng(4)
+        out = {}
+        for name, N, n in (("n4_c3", 16384, 4), ("n64_c5", 32768, 64)):
+            parms = S.EncryptionParameters("ckks")
+            parms.set_poly_modulus_degree(N)
+            parms.set_coeff_modulus(S.CoeffModulus.Create(N, [60, 40, 40, 40, 40, 60]))
+            ctx = S.SEALContext.Create(parms)
+            kg = S.KeyGenerator(ctx, 31)
+            enc_, dec_ = S.Encryptor(ctx, kg.public_key(), 32), S.Decryptor(ctx, kg.secret_key())
+            encoder, ev, gk = S.CKKSEncoder(ctx), S.Evaluator(ctx), kg.galois_keys()
+            A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+            scale = 2.0 ** 40
+            sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+            enc = lambda dd: dict(zip(dd, encoder.encode_many(list(dd.values()), scale)))
+            ctA, ctB = enc_.encrypt(encoder.encode(A.reshape(-1), scale)), enc_.encrypt(encoder.encode(B.reshape(-1), scale))
+            args = (ctA, ctB, n, enc(sig), enc(tau), [enc(x) for x in phi], [enc(x) for x in psi], gk)
+            serial = alg.cc_matrix_multiplication_sparse(ev, *args)
+            bits = lambda c: ctx.backend.to_host(c.data)
+            ok = True
+            for step1 in (False, True):
+                sh = par.cc_matrix_multiplication_sparse_sharded(ev, *args, shard_step1=step1)
+                ok = ok and bool((bits(sh) == bits(serial)).all()) and sh.size() == 3
+            got = encoder.decode(dec_.decrypt(sh))[:n * n].real.reshape(n, n)
+            out[name] = (ok, float(np.abs(got - A @ B).max()))
+            del ctx, kg, gk, args, serial, sh
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_config5_sparse_matrix_product_sharded_world2():
+    """BASELINE config 5 (matrix_mult_benchmark.cpp:13-71; 64 x 64 at N = 32768) in its sharded form on the HIP engine:
+    Step 2 split by k over two ranks (sharing the box's GPU, rendezvous over gloo), one all-reduce of the size-3 sum;
+    bits equal the serial sparse product at n = 4 (C3) and n = 64 (C5), and the n = 64 result decrypts to A.B."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config5, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = []
+    for _ in procs:
+        try:
+            out.append(q.get(timeout=420))
+        except Exception:
+            break
+    for p in procs:
+        p.join(timeout=20)
+        if p.is_alive():   # a rank that raised leaves its peer blocked in the collective: never wait for gloo's timeout
+            p.terminate()
+    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed or hung (see its traceback above)"
+    for rank, res in sorted(out):
+        for name, (same, err) in res.items():
+            assert same, f"rank {rank} {name}: sharded sparse product differs from the serial one"
+            assert err < 1e-3, (name, err)

@@ -145,3 +145,60 @@ def test_sharded_matrix_product_and_lr_predict_world2():
         assert mm_same, f"rank {rank}: sharded matrix product differs from the serial one"
         assert mm_val
         assert lr_same, f"rank {rank}: row-sharded LR predict differs from the serial one"
+
+
+def _worker_sparse_matmul(rank, world, port, n, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import seal_fyp_logistic_regression_amd.seal as S
+        from seal_fyp_logistic_regression_amd import algorithms as alg
+        from seal_fyp_logistic_regression_amd import parallel as par
+        from tests.test_host_api_cpu import make
+        e = make(2048, [60, 40, 40, 40, 40, 60], seed=8)
+        rng = np.random.default_rng(3)
+        A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+        scale = 2.0 ** 40
+        sig, tau, phi, psi = alg.matmul_permutation_diagonals(n)
+        enc = lambda dd: {l: e["encoder"].encode(v, scale) for l, v in dd.items()}
+        mk = lambda seed, M: S.Encryptor(e["ctx"], e["kg"].public_key(), seed=seed).encrypt(e["encoder"].encode(M.reshape(-1), scale))
+        args = (mk(7, A), mk(8, B), n, enc(sig), enc(tau), [enc(x) for x in phi], [enc(x) for x in psi], e["gk"])
+        serial = alg.cc_matrix_multiplication_sparse(e["ev"], *args)
+        res = []
+        for step1 in (False, True):
+            sh = par.cc_matrix_multiplication_sparse_sharded(e["ev"], *args, shard_step1=step1)
+            same = bool((np.asarray(serial.data) == np.asarray(sh.data)).all()) and sh.size() == 3 and \
+                sh.parms_id() == serial.parms_id() and sh.scale == serial.scale
+            got = e["encoder"].decode(e["dec"].decrypt(sh))[:n * n].real.reshape(n, n)
+            res.append((same, bool(np.allclose(got, A @ B, atol=1e-3))))
+        q.put((rank, res))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [3, 2])
+def test_sharded_sparse_matrix_product_world2(n):
+    """config 5's form of the matrix product (non-zero diagonals only) with Step 2 split by k over two ranks -- n = 2
+    leaves rank 1 without a unit -- with sigma / tau replicated and diagonal-sharded: bits of the serial sparse product."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_sparse_matmul, args=(r, 2, port, n, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = []
+    for _ in procs:
+        try:
+            out.append(q.get(timeout=240))
+        except Exception:
+            break
+    for p in procs:
+        p.join(timeout=30)
+        if p.is_alive():
+            p.terminate()
+    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
+    for rank, res in sorted(out):
+        for step1, (same, val) in zip((False, True), res):
+            assert same, f"rank {rank}, shard_step1={step1}: sharded sparse product differs from the serial one"
+            assert val
