@@ -318,6 +318,71 @@ int main()
           }, "scale out of bounds"),
           "scale out of bounds throws");
 
+    // BFV: what vector_ops.cpp:101-195 and 5_rotation.cpp:88-165 do before their CKKS halves
+    {
+        EncryptionParameters bp(scheme_type::BFV);
+        bp.set_poly_modulus_degree(8192);
+        bp.set_coeff_modulus(CoeffModulus::BFVDefault(8192));
+        bp.set_plain_modulus(786433);
+        auto bctx = SEALContext::Create(bp);
+        KeyGenerator bkg(bctx);
+        PublicKey bpk = bkg.public_key();
+        SecretKey bsk = bkg.secret_key();
+        RelinKeys brk = bkg.relin_keys();
+        GaloisKeys bgk = bkg.galois_keys();
+        Encryptor benc(bctx, bpk);
+        Evaluator bev(bctx);
+        Decryptor bdec(bctx, bsk);
+        BatchEncoder be(bctx);
+        const size_t slots = be.slot_count(), row = slots / 2;
+        const uint64_t t = 786433;
+        CHECK(slots == 8192, "BatchEncoder slot_count");
+        vector<uint64_t> m1(slots), m2(slots), back;
+        for (size_t i = 0; i < slots; i++) m1[i] = i, m2[i] = (i % 2) + 1;
+        Plaintext p1, p2, pr;
+        be.encode(m1, p1);
+        be.encode(m2, p2);
+        be.decode(p1, back);
+        CHECK(back == m1, "BatchEncoder decode(encode(x)) == x");
+        Ciphertext c;
+        benc.encrypt(p1, c);
+        const int fresh = bdec.invariant_noise_budget(c);
+        CHECK(!c.is_ntt_form() && fresh > 100 && fresh < 174, "BFV encrypt: coefficient form, fresh noise budget in range");
+        bdec.decrypt(c, pr);
+        be.decode(pr, back);
+        CHECK(back == m1, "BFV decrypt(encrypt(x)) == x");
+        bev.add_plain_inplace(c, p2);
+        bev.square_inplace(c);
+        CHECK(c.size() == 3, "BFV square gives size 3");
+        bev.relinearize_inplace(c, brk);
+        const int after = bdec.invariant_noise_budget(c);
+        bdec.decrypt(c, pr);
+        be.decode(pr, back);
+        bool ok = c.size() == 2;
+        for (size_t i = 0; i < slots; i++) ok = ok && back[i] == ((m1[i] + m2[i]) % t) * ((m1[i] + m2[i]) % t) % t;
+        CHECK(ok && after > 0 && after < fresh, "BFV (x + y)^2 with add_plain, square, relinearize (vector_ops.cpp:178-180)");
+        vector<uint64_t> pm(slots, 0);
+        for (int i = 0; i < 4; i++) pm[i] = i, pm[row + i] = 4 + i;
+        Plaintext pp;
+        be.encode(pm, pp);
+        benc.encrypt(pp, c);
+        bev.rotate_rows_inplace(c, 3, bgk);       // NAF(3) = [-1, 4] with the default power-of-two keys
+        bdec.decrypt(c, pr);
+        be.decode(pr, back);
+        CHECK(back[0] == 3 && back[row - 3] == 0 && back[row - 1] == 2 && back[row] == 7 && back[2 * row - 1] == 6,
+              "BFV rotate_rows by 3 (5_rotation.cpp:132)");
+        bev.rotate_columns_inplace(c, bgk);
+        bdec.decrypt(c, pr);
+        be.decode(pr, back);
+        CHECK(back[0] == 7 && back[row] == 3, "BFV rotate_columns swaps the rows (5_rotation.cpp:143)");
+        bev.rotate_rows_inplace(c, -4, bgk);
+        bdec.decrypt(c, pr);
+        be.decode(pr, back);
+        CHECK(back[0] == 0 && back[1] == 4 && back[4] == 7 && back[row + 2] == 1 && back[row + 4] == 3 &&
+                  bdec.invariant_noise_budget(c) > 0,
+              "BFV rotate_rows by -4 (5_rotation.cpp:152)");
+    }
+
     cout << (failures ? "SELFTEST FAILED" : "SELFTEST PASSED") << " (" << failures << " failures)" << endl;
     return failures ? 1 : 0;
 }

@@ -34,6 +34,7 @@
 #include <vector>
 
 #include "../hefx.h"
+#include "shim_bfv.h"
 
 namespace seal {
 
@@ -290,6 +291,12 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     pend_bytes += out_words * 8;
     BufPtr out = nd.dst;
     if (pend_bytes > pend_budget || pend.size() > 400000) flush();  // bounded memory: run what is recorded
+    // SEAL_SHIM_SYNC=1 promises a caller's chrono timers completed work: only the rotate_vector / multiply_plain pairs of
+    // the linear-transform loops stay recorded there (their add_many observes them inside the timed region)
+    if (sync_mode() && kind != Node::ROT && kind != Node::MULPT && !pend.empty()) {
+        flush();
+        (void)hefx_stream_sync(ctx_raw, nullptr);
+    }
     return out;
 }
 
@@ -622,6 +629,45 @@ public:
     int k() const { return k_; }
     const std::vector<std::uint64_t> &primes() const { return primes_; }
     bool is_ckks() const { return scheme_ == scheme_type::ckks; }
+    std::uint64_t plain_modulus_value() const { return t_; }
+    // ---- BFV (shim_bfv.h): everything derived from (Q = q_0..q_(L-1), t), built on first use.  BFV ciphertexts live at
+    // the first data level only (the demos never mod-switch them).
+    struct BfvTools {
+        int L = 0;                                  // data primes
+        std::uint64_t t = 0;
+        shim::bfv::Basis data, aux;                 // Q-basis and the auxiliary basis of the tensor product
+        shim::bfv::Big delta;                       // floor(Q / t)
+        std::vector<std::uint64_t> delta_mod;       // delta mod q_j
+        std::shared_ptr<shim::Engine> aux_engine;   // hefx context over the auxiliary primes (NTT + dyadic products)
+        shim::bfv::PlainNtt pntt;
+        bool batching = false;
+    };
+    const BfvTools &bfv() const
+    {
+        if (bfv_) return *bfv_;
+        if (is_ckks()) throw std::logic_error("not a BFV context");
+        if (t_ < 2) throw std::invalid_argument("plain_modulus is not set");
+        auto b = std::make_shared<BfvTools>();
+        b->L = k_ > 1 ? k_ - 1 : 1;
+        b->t = t_;
+        b->data.init(std::vector<std::uint64_t>(primes_.begin(), primes_.begin() + b->L));
+        shim::bfv::Big rem;
+        shim::bfv::divrem(b->data.M, shim::bfv::Big(t_), b->delta, rem);
+        for (int j = 0; j < b->L; ++j) b->delta_mod.push_back(shim::bfv::mod_small(b->delta, primes_[j]));
+        // tensor-product coefficients are sums of N products of centred residues: |x| < N (Q/2)^2 * 2
+        int logn = 0;
+        while (((std::size_t)1 << logn) < n_) ++logn;
+        const int need = 2 * b->data.M.bits() + logn + 3;
+        std::vector<std::uint64_t> aux;
+        for (std::uint64_t v = ((std::uint64_t)1 << 60) - 2 * n_ + 1; (int)aux.size() * 59 < need; v -= 2 * n_)
+            if (shim::is_prime(v) && std::find(primes_.begin(), primes_.end(), v) == primes_.end()) aux.push_back(v);
+        if (aux.size() > 7) throw std::invalid_argument("coeff_modulus too large for the BFV demo path of this shim");
+        b->aux.init(aux);
+        b->aux_engine = shim::get_engine((std::uint32_t)n_, aux);
+        b->batching = b->pntt.init(t_, n_);
+        bfv_ = b;
+        return *bfv_;
+    }
     // number of RNS rows of a level, from its parms_id (0 if unknown)
     int rows_of(const parms_id_type &id) const
     {
@@ -638,6 +684,7 @@ private:
         n_ = parms.poly_modulus_degree();
         scheme_ = parms.scheme();
         k_ = (int)parms.coeff_modulus().size();
+        t_ = parms.plain_modulus().value();
         if (k_ < 1) throw std::invalid_argument("coeff_modulus is not set");
         if (n_ < 1024 || (n_ & (n_ - 1))) throw std::invalid_argument("poly_modulus_degree is not valid");
         for (auto &q : parms.coeff_modulus()) primes_.push_back(q.value());
@@ -679,6 +726,8 @@ private:
     std::vector<std::uint64_t> primes_;
     std::vector<std::shared_ptr<ContextData>> levels_;  // index = rows-1
     mutable std::shared_ptr<shim::Engine> eng_;
+    std::uint64_t t_ = 0;
+    mutable std::shared_ptr<BfvTools> bfv_;
 };
 
 namespace shim {
@@ -689,6 +738,19 @@ inline std::shared_ptr<SEALContext> as_ptr(const std::shared_ptr<SEALContext> &c
     return c;
 }
 inline std::shared_ptr<SEALContext> as_ptr(const SEALContext &c) { return std::make_shared<SEALContext>(c); }
+
+// Delta * m modulo every data prime, [L][N] (coefficient form): what BFV encryption and add_plain add to c0
+inline std::vector<std::uint64_t> bfv_scaled_plain(const SEALContext &ctx, const std::vector<std::uint64_t> &coeffs)
+{
+    const auto &B = ctx.bfv();
+    const std::size_t n = ctx.n();
+    std::vector<std::uint64_t> out((std::size_t)B.L * n, 0);
+    for (int j = 0; j < B.L; ++j) {
+        const std::uint64_t q = ctx.primes()[j], d = B.delta_mod[j];
+        for (std::size_t i = 0; i < coeffs.size() && i < n; ++i) out[(std::size_t)j * n + i] = bfv::mulmod64(d, coeffs[i] % q, q);
+    }
+    return out;
+}
 }  // namespace shim
 
 // ------------------------------------------------------------------------------------------------
@@ -697,18 +759,34 @@ inline std::shared_ptr<SEALContext> as_ptr(const SEALContext &c) { return std::m
 class Plaintext {
 public:
     Plaintext() = default;
-    explicit Plaintext(const std::string &) { throw std::logic_error("BFV plaintext polynomials are not built in this shim"); }
+    explicit Plaintext(const std::string &) { throw std::logic_error("BFV plaintext polynomials from hex strings are not built in this shim"); }
     double &scale() { return scale_; }
     const double &scale() const { return scale_; }
     parms_id_type &parms_id() { return id_; }
     const parms_id_type &parms_id() const { return id_; }
-    bool is_ntt_form() const { return true; }
+    bool is_ntt_form() const { return bfv.empty(); }
     bool is_zero() const { return zero_; }
-    std::string to_string() const { throw std::logic_error("BFV plaintext polynomials are not built in this shim"); }
+    // SEAL: number of uint64 words of the plaintext (CKKS: rows * N in NTT form; BFV: coefficients modulo t)
+    std::size_t coeff_count() const { return bfv.empty() && buf ? buf->words : bfv.size(); }
+    // read access to the words (SEAL's Plaintext::data()); CKKS payloads live on the device: a host mirror is fetched
+    const std::uint64_t *data() const
+    {
+        if (!bfv.empty()) return bfv.data();
+        if (!buf) return nullptr;
+        if (!mirror_ || mirror_of_ != buf->p) {
+            mirror_ = std::make_shared<std::vector<std::uint64_t>>(shim::download(buf));
+            mirror_of_ = buf->p;
+        }
+        return mirror_->data();
+    }
+    std::string to_string() const { throw std::logic_error("BFV plaintext polynomials as hex strings are not built in this shim"); }
     // shim internals
-    shim::BufPtr buf;
+    shim::BufPtr buf;                 // CKKS: [rows][N] NTT form on the device
+    std::vector<std::uint64_t> bfv;   // BFV: N coefficients modulo the plain modulus, on the host
     int rows = 0;
     bool zero_ = false;
+    mutable std::shared_ptr<std::vector<std::uint64_t>> mirror_;
+    mutable const std::uint64_t *mirror_of_ = nullptr;
 
 private:
     double scale_ = 1.0;
@@ -724,11 +802,27 @@ public:
     const parms_id_type &parms_id() const { return id_; }
     std::size_t size() const { return size_; }
     std::size_t coeff_mod_count() const { return (std::size_t)rows; }
-    bool is_ntt_form() const { return true; }
+    bool is_ntt_form() const { return ntt_form_; }
+    std::size_t poly_modulus_degree() const { return buf && size_ && rows ? buf->words / (size_ * (std::size_t)rows) : 0; }
+    // read access to the words in SEAL's layout (SEAL's Ciphertext::data()): a host mirror of the device payload,
+    // fetched on first use (this is how tools/gen_seal_vectors.cpp reads results; the evaluator never needs it)
+    const std::uint64_t *data() const
+    {
+        if (!buf) return nullptr;
+        if (!mirror_ || mirror_of_ != buf->p) {
+            mirror_ = std::make_shared<std::vector<std::uint64_t>>(shim::download(buf));
+            mirror_of_ = buf->p;
+        }
+        return mirror_->data();
+    }
+    const std::uint64_t *data(std::size_t poly) const { return data() + poly * (std::size_t)rows * poly_modulus_degree(); }
     // shim internals
     shim::BufPtr buf;
     int rows = 0;
     std::size_t size_ = 0;
+    mutable std::shared_ptr<std::vector<std::uint64_t>> mirror_;
+    mutable const std::uint64_t *mirror_of_ = nullptr;
+    bool ntt_form_ = true;  // CKKS ciphertexts are always NTT form, BFV ones coefficient form (as in SEAL)
     void set(shim::BufPtr b, std::size_t size, int r, const parms_id_type &id, double scale)
     {
         buf = std::move(b);
@@ -751,15 +845,62 @@ public:
 class PublicKey {
 public:
     shim::BufPtr buf;  // [2][k][N]
+    // SEAL: a public key (and every component of a key-switching key) is a size-2 key-level ciphertext
+    const Ciphertext &data() const
+    {
+        if (!view_.buf || view_.buf != buf) view_.set(buf, 2, rows_, parms_id_zero, 1.0);
+        return view_;
+    }
+    int rows_ = 0;
+
+private:
+    mutable Ciphertext view_;
 };
 class KSwitchKeys {
 public:
     bool has_key(std::uint32_t elt) const { return keys.count(elt) != 0; }
     std::map<std::uint32_t, shim::BufPtr> keys;  // Galois element -> [k-1][2][k][N]; relin key under element 0
     std::size_t size() const { return keys.size(); }
+
+protected:
+    // SEAL's view of one key: vector<PublicKey>, component i = digit i = [2][k][N] (a copy of that slice)
+    const std::vector<PublicKey> &components(std::uint32_t elt) const
+    {
+        auto hit = views_.find(elt);
+        if (hit != views_.end()) return hit->second;
+        const shim::BufPtr &key = keys.at(elt);
+        // [k-1][2][k][N] words: solve words = (k-1) * 2 * k * N for k with N from the engine
+        const std::size_t n = key->eng->n;
+        std::size_t k = 2;
+        while ((k - 1) * 2 * k * n < key->words) ++k;
+        std::vector<PublicKey> comps(k - 1);
+        const std::size_t slice = 2 * k * n;
+        for (std::size_t i = 0; i + 1 < k; ++i) {
+            comps[i].buf = shim::new_buf(key->eng, slice);
+            shim::check(hefx_copy(key->eng->ready({}), comps[i].buf->p, key->p + i * slice, slice * 8, nullptr));
+            comps[i].rows_ = (int)k;
+        }
+        return views_[elt] = std::move(comps);
+    }
+    mutable std::map<std::uint32_t, std::vector<PublicKey>> views_;
 };
-class RelinKeys : public KSwitchKeys {};
-class GaloisKeys : public KSwitchKeys {};
+class RelinKeys : public KSwitchKeys {
+public:
+    static std::size_t get_index(std::size_t key_power) { return key_power - 2; }
+    // shim-internal lookups use has_key(0u) (the relinearisation key is stored under element 0); SEAL's has_key(key_power)
+    // is has_power
+    bool has_power(std::size_t key_power) const { return key_power == 2 && keys.count(0) != 0; }
+    const std::vector<PublicKey> &key(std::size_t key_power) const
+    {
+        if (key_power != 2) throw std::invalid_argument("key_power is not valid");
+        return components(0);
+    }
+};
+class GaloisKeys : public KSwitchKeys {
+public:
+    static std::size_t get_index(std::uint64_t galois_elt) { return (std::size_t)((galois_elt - 1) >> 1); }
+    const std::vector<PublicKey> &key(std::uint64_t galois_elt) const { return components((std::uint32_t)galois_elt); }
+};
 
 // ------------------------------------------------------------------------------------------------
 // KeyGenerator (App. A.11): sampling (hefx_sample_*) and arithmetic on the GPU, key assembly on the host
@@ -769,8 +910,7 @@ public:
     template <class Ctx>
     explicit KeyGenerator(const Ctx &context) : ctx_(shim::as_ptr(context))
     {
-        // BFV drivers compile against the shim but stop here, with a message instead of a null payload later
-        if (!ctx_->is_ckks()) throw std::logic_error("BFV is not built in this shim (CKKS hot path only)");
+        // the keys of BFV and CKKS are the same objects (App. A.11): one code path
         const int k = ctx_->k();
         auto &e = ctx_->engine();
         sk_.buf = shim::new_buf(e, (std::size_t)k * ctx_->n());
@@ -891,7 +1031,7 @@ public:
     // (pk0*u + e0 + m, pk1*u + e1) over the plaintext's level
     void encrypt(const Plaintext &plain, Ciphertext &dest) const
     {
-        if (!ctx_->is_ckks()) throw std::logic_error("BFV is not built in this shim");
+        if (!ctx_->is_ckks()) return encrypt_bfv(plain, dest);
         if (!plain.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
         auto &e = ctx_->engine();
         const int L = plain.rows;
@@ -902,6 +1042,23 @@ public:
     }
 
 private:
+    // BFV: (pk0*u + e0 + Delta*m, pk1*u + e1) at the first data level, coefficient form (vector_ops.cpp:155)
+    void encrypt_bfv(const Plaintext &plain, Ciphertext &dest) const
+    {
+        const auto &B = ctx_->bfv();
+        if (plain.bfv.empty() || plain.bfv.size() > ctx_->n()) throw std::invalid_argument("plain is not valid for encryption parameters");
+        auto &e = ctx_->engine();
+        const int L = B.L;
+        const std::size_t n = ctx_->n();
+        auto c = shim::new_buf(e, (std::size_t)2 * L * n);
+        shim::check(hefx_encrypt(e->ready({}), L, pk_.buf->p, nullptr, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
+        shim::check(hefx_ntt_inverse(e->ready({}), c->p, 2, L, 0, nullptr));
+        auto dm = shim::upload(e, shim::bfv_scaled_plain(*ctx_, plain.bfv));
+        shim::check(hefx_add_plain(e->ready({}), L, 2, c->p, dm->p, c->p, nullptr));
+        dest.set(c, 2, L, ctx_->id_of_rows(L), 1.0);
+        dest.ntt_form_ = false;
+    }
+
     std::shared_ptr<SEALContext> ctx_;
     PublicKey pk_;
     shim::SamplerState rnd_;
@@ -916,6 +1073,11 @@ public:
     void decrypt(const Ciphertext &ct, Plaintext &dest) const
     {
         if (!ct.buf) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        if (!ctx_->is_ckks()) {
+            int budget = 0;
+            decrypt_bfv(ct, dest, budget);
+            return;
+        }
         auto &e = ctx_->engine();
         const int L = ct.rows;
         auto acc = shim::new_buf(e, (std::size_t)L * ctx_->n());
@@ -926,9 +1088,53 @@ public:
         dest.scale() = ct.scale();
         dest.zero_ = false;
     }
-    int invariant_noise_budget(const Ciphertext &) const { throw std::logic_error("BFV is not built in this shim"); }
+    // bits left before decryption fails: log2(Q) - log2(|| t * [ct(s)]_Q centred mod Q ||_inf) - 1 (vector_ops.cpp:157)
+    int invariant_noise_budget(const Ciphertext &ct) const
+    {
+        if (ctx_->is_ckks()) throw std::invalid_argument("unsupported scheme");
+        if (!ct.buf) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        Plaintext tmp;
+        int budget = 0;
+        decrypt_bfv(ct, tmp, budget);
+        return budget;
+    }
 
 private:
+    // BFV: x = [c0 + c1 s (+ c2 s^2)]_Q on the GPU (NTT domain), then per coefficient t*x = quo*Q + rem on the host:
+    // m = round(t*x/Q) mod t, and |rem centred| is the invariant noise
+    void decrypt_bfv(const Ciphertext &ct, Plaintext &dest, int &budget) const
+    {
+        namespace bf = shim::bfv;
+        const auto &B = ctx_->bfv();
+        if (ct.rows != B.L) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        auto &e = ctx_->engine();
+        const int L = B.L;
+        const std::size_t n = ctx_->n();
+        auto tmp = shim::new_buf(e, ct.buf->words), acc = shim::new_buf(e, (std::size_t)L * n);
+        shim::check(hefx_copy(e->ready({ct.buf.get()}), tmp->p, ct.buf->p, ct.buf->words * 8, nullptr));
+        shim::check(hefx_ntt_forward(e->ready({}), tmp->p, (int)ct.size(), L, 0, nullptr));
+        shim::check(hefx_decrypt(e->ready({}), L, (int)ct.size(), tmp->p, sk_.buf->p, acc->p, nullptr));
+        shim::check(hefx_ntt_inverse(e->ready({}), acc->p, 1, L, 0, nullptr));
+        const std::vector<std::uint64_t> x = shim::download(acc);
+        dest = Plaintext();
+        dest.bfv.assign(n, 0);
+        dest.parms_id() = parms_id_zero;
+        bf::Big worst;
+        for (std::size_t i = 0; i < n; ++i) {
+            const bf::Big xi = B.data.compose(x.data(), n, i);
+            bf::Big quo, rem;
+            bf::divrem(bf::mul_small(xi, B.t), B.data.M, quo, rem);
+            std::uint64_t m = bf::mod_small(quo, B.t);
+            if (bf::cmp(rem, B.data.half) > 0) {  // round up; the noise is the distance to the next multiple of Q
+                m = (m + 1) % B.t;
+                rem = bf::sub(B.data.M, rem);
+            }
+            dest.bfv[i] = m;
+            if (bf::cmp(rem, worst) > 0) worst = rem;
+        }
+        budget = std::max(0, B.data.M.bits() - worst.bits() - 1);
+    }
+
     std::shared_ptr<SEALContext> ctx_;
     SecretKey sk_;
 };
@@ -1170,19 +1376,73 @@ private:
     std::vector<std::complex<double>> zeta_, tw_;
 };
 
-// BFV-only encoders: declared so that the drivers compile (vector_ops.cpp:101-195, 2_encoders.cpp); not built.
+// BatchEncoder (BFV; vector_ops.cpp:127-193, 5_rotation.cpp:108-164): N slots as a 2 x N/2 matrix, slot i <-> the
+// evaluation point psi^(3^i) (row 0) / psi^(-3^i) (row 1), so that X -> X^(3^k) rotates the rows by k and X -> X^(2N-1)
+// swaps them.  Host arithmetic modulo the plain modulus (shim_bfv.h PlainNtt).
 class BatchEncoder {
 public:
     template <class Ctx>
-    explicit BatchEncoder(const Ctx &)
+    explicit BatchEncoder(const Ctx &context) : ctx_(shim::as_ptr(context))
     {
-        throw std::logic_error("BFV (BatchEncoder) is not built in this shim");
+        if (ctx_->is_ckks()) throw std::invalid_argument("unsupported scheme");
+        if (!ctx_->bfv().batching) throw std::invalid_argument("encryption parameters are not valid for batching");
+        const std::size_t n = ctx_->n();
+        int logn = 0;
+        while (((std::size_t)1 << logn) < n) ++logn;
+        index_.resize(n);
+        std::uint64_t pos = 1;
+        for (std::size_t i = 0; i < n / 2; ++i) {
+            index_[i] = shim::bfv::PlainNtt::bitrev((std::uint32_t)((pos - 1) >> 1), logn);
+            index_[n / 2 + i] = shim::bfv::PlainNtt::bitrev((std::uint32_t)((2 * n - pos - 1) >> 1), logn);
+            pos = (pos * 3) & (2 * n - 1);
+        }
     }
-    std::size_t slot_count() const { return 0; }
-    template <class V>
-    void encode(const V &, Plaintext &) const {}
-    template <class V>
-    void decode(const Plaintext &, V &) const {}
+    std::size_t slot_count() const { return ctx_->n(); }
+    void encode(const std::vector<std::uint64_t> &values, Plaintext &dest) const
+    {
+        const std::size_t n = ctx_->n();
+        const std::uint64_t t = ctx_->plain_modulus_value();
+        if (values.size() > n) throw std::invalid_argument("values has invalid size");
+        dest = Plaintext();
+        dest.bfv.assign(n, 0);
+        for (std::size_t i = 0; i < values.size(); ++i) {
+            if (values[i] >= t) throw std::invalid_argument("input value is larger than plain_modulus");
+            dest.bfv[index_[i]] = values[i];
+        }
+        ctx_->bfv().pntt.inverse(dest.bfv);
+    }
+    void encode(const std::vector<std::int64_t> &values, Plaintext &dest) const
+    {
+        const std::int64_t t = (std::int64_t)ctx_->plain_modulus_value();
+        std::vector<std::uint64_t> u(values.size());
+        for (std::size_t i = 0; i < values.size(); ++i) {
+            if (values[i] > t / 2 || values[i] < -(t / 2)) throw std::invalid_argument("input value is larger than plain_modulus");
+            u[i] = (std::uint64_t)(values[i] < 0 ? values[i] + t : values[i]);
+        }
+        encode(u, dest);
+    }
+    void decode(const Plaintext &plain, std::vector<std::uint64_t> &dest) const
+    {
+        const std::size_t n = ctx_->n();
+        if (plain.bfv.empty() || plain.bfv.size() > n) throw std::invalid_argument("plain is not valid for encryption parameters");
+        std::vector<std::uint64_t> tmp(plain.bfv);
+        tmp.resize(n, 0);
+        ctx_->bfv().pntt.forward(tmp);
+        dest.resize(n);
+        for (std::size_t i = 0; i < n; ++i) dest[i] = tmp[index_[i]];
+    }
+    void decode(const Plaintext &plain, std::vector<std::int64_t> &dest) const
+    {
+        std::vector<std::uint64_t> u;
+        decode(plain, u);
+        const std::uint64_t t = ctx_->plain_modulus_value();
+        dest.resize(u.size());
+        for (std::size_t i = 0; i < u.size(); ++i) dest[i] = u[i] > t / 2 ? (std::int64_t)u[i] - (std::int64_t)t : (std::int64_t)u[i];
+    }
+
+private:
+    std::shared_ptr<SEALContext> ctx_;
+    std::vector<std::size_t> index_;
 };
 class IntegerEncoder {
 public:
@@ -1246,6 +1506,15 @@ public:
     void add_plain(const Ciphertext &a, const Plaintext &p, Ciphertext &dest) const
     {
         check_ct(a);
+        if (!ctx_->is_ckks()) {  // BFV: c0 += Delta * m (vector_ops.cpp:178)
+            if (p.bfv.empty()) throw std::invalid_argument("plain is not valid for encryption parameters");
+            auto dm = shim::upload(eng(), shim::bfv_scaled_plain(*ctx_, p.bfv));
+            auto out = shim::new_buf(eng(), a.buf->words);
+            shim::check(hefx_add_plain(eng()->ready({a.buf.get()}), a.rows, (int)a.size(), a.buf->p, dm->p, out->p, nullptr));
+            dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
+            dest.ntt_form_ = false;
+            return;
+        }
         check_pt(a, p);
         if (!close(a.scale(), p.scale())) throw std::invalid_argument("scale mismatch");
         auto out = shim::new_buf(eng(), a.buf->words);
@@ -1284,6 +1553,7 @@ public:
         if (a.parms_id() != b.parms_id()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
         if (a.size() != 2 || b.size() != 2)
             throw std::invalid_argument("multiply: only size-2 operands are built (every reference call site)");
+        if (!ctx_->is_ckks()) return multiply_bfv(a, b, dest);
         const double ns = a.scale() * b.scale();
         check_scale(ns, a.parms_id());
         if (eng()->lazy) {  // recorded (helper.h:227-228, 432): the products of all rows / diagonals go out as one batch
@@ -1311,6 +1581,17 @@ public:
         if (a.size() == 2) return;  // SEAL: nothing to do
         if (a.size() != 3) throw std::invalid_argument("encrypted size must be 2 or 3");
         if (!rk.has_key(0)) throw std::invalid_argument("not enough relinearization keys");
+        if (!ctx_->is_ckks()) {  // BFV: the same key switch, bracketed by NTTs (the ciphertext is in coefficient form)
+            auto &e = eng();
+            auto tmp = shim::new_buf(e, a.buf->words), out = shim::new_buf(e, words(2, a.rows));
+            shim::check(hefx_copy(e->ready({a.buf.get()}), tmp->p, a.buf->p, a.buf->words * 8, nullptr));
+            shim::check(hefx_ntt_forward(e->ready({}), tmp->p, 3, a.rows, 0, nullptr));
+            shim::check(hefx_relinearize(e->ready({}), a.rows, tmp->p, rk.keys.at(0)->p, out->p, nullptr));
+            shim::check(hefx_ntt_inverse(e->ready({}), out->p, 2, a.rows, 0, nullptr));
+            a.set(out, 2, a.rows, a.parms_id(), a.scale());
+            a.ntt_form_ = false;
+            return;
+        }
         if (eng()->lazy) {
             a.set(eng()->record(shim::Engine::Node::RELIN, a.buf, rk.keys.at(0), 0, a.rows, 3, words(2, a.rows), eng()), 2,
                   a.rows, a.parms_id(), a.scale());
@@ -1388,6 +1669,7 @@ public:
     void rotate_vector(const Ciphertext &a, int steps, const GaloisKeys &gk, Ciphertext &dest) const
     {
         check_ct(a);
+        if (!ctx_->is_ckks()) throw std::logic_error("unsupported scheme");
         if (a.size() != 2) throw std::invalid_argument("encrypted size must be 2");
         std::vector<std::uint32_t> plan;
         rotation_plan(steps, gk, plan);
@@ -1419,9 +1701,38 @@ public:
         dest.set(out, 2, a.rows, a.parms_id(), a.scale());
     }
     void complex_conjugate_inplace(Ciphertext &a, const GaloisKeys &gk) const { complex_conjugate(a, gk, a); }
-    // BFV only
-    void rotate_rows_inplace(Ciphertext &, int, const GaloisKeys &) const { throw std::logic_error("BFV is not built in this shim"); }
-    void rotate_columns_inplace(Ciphertext &, const GaloisKeys &) const { throw std::logic_error("BFV is not built in this shim"); }
+    // SEAL 3.4's public apply_galois: one automorphism + key switch with a directly keyed element
+    void apply_galois(const Ciphertext &a, std::uint64_t galois_elt, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        check_ct(a);
+        if (a.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+        const std::uint32_t elt = (std::uint32_t)galois_elt;
+        if (!(elt & 1) || elt >= 2 * ctx_->n()) throw std::invalid_argument("Galois element is not valid");
+        if (!gk.has_key(elt)) throw std::invalid_argument("Galois key not present");
+        if (!ctx_->is_ckks()) return apply_galois_bfv(a, {elt}, gk, dest);
+        auto out = shim::new_buf(eng(), words(2, a.rows));
+        shim::check(hefx_apply_galois(eng()->ready({a.buf.get()}), a.rows, a.buf->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+        dest.set(out, 2, a.rows, a.parms_id(), a.scale());
+    }
+    void apply_galois_inplace(Ciphertext &a, std::uint64_t galois_elt, const GaloisKeys &gk) const { apply_galois(a, galois_elt, gk, a); }
+    // BFV only (5_rotation.cpp:130-160): the same Galois key switches as rotate_vector / complex_conjugate, bracketed
+    // by NTTs because BFV ciphertexts are kept in coefficient form
+    void rotate_rows(const Ciphertext &a, int steps, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        if (ctx_->is_ckks()) throw std::logic_error("unsupported scheme");
+        std::vector<std::uint32_t> plan;
+        rotation_plan(steps, gk, plan);
+        apply_galois_bfv(a, plan, gk, dest);
+    }
+    void rotate_rows_inplace(Ciphertext &a, int steps, const GaloisKeys &gk) const { rotate_rows(a, steps, gk, a); }
+    void rotate_columns(const Ciphertext &a, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        if (ctx_->is_ckks()) throw std::logic_error("unsupported scheme");
+        const std::uint32_t elt = (std::uint32_t)(2 * ctx_->n() - 1);
+        if (!gk.has_key(elt)) throw std::invalid_argument("Galois key not present");
+        apply_galois_bfv(a, {elt}, gk, dest);
+    }
+    void rotate_columns_inplace(Ciphertext &a, const GaloisKeys &gk) const { rotate_columns(a, gk, a); }
 
     void rotation_plan(int steps, const GaloisKeys &gk, std::vector<std::uint32_t> &plan) const
     {
@@ -1543,6 +1854,75 @@ public:
     }
 
 private:
+    // BFV tensor product scaled by t/Q (vector_ops.cpp:179 square_inplace): the exact integer products
+    // c0 = a0 b0, c1 = a0 b1 + a1 b0, c2 = a1 b1 of the centred operands are formed in an auxiliary RNS basis wide
+    // enough to hold them (dyadic products in the NTT domain on the GPU), CRT-composed on the host, multiplied by t,
+    // divided by Q with rounding and reduced into the data basis -- the textbook Fan-Vercauteren multiplication.
+    void multiply_bfv(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest) const
+    {
+        namespace bf = shim::bfv;
+        const auto &B = ctx_->bfv();
+        if (a.rows != B.L) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const std::size_t n = ctx_->n();
+        const int L = B.L, A = (int)B.aux.m.size();
+        auto lift = [&](const Ciphertext &c) {  // [2][L][N] residues -> centred integers -> [2][A][N] residues
+            const std::vector<std::uint64_t> h = shim::download(c.buf);
+            std::vector<std::uint64_t> out((std::size_t)2 * A * n);
+            for (int p = 0; p < 2; ++p)
+                for (std::size_t i = 0; i < n; ++i) {
+                    bf::Big x = B.data.compose(h.data() + (std::size_t)p * L * n, n, i);
+                    const bool neg = bf::cmp(x, B.data.half) > 0;
+                    if (neg) x = bf::sub(B.data.M, x);
+                    for (int j = 0; j < A; ++j) {
+                        const std::uint64_t r = bf::mod_small(x, B.aux.m[j]);
+                        out[((std::size_t)p * A + j) * n + i] = neg && r ? B.aux.m[j] - r : r;
+                    }
+                }
+            return out;
+        };
+        auto &ae = B.aux_engine;
+        auto da = shim::upload(ae, lift(a));
+        auto db = a.buf == b.buf ? da : shim::upload(ae, lift(b));
+        shim::check(hefx_ntt_forward(ae->ready({}), da->p, 2, A, 0, nullptr));
+        if (db != da) shim::check(hefx_ntt_forward(ae->ready({}), db->p, 2, A, 0, nullptr));
+        auto prod = shim::new_buf(ae, (std::size_t)3 * A * n);
+        shim::check(hefx_multiply(ae->ready({}), A, da->p, db->p, prod->p, nullptr));
+        shim::check(hefx_ntt_inverse(ae->ready({}), prod->p, 3, A, 0, nullptr));
+        const std::vector<std::uint64_t> hp = shim::download(prod);
+        std::vector<std::uint64_t> res((std::size_t)3 * L * n);
+        for (int p = 0; p < 3; ++p)
+            for (std::size_t i = 0; i < n; ++i) {
+                bf::Big x = B.aux.compose(hp.data() + (std::size_t)p * A * n, n, i);
+                const bool neg = bf::cmp(x, B.aux.half) > 0;
+                if (neg) x = bf::sub(B.aux.M, x);
+                bf::Big quo, rem;
+                bf::divrem(bf::mul_small(x, B.t), B.data.M, quo, rem);  // round(t |x| / Q)
+                if (bf::cmp(rem, B.data.half) > 0) quo = bf::add(quo, bf::Big(1));
+                for (int j = 0; j < L; ++j) {
+                    const std::uint64_t q = ctx_->primes()[j], r = bf::mod_small(quo, q);
+                    res[((std::size_t)p * L + j) * n + i] = neg && r ? q - r : r;
+                }
+            }
+        dest.set(shim::upload(eng(), res), 3, L, a.parms_id(), a.scale() * b.scale());
+        dest.ntt_form_ = false;
+    }
+    void apply_galois_bfv(const Ciphertext &a, const std::vector<std::uint32_t> &plan, const GaloisKeys &gk, Ciphertext &dest) const
+    {
+        check_ct(a);
+        if (a.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+        auto &e = eng();
+        auto cur = shim::new_buf(e, a.buf->words);
+        shim::check(hefx_copy(e->ready({a.buf.get()}), cur->p, a.buf->p, a.buf->words * 8, nullptr));
+        shim::check(hefx_ntt_forward(e->ready({}), cur->p, 2, a.rows, 0, nullptr));
+        for (std::uint32_t elt : plan) {
+            auto out = shim::new_buf(e, a.buf->words);
+            shim::check(hefx_apply_galois(e->ready({}), a.rows, cur->p, elt, gk.keys.at(elt)->p, out->p, nullptr));
+            cur = out;
+        }
+        shim::check(hefx_ntt_inverse(e->ready({}), cur->p, 2, a.rows, 0, nullptr));
+        dest.set(cur, 2, a.rows, a.parms_id(), a.scale());
+        dest.ntt_form_ = false;
+    }
     const std::shared_ptr<shim::Engine> &eng() const { return ctx_->engine(); }
     std::size_t words(std::size_t size, int rows) const { return size * (std::size_t)rows * ctx_->n(); }
     static bool close(double a, double b) { return a == b || std::fabs(a - b) <= std::max(std::fabs(a), std::fabs(b)) * 9.094947017729282e-13; }
@@ -1576,6 +1956,12 @@ private:
         auto &e = eng();
         const int L = a.rows;
         const std::size_t mx = std::max(a.size(), b.size()), mn = std::min(a.size(), b.size());
+        const bool ntt = a.is_ntt_form();
+        struct Mark {  // element-wise: the result has the operands' form (BFV: coefficient form)
+            Ciphertext &d;
+            bool v;
+            ~Mark() { d.ntt_form_ = v; }
+        } mark{dest, ntt};
         if (e->lazy && mx == mn) {  // the adds of helper.h:464,475 stay in the lockstep batch
             const parms_id_type id = a.parms_id();
             const double sc = a.scale();

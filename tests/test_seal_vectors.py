@@ -100,3 +100,27 @@ def test_hip_engine_on_a_selfcheck_file(tmp_path):
         res = SV.check(vec, SV.EngineImpl(vec.N, vec.primes))
         assert res.pop("rescale_mode") == ("round" if rounded else "floor")
         assert all(res.values()), res
+
+
+@pytest.mark.gpu
+def test_generator_built_against_the_shim_roundtrips_through_the_format(tmp_path):
+    """tools/gen_seal_vectors.cpp compiles against this repository's seal/seal.h (same class surface as SEAL 3.4.5:
+    Ciphertext::data, GaloisKeys::key, RelinKeys::key, PublicKey::data, Evaluator::apply_galois ...) and the files it
+    writes -- here produced by the shim on the GPU, so pinning nothing and labelled so -- load, convert (SEAL's
+    vector<PublicKey> key layout -> [k-1][2][k][N]) and check against the oracle and the engine.  What remains for a
+    person with real SEAL is to compile the same source against it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "drivers", "_ref", "gen_seal_vectors_shim")
+    if not os.path.exists(exe):
+        pytest.skip("drivers/_ref/gen_seal_vectors_shim not built (make -C drivers)")
+    r = subprocess.run([exe, str(tmp_path), "toy", "c2", "cfg1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    from oracle import oracle as O
+    for name, n, k in (("toy", 4096, 3), ("c2", 8192, 4), ("cfg1", 8192, 5)):
+        vec = SV.load(str(tmp_path / f"seal_{name}.bin"))
+        assert (vec.N, vec.k) == (n, k) and not vec.from_real_seal and "shim" in vec.producer
+        for impl in (O.Oracle(vec.N, vec.primes), SV.EngineImpl(vec.N, vec.primes)):
+            res = SV.check(vec, impl)
+            assert res.pop("rescale_mode") == "floor"      # the engine's default division
+            assert all(res.values()), (name, type(impl).__name__, {k_: v for k_, v in res.items() if not v})
