@@ -1011,8 +1011,12 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             ++c->prof_chunks;
         }
         hipStream_t cs = two ? c->streams[ci % ns] : user;
-        KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, chunk_alias, cs, prof));
+        // small chunks carry their descriptors in the first launch's kernel arguments (HEFX_SMALL=0 restores the copy)
+        static const bool small_ok = !(getenv("HEFX_SMALL") && atoi(getenv("HEFX_SMALL")) == 0);
+        const bool small = small_ok && cnt <= ks_small_max() && !hoist && !chunk_alias;
+        if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
+        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, chunk_alias, small ? hb : nullptr,
+                                      cs, prof));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
 #undef KS_TRY

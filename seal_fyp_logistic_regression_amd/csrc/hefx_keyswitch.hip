@@ -110,19 +110,12 @@ __global__ __launch_bounds__(256) void ks_alias_copy_kernel(DevTables T, const K
 // noperm: the hoisted paths decompose the UNROTATED shared source (item 0).
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_kernel(DevTables T, const KsItem *__restrict__ items,
-                                                                              int L, int relin, int noperm, int rows,
-                                                                              KsScratch S)
+__device__ __forceinline__ void intt_digits_body(const DevTables &T, const KsItem &it, int L, int relin, int noperm, int b,
+                                                 int i, int h, const KsScratch &S, u64 *lds)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
-    extern __shared__ __align__(16) u64 lds[];
-    int p, h;
-    split_decode(blockIdx.x, p, h);
-    if (p >= rows) return;
     const int t = threadIdx.x;
-    const int b = p / L, i = p % L;
-    const KsItem it = items[b];
     const u64 *__restrict__ src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * SC::N;
     u64 v[16];
     if (relin || noperm || item_elt(it) == 1u) {
@@ -136,6 +129,38 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_kernel(DevTables T, const KsItem *__restrict__ items,
+                                                                              int L, int relin, int noperm, int rows,
+                                                                              KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    intt_digits_body<LOGN>(T, items[p / L], L, relin, noperm, p / L, p % L, h, S, lds);
+}
+
+// Small batches (a lone rotation of a NAF chain, the lockstep chains of a few dot products): the descriptors travel in
+// the KERNEL ARGUMENTS of this first launch -- no host-to-device descriptor copy ahead of the sequence (a ~4 us blit
+// plus its dependency gap on a ~90 us operation) -- and block 0 leaves them in device memory for the launches after it.
+constexpr int KS_SMALL_MAX = 8;
+struct KsSmallItems {
+    KsItem it[KS_SMALL_MAX];
+};
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_small_kernel(DevTables T, KsSmallItems small,
+                                                                                    KsItem *__restrict__ items_out, int n,
+                                                                                    int L, int relin, int rows, KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    if (blockIdx.x == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
+    int p, h;
+    split_decode(blockIdx.x, p, h);
+    if (p >= rows) return;
+    intt_digits_body<LOGN>(T, small.it[p / L], L, relin, 0, p / L, p % L, h, S, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -631,14 +656,15 @@ static void set_lds(K kernel, size_t bytes)
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                           const KsScratch &scr, int sub, bool hoist, bool alias, hipStream_t s,
-                                           KsProf *prof)
+                                           const KsScratch &scr, int sub, bool hoist, bool alias,
+                                           const KsSmallItems *small, hipStream_t s, KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
         set_lds(ks_intt_digits_kernel<LOGN>, lds);
+        set_lds(ks_intt_digits_small_kernel<LOGN>, lds);
         set_lds(ks_ntt_digits_kernel<LOGN>, lds);
         set_lds(ks_moddown_intt_kernel<LOGN>, lds);
         set_lds(ks_moddown_finish_kernel<LOGN>, lds);
@@ -679,8 +705,12 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL(ks_alias_copy_kernel, dim3(SC::N / 2 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L);
     }
     mark(1);
-    hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, batch, L, rl, 0,
-                       n * L, scr);
+    if (small)
+        hipLaunchKernelGGL((ks_intt_digits_small_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, *small,
+                           const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
+    else
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, batch, L, rl, 0,
+                           n * L, scr);
     if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
         if constexpr (LOGN <= 14) {
             static PerDeviceOnce fattr;
@@ -804,10 +834,19 @@ hipError_t launch_lt2_moddown(const DevTables &T, int L, const KsItem *item, con
 }
 int lt2_chunk() { return LT2_CHUNK; }
 
+int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                  const KsScratch &scr, int sub, bool hoist, bool alias, hipStream_t s, KsProf *prof)
+                                  const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
+                                  hipStream_t s, KsProf *prof)
 {
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, s, prof)
+    KsSmallItems sm;
+    const KsSmallItems *small = nullptr;
+    if (small_items && n <= KS_SMALL_MAX && !hoist && !alias) {
+        for (int i = 0; i < n; ++i) sm.it[i] = small_items[i];
+        for (int i = n; i < KS_SMALL_MAX; ++i) sm.it[i] = KsItem{};
+        small = &sm;
+    }
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }
