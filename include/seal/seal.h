@@ -228,6 +228,10 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     if (const char *d = std::getenv("HEFX_DEVICE")) dev = std::atoi(d);
     check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx_raw));
     if (const char *l = std::getenv("SEAL_SHIM_LAZY")) e->lazy = std::atoi(l) != 0;
+    // the one SEAL semantic that could not be verified offline: SEAL_SHIM_RESCALE=round switches
+    // rescale_to_next from the floor division (3.4.x as App. A.9 reads it; default) to round-to-nearest (3.5+)
+    if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
+        check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "round" ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR));
     if (const char *m = std::getenv("SEAL_SHIM_PENDING_MB")) e->pend_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *st = std::getenv("SEAL_SHIM_STATS")) {
         if (std::atoi(st)) {
@@ -291,9 +295,10 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     pend_bytes += out_words * 8;
     BufPtr out = nd.dst;
     if (pend_bytes > pend_budget || pend.size() > 400000) flush();  // bounded memory: run what is recorded
-    // SEAL_SHIM_SYNC=1 promises a caller's chrono timers completed work: only the rotate_vector / multiply_plain pairs of
-    // the linear-transform loops stay recorded there (their add_many observes them inside the timed region)
-    if (sync_mode() && kind != Node::ROT && kind != Node::MULPT && !pend.empty()) {
+    // SEAL_SHIM_SYNC=1 promises a caller's chrono timers completed work: only the rotations and the products of the
+    // linear-transform loops (helper.h:216-229, 252-257) stay recorded there -- their add_many observes them inside the
+    // timed region; relinearize / rescale / add run (and are waited for) at the call
+    if (sync_mode() && kind != Node::ROT && kind != Node::MULPT && kind != Node::MULCT && !pend.empty()) {
         flush();
         (void)hefx_stream_sync(ctx_raw, nullptr);
     }
