@@ -607,21 +607,47 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                                                              pt != nullptr, cx, T, sp, j, mc);
         }
     } else {
-        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+        // 128-VGPR builds (N >= 16384).  Epilogue knobs (experiments; defaults are what the tree ships):
+        //   HEFX_EPI       operands fetched per group (4, 8 or 16 of the thread's 16 coefficients)
+        //   HEFX_EPI_PIPE  1: the next group's operands are fetched before the current group is computed
+        //   HEFX_EPI_EARLY 1: the first group's operands are fetched after the transform's last LDS exchange, i.e.
+        //                  they travel while its final stages compute
+#ifndef HEFX_EPI
+#define HEFX_EPI 4
+#endif
+#ifndef HEFX_EPI_PIPE
+#define HEFX_EPI_PIPE 0
+#endif
+#ifndef HEFX_EPI_EARLY
+#define HEFX_EPI_EARLY 0
+#endif
+        constexpr int GS = HEFX_EPI, NG = 16 / GS, NBUF = HEFX_EPI_PIPE ? 2 : 1;
+        u64 a[NBUF][GS], sadd[NBUF][GS], pp[NBUF][GS];
+        auto fetch = [&](int g, int bufi) {
 #pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            u64 a[4], sadd[4], pp[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = C::idx_out(t, 4 * hh + r);
-                a[r] = acc[idx];
-                sadd[r] = addin(idx);
-                pp[r] = pt ? pt[idx] : 0;
+            for (int r = 0; r < GS; ++r) {
+                const int idx = C::idx_out(t, GS * g + r);
+                a[bufi][r] = acc[idx];
+                sadd[bufi][r] = addin(idx);
+                pp[bufi][r] = pt ? pt[idx] : 0;
             }
+        };
+        if (HEFX_EPI_EARLY) {
+            auto hook = [&]() { fetch(0, 0); };
+            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, decltype(hook)>(f, ld, mode, mc, lds, tw, cx, t, h, hook);
+        } else {
+            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+            fetch(0, 0);
+        }
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[C::idx_out(t, 4 * hh + r)] =
-                    md_epilogue(A{}, f[4 * hh + r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+        for (int g = 0; g < NG; ++g) {
+            const int cur = HEFX_EPI_PIPE ? (g & 1) : 0;
+            if (HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
+#pragma unroll
+            for (int r = 0; r < GS; ++r)
+                dst[C::idx_out(t, GS * g + r)] =
+                    md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], pt != nullptr, cx, T, sp, j, mc);
+            if (!HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, 0);
         }
     }
 }

@@ -303,10 +303,15 @@ __device__ __forceinline__ void load_rem_tw(typename A::TW (&w)[15], const typen
 // idx_out(t,r) on exit, NOT yet canonical (apply A::fwd_finish).
 // `pre` is the twiddle-index prefix: 1 for a whole transform of size 2^LOGN; 2+h when this call is half h of a
 // transform of size 2^(LOGN+1) whose first stage was applied by the caller (stage s uses tw[(pre << s) + i]).
-template <int LOGN, class A>
+struct NoHook {
+    __device__ __forceinline__ void operator()() const {}
+};
+// `tail_hook` runs once, right after the last LDS exchange (before the final stages' arithmetic): a caller's chance to
+// put loads in flight that only its epilogue needs (ks_moddown_finish)
+template <int LOGN, class A, class HOOK = NoHook>
 __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A::V *lds,
                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                             int pre)
+                                             int pre, const HOOK &tail_hook = HOOK())
 {
     using C = NttCfg<LOGN>;
     typename A::TW w[15];
@@ -321,6 +326,7 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
         }
+        if (C::R == 0 && p == C::FP - 1) tail_hook();
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int half = 8 >> u;
@@ -347,6 +353,7 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
 #pragma unroll
             for (int e = 0; e < C::G; ++e) v[c * C::G + e] = lds[C::phys(g * C::G + e)];
         }
+        tail_hook();
 #pragma unroll
         for (int u = 0; u < C::R; ++u) {
             const int half = C::G >> (u + 1);
@@ -483,10 +490,10 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 // v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
 // NB = number of load batches of the first stage: 2 (eight pairs each) under the 128-VGPR cap, 1 (all sixteen pairs in
 // flight at once, one exposed memory latency instead of two) in the 256-VGPR builds.
-template <int LOGN, class A, class LD, int NB = 2>
+template <int LOGN, class A, class LD, int NB = 2, class HOOK = NoHook>
 __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, const InMode &mode,
                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
-                                              const typename A::Ctx &cx, int t, int h)
+                                              const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK())
 {
     const typename A::TW w1 = tw[1];
     // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
@@ -517,7 +524,7 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
             HEFX_STAGE_FENCE();
         }
     }
-    ntt_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
+    ntt_fwd_core<LOGN - 1, A, HOOK>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h, tail_hook);
 }
 
 template <int LOGN, class A, class LD, int NB = 2>

@@ -440,3 +440,43 @@ def test_c_abi_allreduce_on_a_one_rank_communicator():
         e.comm_init(1, 0, uid)            # one communicator per context
     e.comm_destroy()
     assert e.comm_world == 0
+
+
+@pytest.mark.parametrize("N", [4096, 16384])
+def test_primes_at_the_top_of_the_admissible_range_bit_exact(N):
+    """The integer NTT policy keeps values in [0,8q) forward / [0,4q) inverse (under-estimated Shoup quotient), which is
+    tight against 2^64 for primes just below 2^61 -- the largest hefx_context_create admits (SEAL's own primes stop at
+    60 bits).  NTT round trip, key switch (rotation, fused product, relinearisation) and both rescales against the
+    oracle on the four largest such primes, with all-(q-1) inputs as the worst case for every lazy sum."""
+    from oracle import oracle as O
+    from seal_fyp_logistic_regression_amd import Engine
+    from seal_fyp_logistic_regression_amd.seal import _is_prime
+    primes, v = [], (1 << 61) - 2 * N + 1
+    while len(primes) < 4:
+        if _is_prime(v):
+            primes.append(v)
+        v -= 2 * N
+    assert all(p.bit_length() == 61 for p in primes)
+    o, e = O.Oracle(N, primes), Engine(N, primes)
+    k, L = 4, 3
+    worst = np.stack([np.full(N, p - 1, dtype=np.uint64) for p in primes])
+    for a in (o.uniform(k, 1, 3)[0], worst):
+        d = e.to_device(a[None])
+        e.ntt_forward(d, 1, k, 0)
+        assert (d.download()[0] == np.stack([o.ntt_fwd(j, a[j]) for j in range(k)])).all()
+        e.ntt_inverse(d, 1, k, 0)
+        assert (d.download()[0] == a).all()
+    key = _rand_key(o, 7)
+    dkey = e.to_device(key)
+    ct_worst = np.stack([worst[:L], worst[:L]])
+    for ct in (o.uniform(L, 2, 11), ct_worst):
+        pt = o.uniform(L, 1, 12)[0]
+        for elt in (3, 2 * N - 1, O.galois_elt_from_step(N, -5)):
+            assert (e.apply_galois(L, e.to_device(ct), elt, dkey).download() == o.apply_galois(ct, elt, key)).all()
+            got = e.rotate_multiply_plain_batch(L, [e.to_device(ct)] * 3, [elt] * 3, [dkey] * 3, [e.to_device(pt)] * 3)
+            assert all((g.download() == o.rotate_mulplain(ct, elt, key, pt)).all() for g in got)
+        m = o.multiply(ct, ct)
+        r = o.relinearize(m, key)
+        assert (e.relinearize(L, e.to_device(m), dkey).download() == r).all()
+        for rounded in (False, True):
+            assert (e.rescale_to_next(L, 2, e.to_device(r), rounded=rounded).download() == o.rescale(r, rounded=rounded)).all()
