@@ -1014,9 +1014,14 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         // small chunks carry their descriptors in the first launch's kernel arguments (HEFX_SMALL=0 restores the copy)
         static const bool small_ok = !(getenv("HEFX_SMALL") && atoi(getenv("HEFX_SMALL")) == 0);
         const bool small = small_ok && cnt <= ks_small_max() && !hoist && !chunk_alias;
+        // ... and run on quarter-row workgroups when split-2 workgroups (2 L (L+1) per item in the widest launch) would
+        // leave CUs idle: HEFX_QUARTER=0/1 overrides the size test
+        static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
+        const bool quarter = small && !fused && nchunks == 1 &&
+                             (quarter_force >= 0 ? quarter_force != 0 : cnt * 2 * L * (L + 1) <= 256);
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, chunk_alias, small ? hb : nullptr,
-                                      cs, prof));
+                                      quarter, cs, prof));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
 #undef KS_TRY

@@ -125,9 +125,10 @@ struct KsProf {
 };
 // small_items != nullptr (host copy of the n <= ks_small_max() descriptors of a non-hoisted, non-aliasing chunk): the
 // descriptors are passed in the first launch's arguments; d_items is then written by that launch, not copied to
+// quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  hipStream_t s, KsProf *prof);
+                                  bool quarter, hipStream_t s, KsProf *prof);
 int ks_small_max();
 // double-hoisted linear transform (hefx_keyswitch.hip): see lt2_mac_kernel
 hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,

@@ -673,6 +673,180 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
         moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
 }
 
+// ------------------------------------------------------------------------------------------------
+// SMALL-BATCH path: quarter rows (hefx_ntt8.cuh) -- the same five launches with every row handled by four workgroups
+// of N/32 threads, eight coefficients per thread.  Selected when a chunk cannot fill the chip with split-2 workgroups
+// (a lone rotation of a NAF chain, the eight lockstep chains of the LR gradient, logistic_regression_ckks.cpp:295-300 ->
+// helper.h:472-476): there the caller waits for the latency of one 60-bit transform, which is instruction issue on the
+// one CU that runs it.  Same integers, same bits.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+struct QuarterCfg {
+    using C = Ntt8Cfg<LOGN - 2>;
+    static constexpr int N = 1 << LOGN;
+    static constexpr int Q = N / 4;   // points per workgroup
+    static constexpr int T = C::T;    // threads per workgroup = N/32
+    static constexpr size_t LDS_BYTES = sizeof(u64) * C::LDS_WORDS;
+};
+// rows -> grid: the four quarters of row p sit at block ids that differ by 8 (same XCD under round-robin dispatch)
+__host__ __device__ static inline int quarter_grid(int rows) { return ((rows + 7) / 8) * 32; }
+__device__ static __forceinline__ void quarter_decode(int bid, int &p, int &part)
+{
+    part = (bid >> 3) & 3;
+    p = ((bid >> 5) << 3) | (bid & 7);
+}
+// EO position of coefficient j (rows in coefficient form are stored [evens | odds], as the split-2 kernels do)
+template <int LOGN>
+__device__ static __forceinline__ int eo_pos(int j) { return (j & 1) * (1 << (LOGN - 1)) + (j >> 1); }
+
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_intt_digits_q_kernel(DevTables T, KsSmallItems small,
+                                                                     KsItem *__restrict__ items_out, int n, int L,
+                                                                     int relin, int rows, KsScratch S)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    if (blockIdx.x == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
+    int p, part;
+    quarter_decode(blockIdx.x, p, part);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int b = p / L, i = p % L;
+    const KsItem it = small.it[b];
+    const u64 *__restrict__ src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * QC::N;
+    const uint32_t elt = relin ? 1u : item_elt(it);
+    u64 v[8];
+    quarter_inv<LOGN>(v, [src, elt](int j) {
+        return elt == 1u ? reinterpret_cast<const ulonglong2 *>(src)[j] : gather_pair(src, (uint32_t)j, elt, LOGN);
+    }, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, part);
+    u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * QC::N;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) dd[eo_pos<LOGN>(4 * C::idx_nat(t, r) + part)] = v[r];
+}
+
+// forward loader over a coefficient-form row stored EO
+template <int LOGN>
+struct EoQuadLoader {
+    const u64 *__restrict__ row;
+    int t;
+    __device__ __forceinline__ void operator()(int r, u64 &x0, u64 &x1, u64 &x2, u64 &x3) const
+    {
+        using C = typename QuarterCfg<LOGN>::C;
+        const int e = eo_pos<LOGN>(C::idx_nat(t, r));
+        constexpr int STEP = (1 << LOGN) / 8;  // N/4 coefficients further = N/8 EO slots further
+        x0 = row[e];
+        x1 = row[e + STEP];
+        x2 = row[e + 2 * STEP];
+        x3 = row[e + 3 * STEP];
+    }
+};
+
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(DevTables T, int L, int rows, KsScratch S)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    // block -> (digit g = (b, i), target slot jj, quarter): the 4 L workgroups of a digit share an XCD
+    const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;
+    int jj = slot >> 2;
+    const int part = slot & 3;
+    if (g >= rows) return;
+    const int t = threadIdx.x;
+    const int b = g / L, i = g % L;
+    if (jj >= i) ++jj;
+    const int m = jj < L ? jj : T.k - 1;
+    const ModConst mc = T.mods[m];
+    const u64 qi = T.mods[i].q;
+    u64 v[8];
+    const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
+    const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, t};
+    quarter_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, part);
+    u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) xd[C::idx_out(t, r)] = v[r];
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_intt_q_kernel(DevTables T, int L, int rows, KsScratch S)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    int p, part;
+    quarter_decode(blockIdx.x, p, part);
+    if (p >= rows) return;
+    const int t = threadIdx.x;
+    const int sp = T.k - 1;
+    const ModConst mc = T.mods[sp];
+    const ulonglong2 *__restrict__ src =
+        reinterpret_cast<const ulonglong2 *>(S.acc + ((size_t)p * (L + 1) + L) * QC::N);  // p = b*2 + c
+    u64 v[8];
+    quarter_inv<LOGN>(v, [src](int j) { return src[j]; }, lds, ntt_tables(T, sp), mc, T.modsf[sp], t, part);
+    const u64 half = mc.q >> 1;
+    u64 *__restrict__ ud = S.u + (size_t)p * QC::N;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ud[eo_pos<LOGN>(4 * C::idx_nat(t, r) + part)] = csub(v[r] + half, mc.q);
+}
+
+template <int LOGN, class A>
+__device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const KsItem &it, int L, int relin,
+                                                      const KsScratch &S, u64 *lds,
+                                                      const typename A::TW *__restrict__ tw, const typename A::Ctx &cx,
+                                                      const ModConst &mc, int b, int c, int j, int t, int part)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    const int sp = T.k - 1;
+    const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
+    const InMode mode = {true, true, true, half_j};
+    const EoQuadLoader<LOGN> ld{S.u + ((size_t)b * 2 + c) * QC::N, t};
+    const size_t off = (size_t)part * QC::Q;
+    const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * QC::N + off;
+    const u64 *__restrict__ addrow = it.c_in + ((size_t)(relin ? c : 0) * L + j) * QC::N;
+    const bool has_add = relin || c == 0;
+    const uint32_t elt = relin ? 1u : item_elt(it);
+    const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * QC::N + off : nullptr;
+    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * QC::N + off;
+    // the epilogue's operands do not depend on the transform: fetched before it, they travel while it runs
+    u64 a[8], sadd[8], pp[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int idx = C::idx_out(t, r);
+        a[r] = acc[idx];
+        sadd[r] = !has_add ? 0 : addrow[elt == 1u ? (uint32_t)(off + idx) : galois_index((uint32_t)(off + idx), elt, LOGN)];
+        pp[r] = pt ? pt[idx] : 0;
+    }
+    typename A::V f[8];
+    quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+        dst[C::idx_out(t, r)] = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kernel(DevTables T, const KsItem *__restrict__ items,
+                                                                        int L, int relin, int rows, KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;  // g = remainder polynomial (b, c)
+    const int j = slot >> 2, part = slot & 3;
+    if (g >= rows) return;
+    const int t = threadIdx.x;
+    const int b = g >> 1, c = g & 1;
+    const ModConst mc = T.mods[j];
+    const ModConstF mf = T.modsf[j];
+    const NttTables nt = ntt_tables(T, j);
+    const KsItem it = items[b];
+    if (mf.q != 0.0)
+        moddown_finish_q_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, part);
+    else
+        moddown_finish_q_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, part);
+}
+
 template <typename K>
 static void set_lds(K kernel, size_t bytes)
 {
@@ -683,7 +857,7 @@ static void set_lds(K kernel, size_t bytes)
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, int sub, bool hoist, bool alias,
-                                           const KsSmallItems *small, hipStream_t s, KsProf *prof)
+                                           const KsSmallItems *small, bool quarter, hipStream_t s, KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -723,6 +897,34 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(5);
         hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch,
                            L, 0, n * 2, scr);
+        mark(-1);
+        return hipGetLastError();
+    }
+    // quarter rows: a small chunk that cannot fill the chip with split-2 workgroups (unfused, no aliasing / hoisting)
+    if (small && quarter && sub >= n) {
+        static PerDeviceOnce attrq;
+        const size_t ldsq = QuarterCfg<LOGN>::LDS_BYTES;
+        if (attrq.first()) {
+            set_lds(ks_intt_digits_q_kernel<LOGN>, ldsq);
+            set_lds(ks_ntt_digits_q_kernel<LOGN>, ldsq);
+            set_lds(ks_moddown_intt_q_kernel<LOGN>, ldsq);
+            set_lds(ks_moddown_finish_q_kernel<LOGN>, ldsq);
+        }
+        constexpr int TQ = QuarterCfg<LOGN>::T;
+        mark(1);
+        hipLaunchKernelGGL((ks_intt_digits_q_kernel<LOGN>), dim3(quarter_grid(n * L)), dim3(TQ), ldsq, s, T, *small,
+                           const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
+        mark(2);
+        hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(((n * L + 7) / 8) * 8 * 4 * L), dim3(TQ), ldsq, s, T, L,
+                           n * L, scr);
+        mark(3);
+        hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, rl, 0,
+                           n, scr);
+        mark(4);
+        hipLaunchKernelGGL((ks_moddown_intt_q_kernel<LOGN>), dim3(quarter_grid(n * 2)), dim3(TQ), ldsq, s, T, L, n * 2, scr);
+        mark(5);
+        hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(((n * 2 + 7) / 8) * 8 * 4 * L), dim3(TQ), ldsq, s, T,
+                           batch, L, rl, n * 2, scr);
         mark(-1);
         return hipGetLastError();
     }
@@ -863,7 +1065,7 @@ int lt2_chunk() { return LT2_CHUNK; }
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  hipStream_t s, KsProf *prof)
+                                  bool quarter, hipStream_t s, KsProf *prof)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
@@ -872,7 +1074,8 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
         for (int i = n; i < KS_SMALL_MAX; ++i) sm.it[i] = KsItem{};
         small = &sm;
     }
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, s, prof)
+    quarter = quarter && T.logn >= 12;  // quarter rows of N = 2048 would be half-wave workgroups
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

@@ -22,6 +22,8 @@
 //             no range corrections in the forward transform (growth 0.52q per stage), one re-centering per
 //             radix-16 pass in the inverse.  Exactness argument in DESIGN.md ("FP64 modmul").
 #pragma once
+#include <type_traits>
+
 #include "hefx_modarith.cuh"
 
 // Scheduling fence between radix-2 stages: keeps hipcc from hoisting every twiddle load of a pass (60 VGPRs)
@@ -125,7 +127,21 @@ struct ArithU64 {
     {
         return shoup_lazy4(a0 + c.q - a1, w.x, w.y, c.q);
     }
-    __device__ static __forceinline__ void inv_pass_begin(V (&)[16], const Ctx &) {}
+    template <int NV>
+    __device__ static __forceinline__ void inv_pass_begin(V (&)[NV], const Ctx &) {}
+    // quarter-row helpers (hefx_ntt8.cuh).  Forward: second stage on values < 5q, result < 8q.  Inverse: sum / twiddled
+    // difference of two values of the inverse range [0,4q), results back in [0,4q).
+    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &w, const Ctx &c, int h)
+    {
+        const u64 a = csub(x, c.four_q);
+        const u64 t = shoup_lazy4(y, w.x, w.y, c.q);
+        return h ? a + c.four_q - t : a + t;
+    }
+    __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &c) { return csub(x + y, c.four_q); }
+    __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c)
+    {
+        return shoup_lazy4(x + c.four_q - y, w.x, w.y, c.q);
+    }
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     static constexpr bool IS_F64 = false;
     template <bool RED>
@@ -219,11 +235,19 @@ struct ArithF64 {
         return mm(a0 - a1, w, c);
     }
     // sums double per inverse stage: re-centre the 16 registers once per radix-16 pass (|x| <= 16*0.52q after it)
-    __device__ static __forceinline__ void inv_pass_begin(V (&v)[16], const Ctx &c)
+    template <int NV>
+    __device__ static __forceinline__ void inv_pass_begin(V (&v)[NV], const Ctx &c)
     {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) v[e] = red(v[e], c);
+        for (int e = 0; e < NV; ++e) v[e] = red(v[e], c);
     }
+    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &w, const Ctx &c, int h)
+    {
+        const double t = mm(y, w, c);
+        return h ? x - t : x + t;
+    }
+    __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &) { return x + y; }
+    __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c) { return mm(x - y, w, c); }
     // u64 <-> double for integers in [0, 2^52) by exponent splicing: one integer OR/AND on the high word plus one
     // v_add_f64, instead of the v_cvt/v_ldexp/v_trunc/v_floor sequences of a generic conversion
     __device__ static __forceinline__ V from_u64(u64 x)

@@ -137,4 +137,182 @@ __device__ __forceinline__ void split8_fwd_a(u64 (&out)[8], const LD &ld, u64 *l
     for (int r = 0; r < 8; ++r) out[r] = A::fwd_finish(f[r], cx);
 }
 
+// Inverse core with eight coefficients per thread: v[r] = NTT value idx_out(t,r) on entry (U64: [0,4q); F64: |v| < 2^45),
+// coefficient idx_nat(t,r) on exit, not yet canonical (A::inv_finish).  Mirror of ntt8_fwd_core; N^-1 folded into the
+// last stage exactly as in ntt_inv_core.
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A::V *lds,
+                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
+{
+    using C = Ntt8Cfg<LOGN>;
+    typename A::TW w[7];
+    if (C::R > 0) {
+        load_rem_tw8<LOGN, A>(w, itw, t, 1);
+        A::inv_pass_begin(v, cx);
+#pragma unroll
+        for (int u = C::R - 1; u >= 0; --u) {
+            const int half = C::G >> (u + 1);
+#pragma unroll
+            for (int c = 0; c < C::NG; ++c) {
+#pragma unroll
+                for (int e = 0; e < C::G; ++e) {
+                    if (e & half) continue;
+                    A::gs(v[c * C::G + e], v[c * C::G + (e | half)],
+                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx);
+                }
+            }
+        }
+        load_pass_tw8<LOGN, A>(w, itw, C::FP - 1, t, 1);
+#pragma unroll
+        for (int c = 0; c < C::NG; ++c) {
+            const int g = t + C::T * c;
+#pragma unroll
+            for (int e = 0; e < C::G; ++e) lds[C::phys(g * C::G + e)] = v[c * C::G + e];
+        }
+        __syncthreads();
+    } else {
+        load_pass_tw8<LOGN, A>(w, itw, C::FP - 1, t, 1);
+    }
+#pragma unroll
+    for (int p = C::FP - 1; p >= 0; --p) {
+        const int LOGS = LOGN - 3 * (p + 1);
+        const int S = 1 << LOGS;
+        const int b = t >> LOGS;
+        const int base = b * (8 * S) + (t & (S - 1));
+        if (p < C::FP - 1 || C::R > 0) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = lds[C::phys(base + S * e)];
+        }
+        A::inv_pass_begin(v, cx);
+#pragma unroll
+        for (int u = 2; u >= 0; --u) {
+            const int half = 4 >> u;
+            if (p == 0 && u == 0) {  // last stage: fold N^-1
+#pragma unroll
+                for (int e = 0; e < 4; ++e) A::gs_last(v[e], v[e | 4], cx);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    if (e & half) continue;
+                    A::gs(v[e], v[e | half], w[(1 << u) - 1 + (e >> (3 - u))], cx);
+                }
+            }
+        }
+        if (p > 0) {
+            load_pass_tw8<LOGN, A>(w, itw, p - 1, t, 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) lds[C::phys(base + S * e)] = v[e];
+            __syncthreads();
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// QUARTER rows for small batches: a row of 2^LOGN points is handled by FOUR workgroups of N/32 threads, eight
+// coefficients per thread -- the same two waves per SIMD as the split-2 workgroups (one wave alone cannot keep a SIMD
+// issuing: dependent VALU instructions need a second wave to fill the pipeline, which is why quarter rows with sixteen
+// coefficients per thread were slower), but ~2300 instead of ~3600 instructions per thread on a 60-bit row and twice as
+// many CUs per row.  The first TWO forward stages (gaps N/2, N/4; twiddles tw[1], tw[2 + h0]) are applied while
+// loading -- every quarter reads the whole row and keeps one of four outputs per position -- and the first two
+// inverse stages (gaps 1, 2) combine the four values of positions 4g..4g+3.  Used when a chunk cannot fill the chip:
+// a lone rotation of a NAF chain, the lockstep chains of a few dot products.
+// ------------------------------------------------------------------------------------------------
+// ld(r, x0, x1, x2, x3): raw words of the coefficients idx_nat(t,r) + m*N/4, m = 0..3; on return
+// f[r] = unfinished NTT value at qd*N/4 + idx_out(t,r), qd = 2*h0 + h1
+template <int LOGN, class A, class LD>
+__device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD &ld, const InMode &mode,
+                                                const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
+                                                const typename A::Ctx &cx, int t, int qd)
+{
+    const int h0 = qd >> 1, h1 = qd & 1;
+    const typename A::TW w1 = tw[1], w2 = tw[2 + h0];
+    auto stage = [&](auto red) {
+        constexpr bool RED = decltype(red)::value;
+        u64 x[8][4];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ld(r, x[r][0], x[r][1], x[r][2], x[r][3]);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            // stage 0 (gap N/2): half h0 of (x0, x2) and of (x1, x3); stage 1 (gap N/4): quarter h1 of that half
+            const typename A::V a = A::ct_half(A::template input<RED>(x[r][0], mode, cx, mc),
+                                               A::template input<RED>(x[r][2], mode, cx, mc), w1, cx, h0);
+            const typename A::V b = A::ct_half(A::template input<RED>(x[r][1], mode, cx, mc),
+                                               A::template input<RED>(x[r][3], mode, cx, mc), w1, cx, h0);
+            f[r] = A::ct_sel(a, b, w2, cx, h1);
+        }
+        HEFX_STAGE_FENCE();
+    };
+    if (A::IS_F64 ? mode.red_f64 : mode.red_int)
+        stage(std::true_type{});
+    else
+        stage(std::false_type{});
+    ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 4 + qd);
+}
+
+template <int LOGN, class LD>
+__device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InMode &mode, u64 *lds, const NttTables &nt,
+                                            const ModConst &mc, const ModConstF &mf, int t, int qd)
+{
+    if (mf.q != 0.0) {
+        const ArithF64::Ctx cx = ArithF64::make(mf);
+        double f[8];
+        quarter_fwd_raw<LOGN, ArithF64, LD>(f, ld, mode, mc, lds, nt.twf, cx, t, qd);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = ArithF64::fwd_finish(f[r], cx);
+    } else {
+        const ArithU64::Ctx cx = ArithU64::make(mc);
+        quarter_fwd_raw<LOGN, ArithU64, LD>(v, ld, mode, mc, lds, nt.tw, cx, t, qd);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = ArithU64::fwd_finish(v[r], cx);
+    }
+}
+
+// ldp(j) = (value[2j], value[2j+1]) of the row (canonical NTT values); part = position mod 4 of the kept value; on return
+// v[r] = coefficient 4*idx_nat(t,r) + part, canonical
+template <int LOGN, class A, class LDP>
+__device__ __forceinline__ void quarter_inv_a(u64 (&v)[8], const LDP &ldp, u64 *lds,
+                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t,
+                                              int part)
+{
+    using C = Ntt8Cfg<LOGN - 2>;
+    constexpr int N = 1 << LOGN;
+    const int b0 = part & 1, b1 = part >> 1;
+    typename A::V f[8];
+    ulonglong2 p0[8], p1[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int j = C::idx_out(t, r);  // the four positions 4j .. 4j+3
+        p0[r] = ldp(2 * j);
+        p1[r] = ldp(2 * j + 1);
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+        const int j = C::idx_out(t, r);
+        typename A::V e0, e1;  // stage A (gap 1): positions 4j + b0 and 4j + 2 + b0
+        if (b0 == 0) {
+            e0 = A::gs_half_sum(A::from_u64(p0[r].x), A::from_u64(p0[r].y), cx);
+            e1 = A::gs_half_sum(A::from_u64(p1[r].x), A::from_u64(p1[r].y), cx);
+        } else {
+            e0 = A::gs_half_diff(A::from_u64(p0[r].x), A::from_u64(p0[r].y), itw[N / 2 + 2 * j], cx);
+            e1 = A::gs_half_diff(A::from_u64(p1[r].x), A::from_u64(p1[r].y), itw[N / 2 + 2 * j + 1], cx);
+        }
+        // stage B (gap 2): sum (b1 = 0) or twiddled difference (b1 = 1)
+        f[r] = b1 == 0 ? A::inv_add(e0, e1, cx) : A::inv_sub_mul(e0, e1, itw[N / 4 + j], cx);
+    }
+    HEFX_STAGE_FENCE();
+    ntt8_inv_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = A::inv_finish(f[r], cx);
+}
+
+template <int LOGN, class LDP>
+__device__ __forceinline__ void quarter_inv(u64 (&v)[8], const LDP &ldp, u64 *lds, const NttTables &nt,
+                                            const ModConst &mc, const ModConstF &mf, int t, int part)
+{
+    if (mf.q != 0.0)
+        quarter_inv_a<LOGN, ArithF64>(v, ldp, lds, nt.itwf, ArithF64::make(mf), t, part);
+    else
+        quarter_inv_a<LOGN, ArithU64>(v, ldp, lds, nt.itw, ArithU64::make(mc), t, part);
+}
+
 }  // namespace hefx

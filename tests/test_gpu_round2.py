@@ -480,3 +480,56 @@ def test_primes_at_the_top_of_the_admissible_range_bit_exact(N):
         assert (e.relinearize(L, e.to_device(m), dkey).download() == r).all()
         for rounded in (False, True):
             assert (e.rescale_to_next(L, 2, e.to_device(r), rounded=rounded).download() == o.rescale(r, rounded=rounded)).all()
+
+
+@pytest.mark.parametrize("quarter", ["0", "1"])
+def test_small_batch_quarter_row_path_bit_exact(quarter):
+    """The small-batch key switch (quarter-row workgroups with eight coefficients per thread, descriptors in the kernel
+    arguments; HEFX_QUARTER forces it on or off for chunks of <= 8 items) gives the oracle's bits for rotations, fused
+    rotate+multiply_plain and relinearisation at every ring size it is built for (N = 4096 .. 32768: every radix-8 pass
+    / remainder combination of the 8-coefficient cores), top and lower levels, 1..8 items, distinct keys / elements."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, json, os
+sys.path.insert(0, %r)
+import numpy as np
+from oracle import oracle as O
+from seal_fyp_logistic_regression_amd import Engine
+gold = json.load(open(os.path.join(%r, "tests", "golden", "appendix_b.json")))
+sets = {s["name"]: s for s in gold["sets"]}
+ok = True
+for name in ("C2", "C3", "C4", "C5", "toy4096", "toy2048"):
+    if name.startswith("toy"):
+        N = int(name[3:])
+        primes = O.coeff_modulus_create(N, [50, 30, 30, 50])
+    else:
+        N, primes = sets[name]["N"], [int(p, 16) for p in sets[name]["primes"]]
+    o, e = O.Oracle(N, primes), Engine(N, primes)
+    k = len(primes)
+    keys = [o.uniform(k, 2 * (k - 1), 70 + i).reshape(k - 1, 2, k, N) for i in range(3)]
+    dkeys = [e.to_device(x) for x in keys]
+    for L in sorted({k - 1, max(1, k - 2), 1}):
+        for n in (1, 3, 8):
+            cts = [o.uniform(L, 2, 100 * L + i) for i in range(n)]
+            pts = [o.uniform(L, 1, 200 * L + i)[0] for i in range(n)]
+            steps = [(1, -1, 5, 2)[i %% 4] for i in range(n)]
+            elts = [O.galois_elt_from_step(N, s) for s in steps]
+            kk = [i %% 3 for i in range(n)]
+            d = [e.to_device(c) for c in cts]
+            outs = e.apply_galois_batch(L, d, elts, [dkeys[j] for j in kk])
+            ok &= all((outs[i].download() == o.apply_galois(cts[i], elts[i], keys[kk[i]])).all() for i in range(n))
+            outs = e.rotate_multiply_plain_batch(L, d, elts, [dkeys[j] for j in kk], [e.to_device(p) for p in pts])
+            ok &= all((outs[i].download() == o.rotate_mulplain(cts[i], elts[i], keys[kk[i]], pts[i])).all() for i in range(n))
+            m = [o.multiply(cts[i], cts[(i + 1) %% n]) for i in range(n)]
+            outs = e.relinearize_batch(L, [e.to_device(x) for x in m], dkeys[0])
+            ok &= all((outs[i].download() == o.relinearize(m[i], keys[0])).all() for i in range(n))
+        ct = o.uniform(L, 2, 999)     # in place: regular path (the input must be copied first)
+        dd = e.to_device(ct)
+        e.apply_galois(L, dd, 3, dkeys[0], out=dd)
+        ok &= bool((dd.download() == o.apply_galois(ct, 3, keys[0])).all())
+print("PARITY", ok)
+""" % (root, root)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_QUARTER": quarter}, capture_output=True,
+                       text=True, timeout=900)
+    assert "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
