@@ -8,7 +8,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libhefx.so")
 SOURCES = ["hefx_kernels.hip", "hefx_keyswitch.hip", "hefx_encode.hip", "hefx_sample.hip", "hefx_capi.cpp"]
-DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cuh", "../../include/hefx.h"]
+DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cuh", "../../include/hefx.h"]  # a change in any of them rebuilds
 
 
 def hipcc() -> str:

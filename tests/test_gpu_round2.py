@@ -533,3 +533,37 @@ print("PARITY", ok)
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_QUARTER": quarter}, capture_output=True,
                        text=True, timeout=900)
     assert "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
+
+
+def test_python_composition_on_the_gpu_equals_the_native_one_call_paths():
+    """algorithms.linear_transform_plain / the sparse double-hoisted transform prefer a native one-call C-ABI entry when the
+    backend has one; the oracle twin always takes the Python composition.  Here the composition itself runs ON THE GPU
+    (the backend's native entries hidden) and must give the bits of the native call and of the twin."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from tests.test_gpu_composites import make, bits, decode
+    rng = np.random.default_rng(21)
+    d = 9
+    M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
+
+    class Hidden:  # the GPU backend without its one-call linear transform
+        def __init__(self, be):
+            self._be = be
+
+        def __getattr__(self, name):
+            if name in ("linear_transform_plain", "linear_transform_plain_bsgs", "linear_transform_plain_hoisted2_sparse"):
+                raise AttributeError(name)
+            return getattr(self._be, name)
+
+    out = {}
+    for kind in ("gpu", "gpu-composition", "oracle"):
+        e = make(8192, [60, 40, 40, 60], "oracle" if kind == "oracle" else "gpu", seed=9)
+        if kind == "gpu-composition":
+            e["ev"].be = Hidden(e["ev"].be)
+        scale = 2.0 ** 40
+        diags = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+        ct = e["enc"].encrypt(e["encoder"].encode(v, scale))
+        out[kind] = (e, alg.linear_transform_plain(e["ev"], ct, diags, e["gk"]))
+    ref = bits(*out["oracle"])
+    assert (bits(*out["gpu"]) == ref).all()
+    assert (bits(*out["gpu-composition"]) == ref).all()
+    assert np.allclose(decode(*out["gpu-composition"], d), M @ v, atol=1e-4)
