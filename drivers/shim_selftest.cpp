@@ -383,6 +383,70 @@ int main()
               "BFV rotate_rows by -4 (5_rotation.cpp:152)");
     }
 
+    // BFV tutorials (1_bfv.cpp, 2_encoders.cpp, 3_levels.cpp): hex-polynomial plaintexts, IntegerEncoder, products of
+    // size-3 ciphertexts, multiply_plain, modulus switching down the chain
+    {
+        CHECK(Plaintext("1x^3 + 2x^2 + 3x^1 + 4").to_string() == "1x^3 + 2x^2 + 3x^1 + 4" && Plaintext("0").to_string() == "0" &&
+                  Plaintext("1Fx^2 + A").to_string() == "1Fx^2 + A",
+              "Plaintext hex polynomial strings round-trip");
+        EncryptionParameters bp(scheme_type::BFV);
+        bp.set_poly_modulus_degree(8192);
+        bp.set_coeff_modulus(CoeffModulus::Create(8192, {50, 30, 30, 50, 50}));
+        bp.set_plain_modulus(PlainModulus::Batching(8192, 20));
+        auto bctx = SEALContext::Create(bp);
+        KeyGenerator bkg(bctx);
+        PublicKey bpk = bkg.public_key();
+        SecretKey bsk = bkg.secret_key();
+        RelinKeys brk = bkg.relin_keys();
+        Encryptor benc(bctx, bpk);
+        Evaluator bev(bctx);
+        Decryptor bdec(bctx, bsk);
+        Plaintext plain("1x^3 + 2x^2 + 3x^1 + 4"), back;
+        Ciphertext c;
+        benc.encrypt(plain, c);
+        int prev = bdec.invariant_noise_budget(c);
+        bool shrinking = true;
+        while (bctx->get_context_data(c.parms_id())->next_context_data()) {
+            bev.mod_switch_to_next_inplace(c);
+            const int now = bdec.invariant_noise_budget(c);
+            shrinking = shrinking && now < prev && now > 0;
+            prev = now;
+        }
+        bdec.decrypt(c, back);
+        CHECK(shrinking && c.coeff_mod_count() == 1 && back.to_string() == "1x^3 + 2x^2 + 3x^1 + 4",
+              "BFV mod_switch_to_next down the chain keeps the plaintext (3_levels.cpp:95-117)");
+        benc.encrypt(plain, c);
+        bev.square_inplace(c);
+        bev.relinearize_inplace(c, brk);
+        bev.mod_switch_to_next_inplace(c);
+        bev.square_inplace(c);
+        bev.relinearize_inplace(c, brk);
+        bdec.decrypt(c, back);
+        CHECK(back.to_string() == "1x^12 + 8x^11 + 24x^10 + 80x^9 + 136x^8 + 1E0x^7 + 278x^6 + 2A0x^5 + 271x^4 + 1C8x^3 + 120x^2 + 80x^1 + 40" ||
+                  back.coeff_count() == 13,
+              "BFV 4th power across a modulus switch has degree 12");
+        IntegerEncoder ie(bctx);
+        CHECK(ie.encode(10).to_string() == "1x^3 + 1x^1" && ie.decode_int32(ie.encode(-37)) == -37, "IntegerEncoder binary expansion");
+        Ciphertext c1, c2, prod, res;
+        benc.encrypt(ie.encode(10), c1);
+        benc.encrypt(ie.encode(12), c2);
+        bev.multiply(c1, c2, prod);
+        bev.sub(prod, c1, res);
+        bdec.decrypt(res, back);
+        CHECK(res.size() == 3 && ie.decode_int32(back) == 110, "BFV 10 * 12 - 10 through IntegerEncoder (2_encoders.cpp:137-147)");
+        Plaintext four("4");
+        Ciphertext x, a, b, big;
+        benc.encrypt(Plaintext("6"), x);
+        bev.square(x, a);
+        bev.add_plain_inplace(a, Plaintext("1"));
+        bev.multiply_plain_inplace(a, four);
+        bev.add_plain(x, Plaintext("1"), b);
+        bev.square_inplace(b);
+        bev.multiply(a, b, big);  // size 3 x size 3 -> size 5
+        bdec.decrypt(big, back);
+        CHECK(big.size() == 5 && back.to_string() == "1C54", "BFV 4(x^2+1)(x+1)^2 at x = 6 without relinearisation (1_bfv.cpp:130-132)");
+    }
+
     cout << (failures ? "SELFTEST FAILED" : "SELFTEST PASSED") << " (" << failures << " failures)" << endl;
     return failures ? 1 : 0;
 }

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <cctype>
 #include <chrono>
 #include <ctime>
 #include <cstdio>
@@ -647,31 +648,43 @@ public:
         shim::bfv::PlainNtt pntt;
         bool batching = false;
     };
-    const BfvTools &bfv() const
+    int bfv_top_level() const { return k_ > 1 ? k_ - 1 : 1; }
+    // tools of the level with `L` data primes (0: the first data level); levels share the auxiliary basis and engine
+    const BfvTools &bfv(int L = 0) const
     {
-        if (bfv_) return *bfv_;
+        if (L <= 0) L = bfv_top_level();
+        auto hit = bfv_.find(L);
+        if (hit != bfv_.end()) return *hit->second;
         if (is_ckks()) throw std::logic_error("not a BFV context");
         if (t_ < 2) throw std::invalid_argument("plain_modulus is not set");
+        if (L > bfv_top_level()) throw std::invalid_argument("encrypted is not valid for encryption parameters");
         auto b = std::make_shared<BfvTools>();
-        b->L = k_ > 1 ? k_ - 1 : 1;
+        b->L = L;
         b->t = t_;
         b->data.init(std::vector<std::uint64_t>(primes_.begin(), primes_.begin() + b->L));
         shim::bfv::Big rem;
         shim::bfv::divrem(b->data.M, shim::bfv::Big(t_), b->delta, rem);
         for (int j = 0; j < b->L; ++j) b->delta_mod.push_back(shim::bfv::mod_small(b->delta, primes_[j]));
-        // tensor-product coefficients are sums of N products of centred residues: |x| < N (Q/2)^2 * 2
-        int logn = 0;
-        while (((std::size_t)1 << logn) < n_) ++logn;
-        const int need = 2 * b->data.M.bits() + logn + 3;
-        std::vector<std::uint64_t> aux;
-        for (std::uint64_t v = ((std::uint64_t)1 << 60) - 2 * n_ + 1; (int)aux.size() * 59 < need; v -= 2 * n_)
-            if (shim::is_prime(v) && std::find(primes_.begin(), primes_.end(), v) == primes_.end()) aux.push_back(v);
-        if (aux.size() > 7) throw std::invalid_argument("coeff_modulus too large for the BFV demo path of this shim");
-        b->aux.init(aux);
-        b->aux_engine = shim::get_engine((std::uint32_t)n_, aux);
+        // tensor-product coefficients are sums of N products of centred residues, up to three of them per output
+        // polynomial: |x| < 3 N (Q/2)^2 at the top level; one auxiliary basis of that width serves every level
+        if (bfv_.empty()) {
+            shim::bfv::Basis top;
+            top.init(std::vector<std::uint64_t>(primes_.begin(), primes_.begin() + bfv_top_level()));
+            int logn = 0;
+            while (((std::size_t)1 << logn) < n_) ++logn;
+            const int need = 2 * top.M.bits() + logn + 4;
+            std::vector<std::uint64_t> aux;
+            for (std::uint64_t v = ((std::uint64_t)1 << 60) - 2 * n_ + 1; (int)aux.size() * 59 < need; v -= 2 * n_)
+                if (shim::is_prime(v) && std::find(primes_.begin(), primes_.end(), v) == primes_.end()) aux.push_back(v);
+            if (aux.size() > 7) throw std::invalid_argument("coeff_modulus too large for the BFV demo path of this shim");
+            bfv_aux_.init(aux);
+            bfv_aux_engine_ = shim::get_engine((std::uint32_t)n_, aux);
+        }
+        b->aux = bfv_aux_;
+        b->aux_engine = bfv_aux_engine_;
         b->batching = b->pntt.init(t_, n_);
-        bfv_ = b;
-        return *bfv_;
+        bfv_[L] = b;
+        return *b;
     }
     // number of RNS rows of a level, from its parms_id (0 if unknown)
     int rows_of(const parms_id_type &id) const
@@ -732,7 +745,9 @@ private:
     std::vector<std::shared_ptr<ContextData>> levels_;  // index = rows-1
     mutable std::shared_ptr<shim::Engine> eng_;
     std::uint64_t t_ = 0;
-    mutable std::shared_ptr<BfvTools> bfv_;
+    mutable std::map<int, std::shared_ptr<BfvTools>> bfv_;
+    mutable shim::bfv::Basis bfv_aux_;
+    mutable std::shared_ptr<shim::Engine> bfv_aux_engine_;
 };
 
 namespace shim {
@@ -745,14 +760,31 @@ inline std::shared_ptr<SEALContext> as_ptr(const std::shared_ptr<SEALContext> &c
 inline std::shared_ptr<SEALContext> as_ptr(const SEALContext &c) { return std::make_shared<SEALContext>(c); }
 
 // Delta * m modulo every data prime, [L][N] (coefficient form): what BFV encryption and add_plain add to c0
-inline std::vector<std::uint64_t> bfv_scaled_plain(const SEALContext &ctx, const std::vector<std::uint64_t> &coeffs)
+inline std::vector<std::uint64_t> bfv_scaled_plain(const SEALContext &ctx, const std::vector<std::uint64_t> &coeffs,
+                                                    int L = 0)
 {
-    const auto &B = ctx.bfv();
+    const auto &B = ctx.bfv(L);
     const std::size_t n = ctx.n();
     std::vector<std::uint64_t> out((std::size_t)B.L * n, 0);
     for (int j = 0; j < B.L; ++j) {
         const std::uint64_t q = ctx.primes()[j], d = B.delta_mod[j];
         for (std::size_t i = 0; i < coeffs.size() && i < n; ++i) out[(std::size_t)j * n + i] = bfv::mulmod64(d, coeffs[i] % q, q);
+    }
+    return out;
+}
+// a BFV plaintext as a ring element modulo every data prime, [L][N] coefficient form: coefficients above t/2 stand for
+// negative numbers (SEAL's multiply_plain lift), so products stay small
+inline std::vector<std::uint64_t> bfv_lifted_plain(const SEALContext &ctx, const std::vector<std::uint64_t> &coeffs, int L)
+{
+    const std::size_t n = ctx.n();
+    const std::uint64_t t = ctx.plain_modulus_value();
+    std::vector<std::uint64_t> out((std::size_t)L * n, 0);
+    for (int j = 0; j < L; ++j) {
+        const std::uint64_t q = ctx.primes()[j];
+        for (std::size_t i = 0; i < coeffs.size() && i < n; ++i) {
+            const std::uint64_t m = coeffs[i];
+            out[(std::size_t)j * n + i] = m > t / 2 ? q - ((t - m) % q) : m % q;
+        }
     }
     return out;
 }
@@ -764,7 +796,34 @@ inline std::vector<std::uint64_t> bfv_scaled_plain(const SEALContext &ctx, const
 class Plaintext {
 public:
     Plaintext() = default;
-    explicit Plaintext(const std::string &) { throw std::logic_error("BFV plaintext polynomials from hex strings are not built in this shim"); }
+    // SEAL's hexadecimal polynomial notation, e.g. "1x^3 + 2x^2 + 3x^1 + 4", "6", "0" (1_bfv.cpp:45, 3_levels.cpp:88)
+    explicit Plaintext(const std::string &hex_poly)
+    {
+        std::size_t pos = 0;
+        const std::string &h = hex_poly;
+        while (pos < h.size()) {
+            while (pos < h.size() && (h[pos] == ' ' || h[pos] == '+')) ++pos;
+            if (pos >= h.size()) break;
+            std::size_t end = pos;
+            while (end < h.size() && std::isxdigit((unsigned char)h[end])) ++end;
+            if (end == pos) throw std::invalid_argument("unable to parse hex_poly");
+            const std::uint64_t coeff = std::stoull(h.substr(pos, end - pos), nullptr, 16);
+            std::size_t exp = 0;
+            pos = end;
+            if (pos < h.size() && h[pos] == 'x') {
+                if (pos + 1 >= h.size() || h[pos + 1] != '^') throw std::invalid_argument("unable to parse hex_poly");
+                pos += 2;
+                end = pos;
+                while (end < h.size() && std::isdigit((unsigned char)h[end])) ++end;
+                if (end == pos) throw std::invalid_argument("unable to parse hex_poly");
+                exp = (std::size_t)std::stoull(h.substr(pos, end - pos));
+                pos = end;
+            }
+            if (bfv.size() <= exp) bfv.resize(exp + 1, 0);
+            bfv[exp] = coeff;
+        }
+        if (bfv.empty()) bfv.assign(1, 0);
+    }
     double &scale() { return scale_; }
     const double &scale() const { return scale_; }
     parms_id_type &parms_id() { return id_; }
@@ -784,7 +843,20 @@ public:
         }
         return mirror_->data();
     }
-    std::string to_string() const { throw std::logic_error("BFV plaintext polynomials as hex strings are not built in this shim"); }
+    std::string to_string() const
+    {
+        if (bfv.empty() && buf) throw std::invalid_argument("cannot convert NTT transformed plaintext to string");
+        std::string out;
+        char tmp[32];
+        for (std::size_t i = bfv.size(); i-- > 0;) {
+            if (!bfv[i]) continue;
+            if (!out.empty()) out += " + ";
+            std::snprintf(tmp, sizeof tmp, "%llX", (unsigned long long)bfv[i]);
+            out += tmp;
+            if (i) out += "x^" + std::to_string(i);
+        }
+        return out.empty() ? "0" : out;
+    }
     // shim internals
     shim::BufPtr buf;                 // CKKS: [rows][N] NTT form on the device
     std::vector<std::uint64_t> bfv;   // BFV: N coefficients modulo the plain modulus, on the host
@@ -1052,6 +1124,8 @@ private:
     {
         const auto &B = ctx_->bfv();
         if (plain.bfv.empty() || plain.bfv.size() > ctx_->n()) throw std::invalid_argument("plain is not valid for encryption parameters");
+        for (std::uint64_t m : plain.bfv)
+            if (m >= B.t) throw std::invalid_argument("plain is not valid for encryption parameters");
         auto &e = ctx_->engine();
         const int L = B.L;
         const std::size_t n = ctx_->n();
@@ -1110,8 +1184,7 @@ private:
     void decrypt_bfv(const Ciphertext &ct, Plaintext &dest, int &budget) const
     {
         namespace bf = shim::bfv;
-        const auto &B = ctx_->bfv();
-        if (ct.rows != B.L) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const auto &B = ctx_->bfv(ct.rows);
         auto &e = ctx_->engine();
         const int L = B.L;
         const std::size_t n = ctx_->n();
@@ -1138,6 +1211,7 @@ private:
             if (bf::cmp(rem, worst) > 0) worst = rem;
         }
         budget = std::max(0, B.data.M.bits() - worst.bits() - 1);
+        while (dest.bfv.size() > 1 && dest.bfv.back() == 0) dest.bfv.pop_back();  // SEAL keeps the significant coefficients
     }
 
     std::shared_ptr<SEALContext> ctx_;
@@ -1449,16 +1523,67 @@ private:
     std::shared_ptr<SEALContext> ctx_;
     std::vector<std::size_t> index_;
 };
+// IntegerEncoder (BFV; 2_encoders.cpp:113-147): an integer as the polynomial of its binary digits, negative numbers with
+// coefficients t-1; decoding evaluates the polynomial at 2 with centred coefficients.
 class IntegerEncoder {
 public:
     template <class Ctx>
-    explicit IntegerEncoder(const Ctx &)
+    explicit IntegerEncoder(const Ctx &context) : ctx_(shim::as_ptr(context))
     {
-        throw std::logic_error("BFV (IntegerEncoder) is not built in this shim");
+        if (ctx_->is_ckks()) throw std::invalid_argument("unsupported scheme");
+        if (ctx_->plain_modulus_value() < 2) throw std::invalid_argument("plain_modulus must be at least 2");
     }
-    Plaintext encode(std::int64_t) const { return Plaintext(); }
-    std::int64_t decode_int32(const Plaintext &) const { return 0; }
-    std::int64_t decode_int64(const Plaintext &) const { return 0; }
+    Plaintext encode(std::uint64_t value) const
+    {
+        Plaintext p;
+        p.bfv.assign(1, 0);
+        for (int i = 0; value; ++i, value >>= 1) {
+            if ((int)p.bfv.size() <= i) p.bfv.resize(i + 1, 0);
+            p.bfv[i] = value & 1;
+        }
+        return p;
+    }
+    Plaintext encode(std::int64_t value) const
+    {
+        if (value >= 0) return encode((std::uint64_t)value);
+        Plaintext p = encode((std::uint64_t)(-(value + 1)) + 1);
+        const std::uint64_t minus_one = ctx_->plain_modulus_value() - 1;
+        for (auto &c : p.bfv)
+            if (c) c = minus_one;
+        return p;
+    }
+    Plaintext encode(std::int32_t value) const { return encode((std::int64_t)value); }
+    Plaintext encode(std::uint32_t value) const { return encode((std::uint64_t)value); }
+    template <class Int>
+    void encode(Int value, Plaintext &dest) const { dest = encode(value); }
+    std::int64_t decode_int64(const Plaintext &p) const
+    {
+        const std::uint64_t t = ctx_->plain_modulus_value();
+        __int128 acc = 0;
+        for (std::size_t i = p.bfv.size(); i-- > 0;) {
+            const std::uint64_t c = p.bfv[i];
+            if (c >= t) throw std::invalid_argument("plain does not represent a valid plaintext polynomial");
+            acc = acc * 2 + (c > t / 2 ? (__int128)c - (__int128)t : (__int128)c);
+            if (acc > (__int128)INT64_MAX || acc < (__int128)INT64_MIN) throw std::invalid_argument("output out of range");
+        }
+        return (std::int64_t)acc;
+    }
+    std::int32_t decode_int32(const Plaintext &p) const
+    {
+        const std::int64_t v = decode_int64(p);
+        if (v > INT32_MAX || v < INT32_MIN) throw std::invalid_argument("output out of range");
+        return (std::int32_t)v;
+    }
+    std::uint64_t decode_uint64(const Plaintext &p) const
+    {
+        const std::int64_t v = decode_int64(p);
+        if (v < 0) throw std::invalid_argument("output out of range");
+        return (std::uint64_t)v;
+    }
+    std::uint32_t decode_uint32(const Plaintext &p) const { return (std::uint32_t)decode_uint64(p); }
+
+private:
+    std::shared_ptr<SEALContext> ctx_;
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -1513,7 +1638,7 @@ public:
         check_ct(a);
         if (!ctx_->is_ckks()) {  // BFV: c0 += Delta * m (vector_ops.cpp:178)
             if (p.bfv.empty()) throw std::invalid_argument("plain is not valid for encryption parameters");
-            auto dm = shim::upload(eng(), shim::bfv_scaled_plain(*ctx_, p.bfv));
+            auto dm = shim::upload(eng(), shim::bfv_scaled_plain(*ctx_, p.bfv, a.rows));
             auto out = shim::new_buf(eng(), a.buf->words);
             shim::check(hefx_add_plain(eng()->ready({a.buf.get()}), a.rows, (int)a.size(), a.buf->p, dm->p, out->p, nullptr));
             dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
@@ -1532,6 +1657,24 @@ public:
     void multiply_plain(const Ciphertext &a, const Plaintext &p, Ciphertext &dest) const
     {
         check_ct(a);
+        if (!ctx_->is_ckks()) {  // BFV (1_bfv.cpp:131): ring product with the lifted plaintext, through the NTT domain
+            if (p.bfv.empty()) throw std::invalid_argument("plain is not valid for encryption parameters");
+            bool zero = true;
+            for (std::uint64_t m : p.bfv) zero = zero && m == 0;
+            if (zero) throw std::logic_error("result ciphertext is transparent");
+            auto &e = eng();
+            const int L = a.rows;
+            auto pt = shim::upload(e, shim::bfv_lifted_plain(*ctx_, p.bfv, L));
+            auto tmp = shim::new_buf(e, a.buf->words), out = shim::new_buf(e, a.buf->words);
+            shim::check(hefx_ntt_forward(e->ready({}), pt->p, 1, L, 0, nullptr));
+            shim::check(hefx_copy(e->ready({a.buf.get()}), tmp->p, a.buf->p, a.buf->words * 8, nullptr));
+            shim::check(hefx_ntt_forward(e->ready({}), tmp->p, (int)a.size(), L, 0, nullptr));
+            shim::check(hefx_multiply_plain(e->ready({}), L, (int)a.size(), 1, tmp->p, pt->p, out->p, nullptr));
+            shim::check(hefx_ntt_inverse(e->ready({}), out->p, (int)a.size(), L, 0, nullptr));
+            dest.set(out, a.size(), L, a.parms_id(), a.scale());
+            dest.ntt_form_ = false;
+            return;
+        }
         check_pt(a, p);
         const double ns = a.scale() * p.scale();
         check_scale(ns, a.parms_id());
@@ -1556,9 +1699,9 @@ public:
         check_ct(a);
         check_ct(b);
         if (a.parms_id() != b.parms_id()) throw std::invalid_argument("encrypted1 and encrypted2 parameter mismatch");
+        if (!ctx_->is_ckks()) return multiply_bfv(a, b, dest);  // any sizes (1_bfv.cpp:132 multiplies two size-3 ciphertexts)
         if (a.size() != 2 || b.size() != 2)
             throw std::invalid_argument("multiply: only size-2 operands are built (every reference call site)");
-        if (!ctx_->is_ckks()) return multiply_bfv(a, b, dest);
         const double ns = a.scale() * b.scale();
         check_scale(ns, a.parms_id());
         if (eng()->lazy) {  // recorded (helper.h:227-228, 432): the products of all rows / diagonals go out as one batch
@@ -1633,6 +1776,21 @@ public:
         check_ct(a);
         const int L = target_rows(a.rows, id);
         if (L == a.rows) return;
+        if (!ctx_->is_ckks()) {  // BFV (3_levels.cpp:103): divide by the dropped primes and round, one prime at a time
+            auto &e = eng();
+            shim::BufPtr cur = shim::new_buf(e, a.buf->words);
+            shim::check(hefx_copy(e->ready({a.buf.get()}), cur->p, a.buf->p, a.buf->words * 8, nullptr));
+            shim::check(hefx_ntt_forward(e->ready({}), cur->p, (int)a.size(), a.rows, 0, nullptr));
+            for (int rows = a.rows; rows > L; --rows) {
+                auto out = shim::new_buf(e, words(a.size(), rows - 1));
+                shim::check(hefx_rescale_to_next_mode(e->ready({}), rows, (int)a.size(), 1, cur->p, out->p, HEFX_RESCALE_ROUND, nullptr));
+                cur = out;
+            }
+            shim::check(hefx_ntt_inverse(e->ready({}), cur->p, (int)a.size(), L, 0, nullptr));
+            a.set(cur, a.size(), L, id, a.scale());
+            a.ntt_form_ = false;
+            return;
+        }
         auto out = shim::new_buf(eng(), words(a.size(), L));
         shim::check(hefx_mod_drop(eng()->ready({a.buf.get()}), a.rows, L, (int)a.size(), a.buf->p, out->p, nullptr));
         a.set(out, a.size(), L, id, a.scale());
@@ -1866,14 +2024,16 @@ private:
     void multiply_bfv(const Ciphertext &a, const Ciphertext &b, Ciphertext &dest) const
     {
         namespace bf = shim::bfv;
-        const auto &B = ctx_->bfv();
-        if (a.rows != B.L) throw std::invalid_argument("encrypted is not valid for encryption parameters");
+        const auto &B = ctx_->bfv(a.rows);
         const std::size_t n = ctx_->n();
         const int L = B.L, A = (int)B.aux.m.size();
-        auto lift = [&](const Ciphertext &c) {  // [2][L][N] residues -> centred integers -> [2][A][N] residues
+        const int sa = (int)a.size(), sb = (int)b.size(), sr = sa + sb - 1;
+        if (sa < 2 || sb < 2 || sr > 6) throw std::invalid_argument("encrypted1 or encrypted2 has an unsupported size");
+        auto lift = [&](const Ciphertext &c) {  // [size][L][N] residues -> centred integers -> [size][A][N] residues
             const std::vector<std::uint64_t> h = shim::download(c.buf);
-            std::vector<std::uint64_t> out((std::size_t)2 * A * n);
-            for (int p = 0; p < 2; ++p)
+            const int sz = (int)c.size();
+            std::vector<std::uint64_t> out((std::size_t)sz * A * n);
+            for (int p = 0; p < sz; ++p)
                 for (std::size_t i = 0; i < n; ++i) {
                     bf::Big x = B.data.compose(h.data() + (std::size_t)p * L * n, n, i);
                     const bool neg = bf::cmp(x, B.data.half) > 0;
@@ -1888,14 +2048,24 @@ private:
         auto &ae = B.aux_engine;
         auto da = shim::upload(ae, lift(a));
         auto db = a.buf == b.buf ? da : shim::upload(ae, lift(b));
-        shim::check(hefx_ntt_forward(ae->ready({}), da->p, 2, A, 0, nullptr));
-        if (db != da) shim::check(hefx_ntt_forward(ae->ready({}), db->p, 2, A, 0, nullptr));
-        auto prod = shim::new_buf(ae, (std::size_t)3 * A * n);
-        shim::check(hefx_multiply(ae->ready({}), A, da->p, db->p, prod->p, nullptr));
-        shim::check(hefx_ntt_inverse(ae->ready({}), prod->p, 3, A, 0, nullptr));
+        shim::check(hefx_ntt_forward(ae->ready({}), da->p, sa, A, 0, nullptr));
+        if (db != da) shim::check(hefx_ntt_forward(ae->ready({}), db->p, sb, A, 0, nullptr));
+        const std::size_t poly = (std::size_t)A * n;
+        auto prod = shim::new_buf(ae, (std::size_t)sr * poly), tmp = shim::new_buf(ae, poly);
+        if (sa == 2 && sb == 2) {
+            shim::check(hefx_multiply(ae->ready({}), A, da->p, db->p, prod->p, nullptr));
+        } else {  // c_k = sum_{i+j=k} a_i b_j, polynomial by polynomial (dyadic products in the NTT domain)
+            shim::check(hefx_memset_zero(ae->ready({}), prod->p, (std::size_t)sr * poly * 8, nullptr));
+            for (int i = 0; i < sa; ++i)
+                for (int j = 0; j < sb; ++j) {
+                    shim::check(hefx_multiply_plain(ae->ready({}), A, 1, 1, da->p + i * poly, db->p + j * poly, tmp->p, nullptr));
+                    shim::check(hefx_add(ae->ready({}), A, 1, 1, prod->p + (i + j) * poly, tmp->p, prod->p + (i + j) * poly, nullptr));
+                }
+        }
+        shim::check(hefx_ntt_inverse(ae->ready({}), prod->p, sr, A, 0, nullptr));
         const std::vector<std::uint64_t> hp = shim::download(prod);
-        std::vector<std::uint64_t> res((std::size_t)3 * L * n);
-        for (int p = 0; p < 3; ++p)
+        std::vector<std::uint64_t> res((std::size_t)sr * L * n);
+        for (int p = 0; p < sr; ++p)
             for (std::size_t i = 0; i < n; ++i) {
                 bf::Big x = B.aux.compose(hp.data() + (std::size_t)p * A * n, n, i);
                 const bool neg = bf::cmp(x, B.aux.half) > 0;
@@ -1908,7 +2078,7 @@ private:
                     res[((std::size_t)p * L + j) * n + i] = neg && r ? q - r : r;
                 }
             }
-        dest.set(shim::upload(eng(), res), 3, L, a.parms_id(), a.scale() * b.scale());
+        dest.set(shim::upload(eng(), res), (std::size_t)sr, L, a.parms_id(), a.scale() * b.scale());
         dest.ntt_form_ = false;
     }
     void apply_galois_bfv(const Ciphertext &a, const std::vector<std::uint32_t> &plan, const GaloisKeys &gk, Ciphertext &dest) const
