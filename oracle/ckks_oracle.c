@@ -14,6 +14,7 @@
 #include "ckks_oracle.h"
 
 #include <assert.h>
+#include <malloc.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -211,6 +212,12 @@ static inline uint64_t shoup(uint64_t w, uint64_t q) { return (uint64_t)(((u128)
 orc_ctx *orc_ctx_create(uint64_t N, const uint64_t *primes, int k)
 {
     if (N < 4 || (N & (N - 1))) return NULL;
+    /* Every evaluator function takes its multi-MB temporaries from malloc, as SEAL takes them from its MemoryPool.  By
+     * default glibc serves blocks above 128 KiB with mmap / munmap -- a page-zeroing system call pair per temporary that
+     * serialises all threads of the many-core CPU baseline (bench.py cpu_baseline) on the address-space lock.  Keep such
+     * blocks in the per-thread arenas instead, so the baseline measures arithmetic, not the allocator. */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
     orc_ctx *c = (orc_ctx *)calloc(1, sizeof *c);
     c->N = N;
     c->k = k;
