@@ -31,8 +31,11 @@ def build(force: bool = False, verbose: bool = False) -> str:
     objs = []
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
-        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-x", "hip", "-c",
-               os.path.join(CSRC, src), "-o", obj]
+        # -pragma-unroll-threshold: the transforms are written as fully unrolled loops over register arrays; the inline
+        # asm statements of hefx_modarith.cuh count as large in the unroller's size estimate and push the inverse
+        # transforms past the default threshold (loops left rolled -> the register arrays go to scratch memory)
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-mllvm", "-pragma-unroll-threshold=1048576", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)

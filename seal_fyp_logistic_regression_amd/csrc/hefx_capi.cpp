@@ -318,7 +318,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         m.ninv_s = h_shoup(m.ninv, q);
         m.ilw = h_mulmod(itw[(size_t)j * n + 1].x, m.ninv, q);
         m.ilw_s = h_shoup(m.ilw, q);
-        m.pad = 0;
+        m.nq = 0 - q;
         // FP64 policy (exact FMA modmul) for primes below 2^41; HEFX_NO_FP64=1 forces the integer policy
         ModConstF &f = modsf[j];
         memset(&f, 0, sizeof f);

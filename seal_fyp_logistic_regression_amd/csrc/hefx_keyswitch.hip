@@ -193,16 +193,17 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
-    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+    // MAC-operand format: canonical words for the integer-policy moduli, unfinished doubles for the FP64 ones
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
     // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
     if (stream_x) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], xd + C::idx_out(t, r));
+        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], xd + C::idx_io(t, r));
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xd[C::idx_out(t, r)] = v[r];
+        for (int r = 0; r < 16; ++r) xd[C::idx_io(t, r)] = v[r];
     }
 }
 
@@ -213,53 +214,212 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
 // instead of 6 (measured 244 -> 218 us per 192-item chunk, ~4.8 TB/s of HBM traffic; sharing across four items at
 // 96 VGPRs was no faster).  Items with different keys take the one-item path.
 // ------------------------------------------------------------------------------------------------
-struct MacAcc {
+// MAC arithmetic, one policy per target modulus (uniform per workgroup).  Each accumulates sum_i x_i * k_i for the two
+// key polynomials (k0, k1) and two adjacent coefficients (.x, .y); the instruction count is what matters -- under the
+// two-stream overlap the whole key switch is VALU-issue bound, and the 128-bit form below was a quarter of all VALU
+// instructions of the operation (SQ_INSTS_VALU, round 2):
+//   MacF  FP64-policy moduli (q < 2^41).  Scratch x holds the UNFINISHED transform value as a double (|x| < 2^45,
+//         hefx_ntt.cuh: no canonicalisation in the digit NTTs either); x*k mod q is the exact 6-instruction FP64 modmul
+//         with a result in (-0.52q, 0.52q), the L results add exactly, one canonicalisation at the end.
+//   MacL  q < 2^60 and L <= 8: 30-bit limbs, x = x1*2^30 + x0, k = k1*2^30 + k0, every partial product < 2^60, so the
+//         three column sums (x0k0 | x0k1 + x1k0 | x1k1) take up to 16 terms in plain v_mad_u64_u32 accumulators with no
+//         carry handling; the columns are put together into 128 bits once, then one Barrett reduction.
+//   MacW  anything wider: full 128-bit accumulators (the generic form).
+// All three deliver the canonical residue of the same integer sum: bit-identical results.
+struct MacW {
+    struct Ctx {
+        ModConst mc;
+    };
+    __device__ static __forceinline__ Ctx make(const ModConst &mc, const ModConstF &) { return Ctx{mc}; }
+    typedef ulonglong2 X;
+    struct K {
+        ulonglong2 k0, k1;
+    };
+    __device__ static __forceinline__ X xin(const ulonglong2 &bits, bool, const Ctx &) { return bits; }
+    __device__ static __forceinline__ K kin(const ulonglong2 &k0, const ulonglong2 &k1, const Ctx &) { return K{k0, k1}; }
     u64 a0xl = 0, a0xh = 0, a0yl = 0, a0yh = 0, a1xl = 0, a1xh = 0, a1yl = 0, a1yh = 0;
-    __device__ __forceinline__ void mac(const ulonglong2 &x, const ulonglong2 &k0, const ulonglong2 &k1)
+    __device__ __forceinline__ void mac(const X &x, const K &k, const Ctx &)
     {
-        mac128(a0xl, a0xh, x.x, k0.x);
-        mac128(a0yl, a0yh, x.y, k0.y);
-        mac128(a1xl, a1xh, x.x, k1.x);
-        mac128(a1yl, a1yh, x.y, k1.y);
+        mac128(a0xl, a0xh, x.x, k.k0.x);
+        mac128(a0yl, a0yh, x.y, k.k0.y);
+        mac128(a1xl, a1xh, x.x, k.k1.x);
+        mac128(a1yl, a1yh, x.y, k.k1.y);
     }
-    template <bool STREAM = false>
-    __device__ __forceinline__ void store(u64 *acc0, u64 *acc1, size_t w, const ModConst &mc) const
+    // this += inner * (dg.x, dg.y): the diagonal product of the double-hoisted transform
+    __device__ __forceinline__ void mac_diag(const MacW &in, const ulonglong2 &dg, const Ctx &c)
     {
         ulonglong2 r0, r1;
-        r0.x = barrett128(a0xl, a0xh, mc);
-        r0.y = barrett128(a0yl, a0yh, mc);
-        r1.x = barrett128(a1xl, a1xh, mc);
-        r1.y = barrett128(a1yl, a1yh, mc);
-        if (STREAM) {
-            __builtin_nontemporal_store(r0.x, acc0 + 2 * w);
-            __builtin_nontemporal_store(r0.y, acc0 + 2 * w + 1);
-            __builtin_nontemporal_store(r1.x, acc1 + 2 * w);
-            __builtin_nontemporal_store(r1.y, acc1 + 2 * w + 1);
-        } else {
-            reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
-            reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
-        }
+        in.result(r0, r1, c);
+        mac128(a0xl, a0xh, r0.x, dg.x);
+        mac128(a0yl, a0yh, r0.y, dg.y);
+        mac128(a1xl, a1xh, r1.x, dg.x);
+        mac128(a1yl, a1yh, r1.y, dg.y);
+    }
+    __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
+    {
+        r0.x = barrett128(a0xl, a0xh, c.mc);
+        r0.y = barrett128(a0yl, a0yh, c.mc);
+        r1.x = barrett128(a1xl, a1xh, c.mc);
+        r1.y = barrett128(a1yl, a1yh, c.mc);
     }
 };
 
-// NI consecutive items (bl .. bl+NI-1) that share `key`; xload(bl, i, w) = record w of digit i's row for this modulus
-template <int NI, bool STREAM, class XL, class AR>
-__device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, int L, int m, size_t n, size_t w, int bl,
-                                          const ModConst &mc, const XL &xload, const AR &accrow)
+struct MacL {
+    typedef MacW::Ctx Ctx;
+    __device__ static __forceinline__ Ctx make(const ModConst &mc, const ModConstF &) { return Ctx{mc}; }
+    struct X {
+        uint32_t xl, xh, yl, yh;
+    };
+    struct K {
+        uint32_t k0xl, k0xh, k0yl, k0yh, k1xl, k1xh, k1yl, k1yh;
+    };
+    __device__ static __forceinline__ uint32_t lo30(u64 v) { return (uint32_t)v & 0x3FFFFFFFu; }
+    __device__ static __forceinline__ uint32_t hi30(u64 v) { return (uint32_t)(v >> 30); }
+    __device__ static __forceinline__ X xin(const ulonglong2 &b, bool, const Ctx &)
+    {
+        return X{lo30(b.x), hi30(b.x), lo30(b.y), hi30(b.y)};
+    }
+    __device__ static __forceinline__ K kin(const ulonglong2 &k0, const ulonglong2 &k1, const Ctx &)
+    {
+        return K{lo30(k0.x), hi30(k0.x), lo30(k0.y), hi30(k0.y), lo30(k1.x), hi30(k1.x), lo30(k1.y), hi30(k1.y)};
+    }
+    u64 c[4][3] = {};  // [a0x, a0y, a1x, a1y][column]
+    __device__ static __forceinline__ void mad(u64 (&col)[3], uint32_t xl, uint32_t xh, uint32_t kl, uint32_t kh)
+    {
+        col[0] += (u64)xl * kl;
+        col[1] += (u64)xl * kh;
+        col[1] += (u64)xh * kl;
+        col[2] += (u64)xh * kh;
+    }
+    __device__ __forceinline__ void mac(const X &x, const K &k, const Ctx &)
+    {
+        mad(c[0], x.xl, x.xh, k.k0xl, k.k0xh);
+        mad(c[1], x.yl, x.yh, k.k0yl, k.k0yh);
+        mad(c[2], x.xl, x.xh, k.k1xl, k.k1xh);
+        mad(c[3], x.yl, x.yh, k.k1yl, k.k1yh);
+    }
+    __device__ __forceinline__ void mac_diag(const MacL &in, const ulonglong2 &dg, const Ctx &cx)
+    {
+        ulonglong2 r0, r1;
+        in.result(r0, r1, cx);
+        const uint32_t dxl = lo30(dg.x), dxh = hi30(dg.x), dyl = lo30(dg.y), dyh = hi30(dg.y);
+        mad(c[0], lo30(r0.x), hi30(r0.x), dxl, dxh);
+        mad(c[1], lo30(r0.y), hi30(r0.y), dyl, dyh);
+        mad(c[2], lo30(r1.x), hi30(r1.x), dxl, dxh);
+        mad(c[3], lo30(r1.y), hi30(r1.y), dyl, dyh);
+    }
+    __device__ static __forceinline__ u64 fold(const u64 (&col)[3], const ModConst &mc)
+    {
+        u64 lo = col[0], hi = 0, t = col[1] << 30;
+        lo += t;
+        hi += (col[1] >> 34) + (lo < t);
+        t = col[2] << 60;
+        lo += t;
+        hi += (col[2] >> 4) + (lo < t);
+        return barrett128(lo, hi, mc);
+    }
+    __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &cx) const
+    {
+        r0.x = fold(c[0], cx.mc);
+        r0.y = fold(c[1], cx.mc);
+        r1.x = fold(c[2], cx.mc);
+        r1.y = fold(c[3], cx.mc);
+    }
+};
+
+struct MacF {
+    typedef ArithF64::Ctx Ctx;
+    __device__ static __forceinline__ Ctx make(const ModConst &, const ModConstF &mf) { return ArithF64::make(mf); }
+    typedef double2 X;
+    struct K {
+        double k0x, k0y, k1x, k1y;
+    };
+    // own: the digit's own prime -- canonical words of the source ciphertext instead of scratch doubles
+    __device__ static __forceinline__ X xin(const ulonglong2 &b, bool own, const Ctx &)
+    {
+        return own ? make_double2(ArithF64::from_u64(b.x), ArithF64::from_u64(b.y))
+                   : make_double2(__longlong_as_double((long long)b.x), __longlong_as_double((long long)b.y));
+    }
+    __device__ static __forceinline__ K kin(const ulonglong2 &k0, const ulonglong2 &k1, const Ctx &)
+    {
+        return K{ArithF64::from_u64(k0.x), ArithF64::from_u64(k0.y), ArithF64::from_u64(k1.x), ArithF64::from_u64(k1.y)};
+    }
+    double a0x = 0.0, a0y = 0.0, a1x = 0.0, a1y = 0.0;
+    __device__ __forceinline__ void mac(const X &x, const K &k, const Ctx &c)
+    {
+        a0x += ArithF64::mm(x.x, k.k0x, c);
+        a0y += ArithF64::mm(x.y, k.k0y, c);
+        a1x += ArithF64::mm(x.x, k.k1x, c);
+        a1y += ArithF64::mm(x.y, k.k1y, c);
+    }
+    // |inner sums| <= L * 0.52q < 2^45 (L <= 61): valid left operands of mm as they are
+    __device__ __forceinline__ void mac_diag(const MacF &in, const ulonglong2 &dg, const Ctx &c)
+    {
+        const double dx = ArithF64::from_u64(dg.x), dy = ArithF64::from_u64(dg.y);
+        a0x += ArithF64::mm(in.a0x, dx, c);
+        a0y += ArithF64::mm(in.a0y, dy, c);
+        a1x += ArithF64::mm(in.a1x, dx, c);
+        a1y += ArithF64::mm(in.a1y, dy, c);
+    }
+    __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
+    {
+        r0.x = ArithF64::canon(a0x, c);
+        r0.y = ArithF64::canon(a0y, c);
+        r1.x = ArithF64::canon(a1x, c);
+        r1.y = ArithF64::canon(a1y, c);
+    }
+};
+
+// policy of target modulus m in a key switch over L digits (block-uniform); f(policy tag) runs the templated body
+template <class F>
+__device__ __forceinline__ void mac_dispatch(const DevTables &T, int m, int L, const F &f)
 {
-    MacAcc A[NI];
+    if (T.modsf[m].q != 0.0)
+        f(MacF());
+    else if (L <= 8 && (T.mods[m].q >> 60) == 0)
+        f(MacL());
+    else
+        f(MacW());
+}
+
+template <bool STREAM>
+__device__ __forceinline__ void mac_store(u64 *acc0, u64 *acc1, size_t w, const ulonglong2 &r0, const ulonglong2 &r1)
+{
+    if (STREAM) {
+        __builtin_nontemporal_store(r0.x, acc0 + 2 * w);
+        __builtin_nontemporal_store(r0.y, acc0 + 2 * w + 1);
+        __builtin_nontemporal_store(r1.x, acc1 + 2 * w);
+        __builtin_nontemporal_store(r1.y, acc1 + 2 * w + 1);
+    } else {
+        reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
+        reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
+    }
+}
+
+// NI consecutive items (bl .. bl+NI-1) that share `key`; xload(bl, i, w) = record w of digit i's row for this modulus
+template <class P, int NI, bool STREAM, class XL, class AR>
+__device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, int L, int jj, int m, size_t n, size_t w,
+                                          int bl, const XL &xload, const AR &accrow)
+{
+    const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
+    P A[NI];
     for (int i = 0; i < L; ++i) {
         const u64 *kbase = key + ((size_t)i * 2 * T.k + m) * n;
-        ulonglong2 x[NI];
+        ulonglong2 xb[NI];
 #pragma unroll
-        for (int e = 0; e < NI; ++e) x[e] = xload(bl + e, i, w);
+        for (int e = 0; e < NI; ++e) xb[e] = xload(bl + e, i, w);
         const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
         const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
+        const typename P::K k = P::kin(k0, k1, cx);
 #pragma unroll
-        for (int e = 0; e < NI; ++e) A[e].mac(x[e], k0, k1);
+        for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[e], i == jj, cx), k, cx);
     }
 #pragma unroll
-    for (int e = 0; e < NI; ++e) A[e].template store<STREAM>(accrow(bl + e, 0), accrow(bl + e, 1), w, mc);
+    for (int e = 0; e < NI; ++e) {
+        ulonglong2 r0, r1;
+        A[e].result(r0, r1, cx);
+        mac_store<STREAM>(accrow(bl + e, 0), accrow(bl + e, 1), w, r0, r1);
+    }
 }
 
 template <bool STREAM>
@@ -270,7 +430,6 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
     const size_t n = (size_t)1 << logn;
     const int jj = blockIdx.y, bl0 = 2 * blockIdx.z;
     const int m = jj < L ? jj : T.k - 1;
-    const ModConst mc = T.mods[m];
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
     // digit i in slot jj: its transform to that modulus from scratch x -- or, for its own prime (i == jj), the
     // Galois-permuted input row itself, gathered from the source ciphertext
@@ -292,12 +451,15 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
     auto accrow = [&](int bl, int c) { return S.acc + (((size_t)(item0 + bl) * 2 + c) * (L + 1) + jj) * n; };
     const u64 *k0 = items[item0 + bl0].key;
     const u64 *k1 = bl0 + 1 < count ? items[item0 + bl0 + 1].key : nullptr;
-    if (k1 == k0) {
-        mac_items<2, STREAM>(T, k0, L, m, n, w, bl0, mc, xload, accrow);
-    } else {
-        mac_items<1, STREAM>(T, k0, L, m, n, w, bl0, mc, xload, accrow);
-        if (k1) mac_items<1, STREAM>(T, k1, L, m, n, w, bl0 + 1, mc, xload, accrow);
-    }
+    mac_dispatch(T, m, L, [&](auto pol) {
+        using P = decltype(pol);
+        if (k1 == k0) {
+            mac_items<P, 2, STREAM>(T, k0, L, jj, m, n, w, bl0, xload, accrow);
+        } else {
+            mac_items<P, 1, STREAM>(T, k0, L, jj, m, n, w, bl0, xload, accrow);
+            if (k1) mac_items<P, 1, STREAM>(T, k1, L, jj, m, n, w, bl0 + 1, xload, accrow);
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -313,30 +475,44 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
 // mod-down remain ((L+1)(L+2) -> 2 + 2L transforms).  The gathered rows are L2-resident (one source), the keys stream
 // from HBM.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const KsItem *__restrict__ items, int L,
-                                                             KsScratch S)
+// sum over the digits of one rotation `it`, gathered through its table: the inner loop of both hoisted forms
+template <class P>
+__device__ __forceinline__ void mac_gathered(P &A, const typename P::Ctx &cx, const DevTables &T, const KsItem &it,
+                                             const u64 *__restrict__ c1, const KsScratch &S, int L, int jj, int m,
+                                             size_t n, size_t w)
 {
-    const int logn = T.logn;
-    const size_t n = (size_t)1 << logn;
-    const int jj = blockIdx.y, b = blockIdx.z;
-    const int m = jj < L ? jj : T.k - 1;
-    const ModConst mc = T.mods[m];
-    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
-    const KsItem it = items[b];
     const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
-    const u64 *__restrict__ c1 = it.c_in + (size_t)L * n;  // the shared source's c1: digit i in NTT form mod its own prime
-    MacAcc A;
     for (int i = 0; i < L; ++i) {
         const u64 *__restrict__ xrow = i == jj ? c1 + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
-        ulonglong2 x;
-        x.x = xrow[pi.x];
-        x.y = xrow[pi.y];
+        ulonglong2 xb;
+        xb.x = xrow[pi.x];
+        xb.y = xrow[pi.y];
         const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
         const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
         const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
-        A.mac(x, k0, k1);
+        A.mac(P::xin(xb, i == jj, cx), P::kin(k0, k1, cx), cx);
     }
-    A.store(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n, w, mc);
+}
+
+__global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const KsItem *__restrict__ items, int L,
+                                                             KsScratch S)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const int jj = blockIdx.y, b = blockIdx.z;
+    const int m = jj < L ? jj : T.k - 1;
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
+    const KsItem it = items[b];
+    mac_dispatch(T, m, L, [&](auto pol) {
+        using P = decltype(pol);
+        const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
+        P A;
+        // the shared source's c1: digit i in NTT form mod its own prime
+        mac_gathered(A, cx, T, it, it.c_in + (size_t)L * n, S, L, jj, m, n, w);
+        ulonglong2 r0, r1;
+        A.result(r0, r1, cx);
+        mac_store<false>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n,
+                         w, r0, r1);
+    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -351,46 +527,32 @@ __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const 
 // algorithm.  The diagonals must be encoded over the special prime too (key-level plaintexts); top data level only.
 // Workgroups own a chunk of LT2_CHUNK rotations and write partial sums that a wide add_many reduces.
 // ------------------------------------------------------------------------------------------------
-constexpr int LT2_CHUNK = 8;
+constexpr int LT2_CHUNK = 8;  // <= 8: the limb policy's middle column takes two terms per rotation, sixteen in all
 
 __global__ __launch_bounds__(256) void lt2_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int nrot,
                                                       KsScratch S, const u64 *__restrict__ src_c1 /* [L][N] */,
                                                       u64 *__restrict__ partial /* [chunks][2][L+1][N] */)
 {
-    const int logn = T.logn;
-    const size_t n = (size_t)1 << logn;
+    const size_t n = (size_t)1 << T.logn;
     const int jj = blockIdx.y, ch = blockIdx.z;
     const int m = jj < L ? jj : T.k - 1;
-    const ModConst mc = T.mods[m];
     const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    MacAcc tot;
     const int l0 = ch * LT2_CHUNK, l1 = l0 + LT2_CHUNK < nrot ? l0 + LT2_CHUNK : nrot;
-    for (int l = l0; l < l1; ++l) {
-        const KsItem it = items[l];
-        const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
-        MacAcc A;
-        for (int i = 0; i < L; ++i) {
-            const u64 *__restrict__ xrow = i == jj ? src_c1 + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
-            ulonglong2 x;
-            x.x = xrow[pi.x];
-            x.y = xrow[pi.y];
-            const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
-            A.mac(x, reinterpret_cast<const ulonglong2 *>(kbase)[w],
-                  reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w]);
+    mac_dispatch(T, m, L, [&](auto pol) {
+        using P = decltype(pol);
+        const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
+        P tot;
+        for (int l = l0; l < l1; ++l) {
+            const KsItem it = items[l];
+            P A;
+            mac_gathered(A, cx, T, it, src_c1, S, L, jj, m, n, w);
+            tot.mac_diag(A, reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)m * n)[w], cx);  // key-level plaintext row m
         }
         ulonglong2 r0, r1;
-        r0.x = barrett128(A.a0xl, A.a0xh, mc);
-        r0.y = barrett128(A.a0yl, A.a0yh, mc);
-        r1.x = barrett128(A.a1xl, A.a1xh, mc);
-        r1.y = barrett128(A.a1yl, A.a1yh, mc);
-        const ulonglong2 dg = reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)m * n)[w];  // key-level plaintext row m
-        mac128(tot.a0xl, tot.a0xh, r0.x, dg.x);
-        mac128(tot.a0yl, tot.a0yh, r0.y, dg.y);
-        mac128(tot.a1xl, tot.a1xh, r1.x, dg.x);
-        mac128(tot.a1yl, tot.a1yh, r1.y, dg.y);
-    }
-    u64 *base = partial + (size_t)ch * 2 * (L + 1) * n;
-    tot.store(base + (size_t)jj * n, base + ((size_t)(L + 1) + jj) * n, w, mc);
+        tot.result(r0, r1, cx);
+        u64 *base = partial + (size_t)ch * 2 * (L + 1) * n;
+        mac_store<false>(base + (size_t)jj * n, base + ((size_t)(L + 1) + jj) * n, w, r0, r1);
+    });
 }
 
 // partial C0[ch][j] = sum_{l in chunk} diag_l[j] * c0[j][perm_l]
@@ -580,7 +742,31 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
-    if constexpr (KsWaves<LOGN>::FWD <= 2) {
+    if constexpr (C::R == 0) {
+        // N = 8192: split_fwd_raw delivers the pair layout idx_io (record t + T*g = two adjacent words per lane, lanes
+        // adjacent; NttCfg::idx_io): 16-byte operand loads and stores, 1 KiB contiguous per instruction
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+#pragma unroll
+        for (int g0 = 0; g0 < 8; g0 += 4) {
+            ulonglong2 a[4], sa[4], pp[4];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int rec = t + C::T * (g0 + g);
+                a[g] = reinterpret_cast<const ulonglong2 *>(acc)[rec];
+                sa[g] = !has_add ? make_ulonglong2(0, 0)
+                        : elt == 1u ? reinterpret_cast<const ulonglong2 *>(addrow + off)[rec]
+                                    : gather_pair(addrow, (uint32_t)(off / 2 + rec), elt, LOGN);
+                pp[g] = pt ? reinterpret_cast<const ulonglong2 *>(pt)[rec] : make_ulonglong2(0, 0);
+            }
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                ulonglong2 o;
+                o.x = md_epilogue(A{}, f[2 * (g0 + g)], a[g].x, sa[g].x, pp[g].x, pt != nullptr, cx, T, sp, j, mc);
+                o.y = md_epilogue(A{}, f[2 * (g0 + g) + 1], a[g].y, sa[g].y, pp[g].y, pt != nullptr, cx, T, sp, j, mc);
+                reinterpret_cast<ulonglong2 *>(dst)[t + C::T * (g0 + g)] = o;
+            }
+        }
+    } else if constexpr (KsWaves<LOGN>::FWD <= 2) {
         // 256-VGPR builds (N <= 8192): the epilogue's operands are independent of the transform, so the first group's
         // loads are issued BEFORE it (they land while the butterflies run) and the groups are software-pipelined --
         // the loads of group g+1 are in flight while group g is computed and stored.  At the 128-VGPR cap of
@@ -589,7 +775,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         auto fetch = [&](int hh, int bufi) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int idx = C::idx_out(t, 4 * hh + r);
+                const int idx = C::idx_io(t, 4 * hh + r);
                 a[bufi][r] = acc[idx];
                 sadd[bufi][r] = addin(idx);
                 pp[bufi][r] = pt ? pt[idx] : 0;
@@ -603,7 +789,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             if (hh + 1 < 4) fetch(hh + 1, cur ^ 1);
 #pragma unroll
             for (int r = 0; r < 4; ++r)
-                dst[C::idx_out(t, 4 * hh + r)] = md_epilogue(A{}, f[4 * hh + r], a[cur][r], sadd[cur][r], pp[cur][r],
+                dst[C::idx_io(t, 4 * hh + r)] = md_epilogue(A{}, f[4 * hh + r], a[cur][r], sadd[cur][r], pp[cur][r],
                                                              pt != nullptr, cx, T, sp, j, mc);
         }
     } else {
@@ -626,7 +812,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         auto fetch = [&](int g, int bufi) {
 #pragma unroll
             for (int r = 0; r < GS; ++r) {
-                const int idx = C::idx_out(t, GS * g + r);
+                const int idx = C::idx_io(t, GS * g + r);
                 a[bufi][r] = acc[idx];
                 sadd[bufi][r] = addin(idx);
                 pp[bufi][r] = pt ? pt[idx] : 0;
@@ -645,7 +831,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             if (HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
 #pragma unroll
             for (int r = 0; r < GS; ++r)
-                dst[C::idx_out(t, GS * g + r)] =
+                dst[C::idx_io(t, GS * g + r)] =
                     md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], pt != nullptr, cx, T, sp, j, mc);
             if (!HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, 0);
         }
@@ -763,7 +949,7 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     u64 v[8];
     const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
     const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, t};
-    quarter_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, part);
+    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, part);
     u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
 #pragma unroll
     for (int r = 0; r < 8; ++r) xd[C::idx_out(t, r)] = v[r];
@@ -861,13 +1047,21 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
+    // experiment knobs: a larger LDS request as an occupancy cap per kernel (bytes; workgroups per CU = 160 KiB / request)
+    auto lds_knob = [lds](const char *name) {
+        const char *e = getenv(name);
+        const size_t v = e ? (size_t)atol(e) : 0;
+        return v > lds ? v : lds;
+    };
+    static const size_t lds_fin = lds_knob("HEFX_FIN_LDS"), lds_ntt = lds_knob("HEFX_NTT_LDS"),
+                        lds_intt = lds_knob("HEFX_INTT_LDS"), lds_mdi = lds_knob("HEFX_MDI_LDS");
     static PerDeviceOnce attr_once;
     if (attr_once.first()) {
-        set_lds(ks_intt_digits_kernel<LOGN>, lds);
+        set_lds(ks_intt_digits_kernel<LOGN>, lds_intt);
         set_lds(ks_intt_digits_small_kernel<LOGN>, lds);
-        set_lds(ks_ntt_digits_kernel<LOGN>, lds);
-        set_lds(ks_moddown_intt_kernel<LOGN>, lds);
-        set_lds(ks_moddown_finish_kernel<LOGN>, lds);
+        set_lds(ks_ntt_digits_kernel<LOGN>, lds_ntt);
+        set_lds(ks_moddown_intt_kernel<LOGN>, lds_mdi);
+        set_lds(ks_moddown_finish_kernel<LOGN>, lds_fin);
         if (getenv("HEFX_DEBUG")) {
             int nb = -1;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ks_ntt_digits_kernel<LOGN>, SC::T, lds);
@@ -937,7 +1131,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_intt_digits_small_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
     else
-        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, batch, L, rl, 0,
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, rl, 0,
                            n * L, scr);
     if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
         if constexpr (LOGN <= 14) {
@@ -955,7 +1149,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         // x of this (sub-)chunk against the 256 MB Infinity Cache: beyond it, stream x (HEFX_STREAM_X=0/1 overrides)
         static const int force = getenv("HEFX_STREAM_X") ? atoi(getenv("HEFX_STREAM_X")) : -1;
         const int stream_x = force >= 0 ? force : ((size_t)m * L * (L + 1) * SC::N * 8 > ((size_t)256 << 20) ? 1 : 0);
-        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds, s, T, L, m * L,
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds_ntt, s, T, L, m * L,
                            item0, stream_x, scr);
         mark(3);
         if (stream_x)
@@ -966,9 +1160,9 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                                L, rl, item0, m, scr);
     }
     mark(4);
-    hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2, scr);
+    hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, scr);
     mark(5);
-    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch, L,
+    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
                        rl, n * 2, scr);
     mark(-1);
     return hipGetLastError();
@@ -1143,11 +1337,11 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
                                  : out + (size_t)poly * (L - 1) * SC::N) + (size_t)j * SC::N + off;
     u64 a[16];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = src[C::idx_out(t, r)];
+    for (int r = 0; r < 16; ++r) a[r] = src[C::idx_io(t, r)];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const u64 z = submod(a[r], v[r], q);
-        dst[C::idx_out(t, r)] = csub(shoup_lazy(z, qinv.x, qinv.y, q), q);
+        dst[C::idx_io(t, r)] = csub(shoup_lazy(z, qinv.x, qinv.y, mc.nq), q);
     }
 }
 
@@ -1206,7 +1400,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ntt_spl
         const InMode mode = {false, false, false, 0};
         split_fwd<LOGN>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[(size_t)h * SC::H + C::idx_out(t, r)] = v[r];
+        for (int r = 0; r < 16; ++r) o[(size_t)h * SC::H + C::idx_io(t, r)] = v[r];
     } else {
         split_inv<LOGN>(v, reinterpret_cast<const ulonglong2 *>(s), lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
 #pragma unroll

@@ -17,7 +17,7 @@ struct ModConst {
     u64 r0, r1;        // floor(2^128/q) = r1*2^64 + r0   (Barrett)
     u64 ninv, ninv_s;  // N^-1 mod q and its Shoup companion floor(ninv*2^64/q)
     u64 ilw, ilw_s;    // (psi^-1 twiddle of the last inverse stage) * N^-1, and Shoup companion
-    u64 pad;
+    u64 nq;            // 2^64 - q (shoup_lazy*, csubn: additions instead of subtractions)
 };
 
 // Per-modulus constants of the FP64 policy (valid only for q < 2^41).
@@ -36,8 +36,6 @@ struct NttTables {
 
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
-// x*w mod q in [0,2q), ws = floor(w*2^64/q); valid for ANY 64-bit x (Harvey/Shoup).
-__device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64(x, ws) * q; }
 
 // floor(x*ws / 2^64) UNDER-estimated by at most 2: only the three partial products that reach bit 64, no carry chain
 // between them.  With x = x1 2^32 + x0, ws = w1 2^32 + w0 the exact value is
@@ -49,8 +47,43 @@ __device__ __forceinline__ u64 mulhi64_under2(u64 x, u64 ws)
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)ws, w1 = (uint32_t)(ws >> 32);
     return (u64)x1 * w1 + ((u64)__umulhi(x0, w1) + (u64)__umulhi(x1, w0));
 }
-// x*w mod q in [0,4q) for ANY 64-bit x: Shoup with the under-estimated quotient (each missing unit adds one q)
-__device__ __forceinline__ u64 shoup_lazy4(u64 x, u64 w, u64 ws, u64 q) { return x * w - mulhi64_under2(x, ws) * q; }
+// x*w - h*q mod 2^64 as x*w + h*nq with nq = 2^64 - q, every partial product a 64-bit multiply-add that also does the
+// addition (and, through the negated modulus, the subtraction): six v_mad_u64_u32 and one 32-bit add where the
+// compiler's form of x*w - h*q takes ten instructions (two v_mad_u64_u32, four v_mul_lo_u32, two three-way adds and a
+// borrow chain).  The four cross products only matter through the low word of their sum; left to itself the optimiser
+// sees that and goes back to 32-bit multiplies plus adds, hence the empty asm (a value barrier, no instruction) and the
+// one-instruction asm for the 32-bit add (written in C it becomes a 64-bit add of u << 32).  Same value, bit for bit.
+__device__ __forceinline__ u64 mul_sub_lo64(u64 x, u64 w, u64 h, u64 nq)
+{
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32), n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+    u64 u = (u64)x0 * w1;
+    u = (u64)x1 * w0 + u;
+    u = (u64)h0 * n1 + u;
+    u = (u64)h1 * n0 + u;
+    asm("" : "+v"(u));
+    u64 a = (u64)x0 * w0;
+    a = (u64)h0 * n0 + a;
+    uint32_t ahi;
+    asm("v_add_u32 %0, %1, %2" : "=v"(ahi) : "v"((uint32_t)(a >> 32)), "v"((uint32_t)u));
+    return (u64)(uint32_t)a | ((u64)ahi << 32);
+}
+// x*w mod q in [0,2q), ws = floor(w*2^64/q), nq = 2^64 - q; valid for ANY 64-bit x (Harvey/Shoup).
+__device__ __forceinline__ u64 shoup_lazy(u64 x, u64 w, u64 ws, u64 nq) { return mul_sub_lo64(x, w, mulhi64(x, ws), nq); }
+// x*w mod q in [0,4q) for ANY 64-bit x: Shoup with the under-estimated quotient (each missing unit adds one q);
+// nq = 2^64 - q
+__device__ __forceinline__ u64 shoup_lazy4(u64 x, u64 w, u64 ws, u64 nq)
+{
+    return mul_sub_lo64(x, w, mulhi64_under2(x, ws), nq);
+}
+// x in [0,2m) -> [0,m) given nm = 2^64 - m as a LOADED value (ModConst::nq and its multiples; computed in the kernel the
+// optimiser turns x + (0 - m) back into a subtraction): one 64-bit add (v_lshl_add_u64), one compare, two selects
+// -- no borrow chain through VCC (x - m needs v_sub_co / v_subb_co and their wait states)
+__device__ __forceinline__ u64 csubn(u64 x, u64 nm)
+{
+    const u64 d = x + nm;
+    return d > x ? x : d;
+}
 
 // x in [0,2m) -> [0,m).  Written on the borrow of x - m (sub, subb, two selects) rather than compare-then-subtract.
 __device__ __forceinline__ u64 csub(u64 x, u64 q)

@@ -62,6 +62,17 @@ struct NttCfg {
         if (R == 0) return t * 16 + r;
         return (t + T * (r >> R)) * G + (r & (G - 1));
     }
+    // NTT-domain index of register r at the MEMORY side of the split transforms (split_fwd* outputs; split_inv* loads
+    // records the same way).  For R > 0 that is idx_out: G >= 2 adjacent words per lane, lanes adjacent -- coalesced.
+    // For R == 0 idx_out would put lanes 128 bytes apart (sixteen consecutive words per thread): every global access
+    // touches 64 cache lines and the operand streams of the resident workgroups evict each other from L1 between a
+    // line's uses (measured at N = 8192: mod-down finish 384 -> 134 us per chunk once its accesses were coalesced).
+    // There the values take one more trip through LDS into the pair layout of R = 1.
+    __device__ static __forceinline__ int idx_io(int t, int r)
+    {
+        if (R == 0) return (t + T * (r >> 1)) * 2 + (r & 1);
+        return idx_out(t, r);
+    }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -77,6 +88,7 @@ struct ArithU64 {
     // canonical, so the bits are those of any exact arithmetic.
     struct Ctx {
         u64 q, two_q, four_q;
+        u64 nq, n2q, n4q;  // 2^64 - q, - 2q, - 4q (shoup_lazy4, csubn)
         u64 ninv, ninv_s, ilw, ilw_s;
     };
     __device__ static __forceinline__ Ctx make(const ModConst &mc)
@@ -85,6 +97,9 @@ struct ArithU64 {
         c.q = mc.q;
         c.two_q = mc.q << 1;
         c.four_q = mc.q << 2;
+        c.nq = mc.nq;
+        c.n2q = mc.nq << 1;
+        c.n4q = mc.nq << 2;
         c.ninv = mc.ninv;
         c.ninv_s = mc.ninv_s;
         c.ilw = mc.ilw;
@@ -94,38 +109,38 @@ struct ArithU64 {
     // forward butterfly, inputs/outputs in [0,8q)
     __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
     {
-        u64 a = csub(x, c.four_q);                      // [0,4q)
-        u64 t = shoup_lazy4(y, w.x, w.y, c.q);          // [0,4q), y any 64-bit word
+        u64 a = csubn(x, c.n4q);                      // [0,4q)
+        u64 t = shoup_lazy4(y, w.x, w.y, c.nq);          // [0,4q), y any 64-bit word
         x = a + t;
         y = a + c.four_q - t;
     }
     // first stage of a split forward transform: keep X (h=0) or Y (h=1); x,y canonical
     __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
     {
-        const u64 t = shoup_lazy4(y, w.x, w.y, c.q);
+        const u64 t = shoup_lazy4(y, w.x, w.y, c.nq);
         return h ? x + c.four_q - t : x + t;            // < 5q
     }
     // inverse butterfly, inputs/outputs in [0,4q)
     __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
     {
-        u64 s = csub(x + y, c.four_q);
+        u64 s = csubn(x + y, c.n4q);
         u64 d = x + c.four_q - y;                       // (0,8q)
         x = s;
-        y = shoup_lazy4(d, w.x, w.y, c.q);
+        y = shoup_lazy4(d, w.x, w.y, c.nq);
     }
     // last inverse stage: exact Shoup products (outputs in [0,2q), what inv_finish expects)
     __device__ static __forceinline__ void gs_last(V &x, V &y, const Ctx &c)
     {
         u64 s = x + y;                                  // < 8q: fine for Shoup (any 64-bit word)
         u64 d = x + c.four_q - y;
-        x = shoup_lazy(s, c.ninv, c.ninv_s, c.q);
-        y = shoup_lazy(d, c.ilw, c.ilw_s, c.q);
+        x = shoup_lazy(s, c.ninv, c.ninv_s, c.nq);
+        y = shoup_lazy(d, c.ilw, c.ilw_s, c.nq);
     }
     // first stage of a split inverse transform on a canonical pair (a0,a1): sum (h=0) or twiddled difference
     __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
     __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
     {
-        return shoup_lazy4(a0 + c.q - a1, w.x, w.y, c.q);
+        return shoup_lazy4(a0 + c.q - a1, w.x, w.y, c.nq);
     }
     template <int NV>
     __device__ static __forceinline__ void inv_pass_begin(V (&)[NV], const Ctx &) {}
@@ -133,14 +148,14 @@ struct ArithU64 {
     // difference of two values of the inverse range [0,4q), results back in [0,4q).
     __device__ static __forceinline__ V ct_sel(V x, V y, const TW &w, const Ctx &c, int h)
     {
-        const u64 a = csub(x, c.four_q);
-        const u64 t = shoup_lazy4(y, w.x, w.y, c.q);
+        const u64 a = csubn(x, c.n4q);
+        const u64 t = shoup_lazy4(y, w.x, w.y, c.nq);
         return h ? a + c.four_q - t : a + t;
     }
-    __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &c) { return csub(x + y, c.four_q); }
+    __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &c) { return csubn(x + y, c.n4q); }
     __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c)
     {
-        return shoup_lazy4(x + c.four_q - y, w.x, w.y, c.q);
+        return shoup_lazy4(x + c.four_q - y, w.x, w.y, c.nq);
     }
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     static constexpr bool IS_F64 = false;
@@ -153,19 +168,21 @@ struct ArithU64 {
     }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c)
     {
-        return csub(csub(csub(x, c.four_q), c.two_q), c.q);
+        return csubn(csubn(csubn(x, c.n4q), c.n2q), c.nq);
     }
+    // what the key MAC reads from scratch for a row of this policy (hefx_keyswitch.hip, MacL / MacW): canonical words
+    __device__ static __forceinline__ u64 mac_operand(V x, const Ctx &c) { return fwd_finish(x, c); }
     // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 8q):
     // ((acc - f) * P^-1 + sadd) [* pt] mod q, canonical
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const ulonglong2 &pinv, const ModConst &mc)
     {
-        u64 z = acc + c.four_q - csub(f, c.four_q);      // < 5q (no 9q intermediate: primes may reach 2^61)
-        z = shoup_lazy(z, pinv.x, pinv.y, c.q) + sadd;   // < 3q
+        u64 z = acc + c.four_q - csubn(f, c.n4q);      // < 5q (no 9q intermediate: primes may reach 2^61)
+        z = shoup_lazy(z, pinv.x, pinv.y, c.nq) + sadd;   // < 3q
         if (has_pt) return mulmod(z, pt, mc);            // product < 3q*q < q*2^64: Barrett128 gives [0,q)
-        return csub(csub(z, c.two_q), c.q);
+        return csubn(csubn(z, c.n2q), c.nq);
     }
-    __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return csub(x, c.q); }
+    __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return csubn(x, c.nq); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -279,6 +296,9 @@ struct ArithF64 {
         return to_u64(r);
     }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c) { return canon(x, c); }
+    // what the key MAC reads from scratch for a row of this policy (MacF): the UNFINISHED value itself, as a double --
+    // an integer with |x| < 2^41 + (LOGN+1) * 0.52q < 2^45, a valid left operand of mm(); no canonicalisation here
+    __device__ static __forceinline__ u64 mac_operand(V x, const Ctx &) { return (u64)__double_as_longlong(x); }
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const double2 &pinv)
     {
@@ -511,7 +531,7 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 // Forward split (transform size 2^LOGN, this workgroup = half h, sub-transform 2^(LOGN-1)):
 // ld(r, x, y) delivers the raw words of coefficients idx_nat(t,r) and idx_nat(t,r)+N/2, `mode` says how they become
 // inputs (reduction / constant subtraction in the row's arithmetic policy); on return
-// v[r] = NTT value at h*N/2 + idx_out(t,r), canonical.  Loads are issued in two batches of eight pairs.
+// v[r] = NTT value at h*N/2 + idx_io(t,r), canonical.  Loads are issued in two batches of eight pairs.
 // NB = number of load batches of the first stage: 2 (eight pairs each) under the 128-VGPR cap, 1 (all sixteen pairs in
 // flight at once, one exposed memory latency instead of two) in the 256-VGPR builds.
 template <int LOGN, class A, class LD, int NB = 2, class HOOK = NoHook>
@@ -549,9 +569,19 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
         }
     }
     ntt_fwd_core<LOGN - 1, A, HOOK>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h, tail_hook);
+    using C = NttCfg<LOGN - 1>;
+    if constexpr (C::R == 0) {  // idx_out -> idx_io through LDS (the last pass read exactly the words written here)
+        typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lf[C::phys(16 * t + r)] = f[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = lf[C::phys(C::idx_io(t, r))];
+    }
 }
 
-template <int LOGN, class A, class LD, int NB = 2>
+// MACOP: deliver A::mac_operand (the key MAC's input format) instead of canonical words
+template <int LOGN, class A, class LD, int NB = 2, bool MACOP = false>
 __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const InMode &mode, const ModConst &mc,
                                             u64 *lds, const typename A::TW *__restrict__ tw,
                                             const typename A::Ctx &cx, int t, int h)
@@ -559,21 +589,21 @@ __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const In
     typename A::V f[16];
     split_fwd_raw<LOGN, A, LD, NB>(f, ld, mode, mc, lds, tw, cx, t, h);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) v[r] = A::fwd_finish(f[r], cx);
+    for (int r = 0; r < 16; ++r) v[r] = MACOP ? A::mac_operand(f[r], cx) : A::fwd_finish(f[r], cx);
 }
 
-template <int LOGN, int NB = 2, class LD>
+template <int LOGN, int NB = 2, bool MACOP = false, class LD>
 __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMode &mode, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
     if (mf.q != 0.0)
-        split_fwd_a<LOGN, ArithF64, LD, NB>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
+        split_fwd_a<LOGN, ArithF64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
     else
-        split_fwd_a<LOGN, ArithU64, LD, NB>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
+        split_fwd_a<LOGN, ArithU64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
 }
 
 // Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the
-// sub-transform; on return v[r] = coefficient 2*idx_nat(t,r) + h, canonical.
+// sub-transform (fetched as lane-adjacent records and exchanged through LDS when R == 0); on return v[r] = coefficient 2*idx_nat(t,r) + h, canonical.
 // `ldp(j)` delivers the row's (value[2j], value[2j+1]) record -- a plain 16-byte load, or a Galois-gathered one
 // (hefx_keyswitch.hip).  The first stage is done in two batches of eight pairs (+ eight twiddles for the odd half) with
 // a scheduling fence between them: issuing all 16 pair loads and 16 twiddle loads at once needs ~250 VGPRs in the FP64
@@ -586,11 +616,14 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
     using C = NttCfg<LOGN - 1>;
     constexpr int BS = 16 / NB;
     typename A::V f[16];
+    // the first stage is element-wise on records, so for R == 0 it runs on lane-adjacent records (idx_nat; see idx_io)
+    // and its results reach the layout the core starts in (idx_out) through LDS
+    auto rec = [&](int r) { return C::R == 0 ? C::idx_nat(t, r) : C::idx_out(t, r); };
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         ulonglong2 pr[BS];
 #pragma unroll
-        for (int r = 0; r < BS; ++r) pr[r] = ldp(C::idx_out(t, BS * g + r));
+        for (int r = 0; r < BS; ++r) pr[r] = ldp(rec(BS * g + r));
         if (h == 0) {
 #pragma unroll
             for (int r = 0; r < BS; ++r)
@@ -598,12 +631,20 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
         } else {
             typename A::TW w[BS];
 #pragma unroll
-            for (int r = 0; r < BS; ++r) w[r] = itw[C::N + C::idx_out(t, BS * g + r)];  // itw[N/2 + j]
+            for (int r = 0; r < BS; ++r) w[r] = itw[C::N + rec(BS * g + r)];  // itw[N/2 + j]
 #pragma unroll
             for (int r = 0; r < BS; ++r)
                 f[BS * g + r] = A::gs_half_diff(A::from_u64(pr[r].x), A::from_u64(pr[r].y), w[r], cx);
         }
         HEFX_STAGE_FENCE();
+    }
+    if constexpr (C::R == 0) {
+        typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lf[C::phys(C::idx_nat(t, r))] = f[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = lf[C::phys(16 * t + r)];  // the words the core's first pass owns
     }
     ntt_inv_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
 #pragma unroll

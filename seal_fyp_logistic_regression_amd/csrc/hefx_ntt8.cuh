@@ -249,7 +249,7 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
     ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 4 + qd);
 }
 
-template <int LOGN, class LD>
+template <int LOGN, bool MACOP = false, class LD>
 __device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InMode &mode, u64 *lds, const NttTables &nt,
                                             const ModConst &mc, const ModConstF &mf, int t, int qd)
 {
@@ -258,12 +258,12 @@ __device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InM
         double f[8];
         quarter_fwd_raw<LOGN, ArithF64, LD>(f, ld, mode, mc, lds, nt.twf, cx, t, qd);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = ArithF64::fwd_finish(f[r], cx);
+        for (int r = 0; r < 8; ++r) v[r] = MACOP ? ArithF64::mac_operand(f[r], cx) : ArithF64::fwd_finish(f[r], cx);
     } else {
         const ArithU64::Ctx cx = ArithU64::make(mc);
         quarter_fwd_raw<LOGN, ArithU64, LD>(v, ld, mode, mc, lds, nt.tw, cx, t, qd);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = ArithU64::fwd_finish(v[r], cx);
+        for (int r = 0; r < 8; ++r) v[r] = MACOP ? ArithU64::mac_operand(v[r], cx) : ArithU64::fwd_finish(v[r], cx);
     }
 }
 
