@@ -54,6 +54,19 @@ struct NttCfg {
     static constexpr int PSH = 4 + R;    // pad G words every 16*G words
     static constexpr int LDS_WORDS = N + (N >> 4);
     __device__ static __forceinline__ int phys(int idx) { return idx + ((idx >> PSH) << R); }
+    // phys() is AFFINE along every access pattern of the cores, which lets the sixteen LDS accesses of a pass share one
+    // address register and differ in the instruction's immediate offset (the compiler cannot prove the absence of
+    // carries in phys(base + S*e) and otherwise spends ~2 VALU instructions per access on it):
+    //   pass with element stride S = 2^LOGS:  LOGS >= PSH -> the pad count advances by S >> PSH per element;
+    //                                         LOGS == R   -> all sixteen words lie in one pad block (16*S = 2^PSH)
+    //   (LOGS = LOGN - 4(p+1) is congruent to R modulo 4, so these are the only cases)
+    //   remainder pass, group c of thread t = words (t + T*c)*G + e: the pad count is (t >> 4) + (T >> 4)*c
+    __host__ __device__ static constexpr int pass_stride(int logs)
+    {
+        return logs >= PSH ? (1 << logs) + (((1 << logs) >> PSH) << R) : (1 << logs);
+    }
+    static constexpr int REM_STRIDE = T * G + ((T >> 4) << R);
+    static_assert(T % 16 == 0, "remainder-pass addressing assumes T is a multiple of 16");
     // coefficient index of register r in the pass-0 layout (coalesced: lane-consecutive words)
     __device__ static __forceinline__ int idx_nat(int t, int r) { return t + T * r; }
     // coefficient index of register r in the layout the forward transform ends in
@@ -366,9 +379,10 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
         const int S = 1 << LOGS;
         const int b = t >> LOGS;
         const int base = b * (16 * S) + (t & (S - 1));
+        const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p > 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
+            for (int e = 0; e < 16; ++e) v[e] = lds[pb + ps * e];
         }
         if (C::R == 0 && p == C::FP - 1) tail_hook();
 #pragma unroll
@@ -386,16 +400,16 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
             load_rem_tw<LOGN, A>(w, tw, t, pre);
         if (p + 1 < C::FP || C::R > 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lds[C::phys(base + S * e)] = v[e];
+            for (int e = 0; e < 16; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
         }
     }
     if (C::R > 0) {
+        const int pg = C::phys(t * C::G);
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
-            const int g = t + C::T * c;
 #pragma unroll
-            for (int e = 0; e < C::G; ++e) v[c * C::G + e] = lds[C::phys(g * C::G + e)];
+            for (int e = 0; e < C::G; ++e) v[c * C::G + e] = lds[pg + C::REM_STRIDE * c + e];
         }
         tail_hook();
 #pragma unroll
@@ -439,11 +453,11 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
             }
         }
         load_pass_tw<LOGN, A>(w, itw, C::FP - 1, t, 1);  // next pass's twiddles travel during the exchange
+        const int pg = C::phys(t * C::G);
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
-            const int g = t + C::T * c;
 #pragma unroll
-            for (int e = 0; e < C::G; ++e) lds[C::phys(g * C::G + e)] = v[c * C::G + e];
+            for (int e = 0; e < C::G; ++e) lds[pg + C::REM_STRIDE * c + e] = v[c * C::G + e];
         }
         __syncthreads();
     } else {
@@ -455,9 +469,10 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
         const int S = 1 << LOGS;
         const int b = t >> LOGS;
         const int base = b * (16 * S) + (t & (S - 1));
+        const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p < C::FP - 1 || C::R > 0) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) v[e] = lds[C::phys(base + S * e)];
+            for (int e = 0; e < 16; ++e) v[e] = lds[pb + ps * e];
         }
         A::inv_pass_begin(v, cx);
 #pragma unroll
@@ -477,7 +492,7 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
         if (p > 0) {
             load_pass_tw<LOGN, A>(w, itw, p - 1, t, 1);
 #pragma unroll
-            for (int e = 0; e < 16; ++e) lds[C::phys(base + S * e)] = v[e];
+            for (int e = 0; e < 16; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
         }
     }
@@ -572,11 +587,13 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
     using C = NttCfg<LOGN - 1>;
     if constexpr (C::R == 0) {  // idx_out -> idx_io through LDS (the last pass read exactly the words written here)
         typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+        // R == 0: phys(i) = i + (i >> 4), written out along both patterns (affine, see NttCfg)
+        const int pw = 17 * t, pr = 2 * t + (t >> 3);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lf[C::phys(16 * t + r)] = f[r];
+        for (int r = 0; r < 16; ++r) lf[pw + r] = f[r];
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) f[r] = lf[C::phys(C::idx_io(t, r))];
+        for (int r = 0; r < 16; ++r) f[r] = lf[pr + (2 * C::T + C::T / 8) * (r >> 1) + (r & 1)];  // phys(idx_io(t, r))
     }
 }
 
@@ -640,11 +657,12 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
     }
     if constexpr (C::R == 0) {
         typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+        const int pw = t + (t >> 4), pr = 17 * t;  // R == 0: phys(i) = i + (i >> 4)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) lf[C::phys(C::idx_nat(t, r))] = f[r];
+        for (int r = 0; r < 16; ++r) lf[pw + (C::T + C::T / 16) * r] = f[r];  // phys(idx_nat(t, r))
         __syncthreads();
 #pragma unroll
-        for (int r = 0; r < 16; ++r) f[r] = lf[C::phys(16 * t + r)];  // the words the core's first pass owns
+        for (int r = 0; r < 16; ++r) f[r] = lf[pr + r];  // phys(16t + r): the words the core's first pass owns
     }
     ntt_inv_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
 #pragma unroll
