@@ -77,6 +77,15 @@ __device__ static __forceinline__ void group_decode(int bid, int fan, int &g, in
 }
 // index of coefficient j in a row stored de-interleaved
 __device__ static __forceinline__ int eo(int j, int H) { return (j & 1) * H + (j >> 1); }
+// the same for j = idx_nat(t, r) = t + T*r of a split-2 loader, written so that the address arithmetic stays 32-bit and
+// affine in r (T is even: the parity is the thread's; one v_add_u32 or an immediate offset per load against a 64-bit
+// add with carry per load for the general form)
+template <class SC>
+__device__ static __forceinline__ uint32_t eo_nat(int t, int r)
+{
+    static_assert(SC::C::T % 2 == 0, "split-2 loaders assume an even thread count");
+    return (uint32_t)((t & 1) * SC::H + (t >> 1)) + (uint32_t)(SC::C::T / 2) * (uint32_t)r;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Galois-gathered reads.  The rotated inputs perm_g(c0), perm_g(c1) are never written out: their three readers --
@@ -189,7 +198,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
     // so a digit of a prime < 2^41 needs no reduction at all (the transform is linear and ends canonical)
     const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const int e = eo(C::idx_nat(t, r), SC::H);
+        const uint32_t e = eo_nat<SC>(t, r);
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
@@ -725,7 +734,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     // u < P is reduced modulo q_j and (P/2 mod q_j) subtracted in the row's policy (exact for any 64-bit word)
     const InMode mode = {true, true, true, half_j};
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const int e = eo(C::idx_nat(t, r), SC::H);
+        const uint32_t e = eo_nat<SC>(t, r);
         x = ud[e];
         y = ud[e + SC::H / 2];
     };
@@ -1325,7 +1334,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     // rounded: subtract (q_l/2 mod q_j) from the reduced remainder, in the row's arithmetic policy
     const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, rounded != 0, T.halfmod[(size_t)(L - 1) * T.k + j]};
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const int e = eo(C::idx_nat(t, r), SC::H);
+        const uint32_t e = eo_nat<SC>(t, r);
         x = dd[e];
         y = dd[e + SC::H / 2];
     };

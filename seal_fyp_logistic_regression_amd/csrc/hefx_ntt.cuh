@@ -127,11 +127,19 @@ struct ArithU64 {
         x = a + t;
         y = a + c.four_q - t;
     }
-    // first stage of a split forward transform: keep X (h=0) or Y (h=1); x,y canonical
-    __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
+    // first stage of a split forward transform: keep X = x + w*y (h=0) or Y = x - w*y (h=1); x,y canonical.  The sign
+    // goes into the twiddle once per workgroup -- (q - w, ~w') is the Shoup pair of -w: floor((q-w) 2^64 / q) =
+    // 2^64 - 1 - floor(w 2^64 / q) because q does not divide w 2^64 -- instead of a select per element.
+    __device__ static __forceinline__ TW half_twiddle(const TW &w, const Ctx &c, int h)
     {
-        const u64 t = shoup_lazy4(y, w.x, w.y, c.nq);
-        return h ? x + c.four_q - t : x + t;            // < 5q
+        TW r;
+        r.x = h ? c.q - w.x : w.x;
+        r.y = h ? ~w.y : w.y;
+        return r;
+    }
+    __device__ static __forceinline__ V ct_half(V x, V y, const TW &wh, const Ctx &c)
+    {
+        return x + shoup_lazy4(y, wh.x, wh.y, c.nq);    // < 5q
     }
     // inverse butterfly, inputs/outputs in [0,4q)
     __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
@@ -159,11 +167,9 @@ struct ArithU64 {
     __device__ static __forceinline__ void inv_pass_begin(V (&)[NV], const Ctx &) {}
     // quarter-row helpers (hefx_ntt8.cuh).  Forward: second stage on values < 5q, result < 8q.  Inverse: sum / twiddled
     // difference of two values of the inverse range [0,4q), results back in [0,4q).
-    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &w, const Ctx &c, int h)
+    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &wh, const Ctx &c)  // wh = half_twiddle(w, c, h)
     {
-        const u64 a = csubn(x, c.n4q);
-        const u64 t = shoup_lazy4(y, w.x, w.y, c.nq);
-        return h ? a + c.four_q - t : a + t;
+        return csubn(x, c.n4q) + shoup_lazy4(y, wh.x, wh.y, c.nq);
     }
     __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &c) { return csubn(x + y, c.n4q); }
     __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c)
@@ -242,11 +248,8 @@ struct ArithF64 {
         x = a + t;
         y = a - t;
     }
-    __device__ static __forceinline__ V ct_half(V x, V y, const TW &w, const Ctx &c, int h)
-    {
-        const double t = mm(y, w, c);
-        return h ? x - t : x + t;
-    }
+    __device__ static __forceinline__ TW half_twiddle(const TW &w, const Ctx &, int h) { return h ? -w : w; }
+    __device__ static __forceinline__ V ct_half(V x, V y, const TW &wh, const Ctx &c) { return x + mm(y, wh, c); }
     __device__ static __forceinline__ void gs(V &x, V &y, const TW &w, const Ctx &c)
     {
         const double s = x + y, d = x - y;
@@ -271,11 +274,7 @@ struct ArithF64 {
 #pragma unroll
         for (int e = 0; e < NV; ++e) v[e] = red(v[e], c);
     }
-    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &w, const Ctx &c, int h)
-    {
-        const double t = mm(y, w, c);
-        return h ? x - t : x + t;
-    }
+    __device__ static __forceinline__ V ct_sel(V x, V y, const TW &wh, const Ctx &c) { return x + mm(y, wh, c); }
     __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &) { return x + y; }
     __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c) { return mm(x - y, w, c); }
     // u64 <-> double for integers in [0, 2^52) by exponent splicing: one integer OR/AND on the high word plus one
@@ -554,7 +553,7 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
                                               const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK())
 {
-    const typename A::TW w1 = tw[1];
+    const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
     // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
     // select per element (which would make every row pay for the reduction)
     constexpr int BS = 16 / NB;
@@ -567,7 +566,7 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
 #pragma unroll
             for (int r = 0; r < BS; ++r)
                 f[BS * g + r] = A::ct_half(A::template input<true>(x[r], mode, cx, mc),
-                                           A::template input<true>(y[r], mode, cx, mc), w1, cx, h);
+                                           A::template input<true>(y[r], mode, cx, mc), w1, cx);
             HEFX_STAGE_FENCE();
         }
     } else {
@@ -579,7 +578,7 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
 #pragma unroll
             for (int r = 0; r < BS; ++r)
                 f[BS * g + r] = A::ct_half(A::template input<false>(x[r], mode, cx, mc),
-                                           A::template input<false>(y[r], mode, cx, mc), w1, cx, h);
+                                           A::template input<false>(y[r], mode, cx, mc), w1, cx);
             HEFX_STAGE_FENCE();
         }
     }

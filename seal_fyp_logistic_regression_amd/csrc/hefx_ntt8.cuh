@@ -125,12 +125,12 @@ __device__ __forceinline__ void split8_fwd_a(u64 (&out)[8], const LD &ld, u64 *l
                                              int h)
 {
     typename A::V f[8];
-    const typename A::TW w1 = tw[1];
+    const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
     u64 x[8], y[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) ld(r, x[r], y[r]);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) f[r] = A::ct_half(A::from_u64(x[r]), A::from_u64(y[r]), w1, cx, h);
+    for (int r = 0; r < 8; ++r) f[r] = A::ct_half(A::from_u64(x[r]), A::from_u64(y[r]), w1, cx);
     HEFX_STAGE_FENCE();
     ntt8_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
 #pragma unroll
@@ -225,7 +225,7 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
                                                 const typename A::Ctx &cx, int t, int qd)
 {
     const int h0 = qd >> 1, h1 = qd & 1;
-    const typename A::TW w1 = tw[1], w2 = tw[2 + h0];
+    const typename A::TW w1 = A::half_twiddle(tw[1], cx, h0), w2 = A::half_twiddle(tw[2 + h0], cx, h1);
     auto stage = [&](auto red) {
         constexpr bool RED = decltype(red)::value;
         u64 x[8][4];
@@ -235,10 +235,10 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
         for (int r = 0; r < 8; ++r) {
             // stage 0 (gap N/2): half h0 of (x0, x2) and of (x1, x3); stage 1 (gap N/4): quarter h1 of that half
             const typename A::V a = A::ct_half(A::template input<RED>(x[r][0], mode, cx, mc),
-                                               A::template input<RED>(x[r][2], mode, cx, mc), w1, cx, h0);
+                                               A::template input<RED>(x[r][2], mode, cx, mc), w1, cx);
             const typename A::V b = A::ct_half(A::template input<RED>(x[r][1], mode, cx, mc),
-                                               A::template input<RED>(x[r][3], mode, cx, mc), w1, cx, h0);
-            f[r] = A::ct_sel(a, b, w2, cx, h1);
+                                               A::template input<RED>(x[r][3], mode, cx, mc), w1, cx);
+            f[r] = A::ct_sel(a, b, w2, cx);
         }
         HEFX_STAGE_FENCE();
     };
