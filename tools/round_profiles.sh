@@ -29,6 +29,6 @@ for f in glob.glob(os.path.join(out, "sq", "**", "*counter_collection.csv"), rec
         if r["Counter_Name"] == "SQ_INSTS_VALU": n[k] += 1
 json.dump({k: dict(launches=n[k], **v) for k, v in agg.items()}, open(os.path.join(out, "sq_counters.json"), "w"), indent=1)
 PY
-rm -rf $out/pf/*/*counter_collection.csv $out/pw/*/*counter_collection.csv $out/sq
+rm -rf $out/pf/*counter_collection.csv $out/pw/*counter_collection.csv $out/pf/*/*counter_collection.csv $out/pw/*/*counter_collection.csv $out/sq
 find $out -name "*_agent_info.csv" -delete
 ls $out
