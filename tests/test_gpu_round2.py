@@ -335,6 +335,32 @@ def test_invalid_item_in_a_multi_chunk_batch_leaves_the_context_usable():
         assert (got[i].download() == o.apply_galois(cts[i], 3, key)).all()
 
 
+def test_batch_items_processed_grouped_by_key_land_in_their_own_outputs():
+    """ks_run processes the items of a batch grouped by key (neighbours then share their key loads in the MAC): a batch
+    whose keys arrive scrambled -- three keys, several chunks, some items in place -- must still put every result where
+    its item says, with the bits of the item-by-item evaluation."""
+    from oracle import oracle as O
+    o, e, primes = _mk("C2", {"HEFX_CHUNK": "4"})
+    L, n = 3, 13
+    steps = [1, 2, 1, 4, 2, 2, 1, 4, 4, 1, 2, 4, 1]
+    keys = {s_: _rand_key(o, 40 + s_) for s_ in (1, 2, 4)}
+    dkeys = {s_: e.to_device(k_) for s_, k_ in keys.items()}
+    elts = [O.galois_elt_from_step(o.N, s_) for s_ in steps]
+    cts = [o.uniform(L, 2, 700 + i) for i in range(n)]
+    pts = [o.uniform(L, 1, 800 + i)[0] for i in range(n)]
+    dcts = [e.to_device(c) for c in cts]
+    outs = e.empty_many(n, (2, L, o.N))
+    for i in (3, 7, 12):                                   # in-place items
+        outs[i] = dcts[i]
+    got = e.apply_galois_batch(L, dcts, elts, [dkeys[s_] for s_ in steps], outs=outs)
+    for i in range(n):
+        assert (got[i].download() == o.apply_galois(cts[i], elts[i], keys[steps[i]])).all(), i
+    dcts = [e.to_device(c) for c in cts]
+    got = e.rotate_multiply_plain_batch(L, dcts, elts, [dkeys[s_] for s_ in steps], [e.to_device(p) for p in pts])
+    for i in range(n):
+        assert (got[i].download() == o.rotate_mulplain(cts[i], elts[i], keys[steps[i]], pts[i])).all(), i
+
+
 def test_two_contexts_with_the_current_device_switched_underneath():
     """Every C-ABI entry selects its context's device itself.  On a one-GPU box both contexts live on
     device 0; the test still drives two interleaved contexts (separate scratch, rings, streams, pools) and -- when a
