@@ -19,6 +19,14 @@ struct Ntt8Cfg {
     static constexpr int PSH = 3 + R;
     static constexpr int LDS_WORDS = N + (N >> 3);
     __device__ static __forceinline__ int phys(int idx) { return idx + ((idx >> PSH) << R); }
+    // affine forms of phys() along the cores' access patterns (same argument as NttCfg::pass_stride: the element
+    // stride 2^logs is congruent to R modulo 3, so either logs >= PSH or the eight words share one pad block)
+    __host__ __device__ static constexpr int pass_stride(int logs)
+    {
+        return logs >= PSH ? (1 << logs) + (((1 << logs) >> PSH) << R) : (1 << logs);
+    }
+    static constexpr int REM_STRIDE = T * G + ((T >> 3) << R);
+    static_assert(T % 8 == 0, "remainder-pass addressing assumes T is a multiple of 8");
     __device__ static __forceinline__ int idx_nat(int t, int r) { return t + T * r; }
     __device__ static __forceinline__ int idx_out(int t, int r)
     {
@@ -70,9 +78,10 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
         const int S = 1 << LOGS;
         const int b = t >> LOGS;
         const int base = b * (8 * S) + (t & (S - 1));
+        const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = lds[C::phys(base + S * e)];
+            for (int e = 0; e < 8; ++e) v[e] = lds[pb + ps * e];
         }
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
@@ -90,16 +99,16 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
             load_rem_tw8<LOGN, A>(w, tw, t, pre);
         if (p + 1 < C::FP || C::R > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) lds[C::phys(base + S * e)] = v[e];
+            for (int e = 0; e < 8; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
         }
     }
     if (C::R > 0) {
+        const int pg = C::phys(t * C::G);
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
-            const int g = t + C::T * c;
 #pragma unroll
-            for (int e = 0; e < C::G; ++e) v[c * C::G + e] = lds[C::phys(g * C::G + e)];
+            for (int e = 0; e < C::G; ++e) v[c * C::G + e] = lds[pg + C::REM_STRIDE * c + e];
         }
 #pragma unroll
         for (int u = 0; u < C::R; ++u) {
@@ -163,11 +172,11 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
             }
         }
         load_pass_tw8<LOGN, A>(w, itw, C::FP - 1, t, 1);
+        const int pg = C::phys(t * C::G);
 #pragma unroll
         for (int c = 0; c < C::NG; ++c) {
-            const int g = t + C::T * c;
 #pragma unroll
-            for (int e = 0; e < C::G; ++e) lds[C::phys(g * C::G + e)] = v[c * C::G + e];
+            for (int e = 0; e < C::G; ++e) lds[pg + C::REM_STRIDE * c + e] = v[c * C::G + e];
         }
         __syncthreads();
     } else {
@@ -179,9 +188,10 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
         const int S = 1 << LOGS;
         const int b = t >> LOGS;
         const int base = b * (8 * S) + (t & (S - 1));
+        const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p < C::FP - 1 || C::R > 0) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = lds[C::phys(base + S * e)];
+            for (int e = 0; e < 8; ++e) v[e] = lds[pb + ps * e];
         }
         A::inv_pass_begin(v, cx);
 #pragma unroll
@@ -201,7 +211,7 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
         if (p > 0) {
             load_pass_tw8<LOGN, A>(w, itw, p - 1, t, 1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) lds[C::phys(base + S * e)] = v[e];
+            for (int e = 0; e < 8; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
         }
     }
