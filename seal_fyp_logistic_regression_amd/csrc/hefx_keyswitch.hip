@@ -217,16 +217,17 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
 }
 
 // ------------------------------------------------------------------------------------------------
-// (3) acc[b][c][jj] = sum_i x[b][i][jj] * key[i][c][m]  (128-bit lazy accumulation, one Barrett at the end)
+// (3) acc[b][c][jj] = sum_i x[b][i][jj] * key[i][c][m]  (lazy accumulation over the digits, one reduction at the end)
 // A thread owns two adjacent coefficients of TWO consecutive items: when both use the same key (every rotation of
-// a batch by the same step, every relinearisation) the two key words are loaded once for both -- 4 loads per digit
-// instead of 6 (measured 244 -> 218 us per 192-item chunk, ~4.8 TB/s of HBM traffic; sharing across four items at
-// 96 VGPRs was no faster).  Items with different keys take the one-item path.
+// a batch by the same step, every relinearisation; the host groups a batch's items by key, hefx_capi.cpp ks_run) the
+// two key words are loaded once for both -- 4 loads per digit instead of 6 (measured 244 -> 218 us per 192-item chunk,
+// ~4.8 TB/s of HBM traffic; sharing across four items at 96 VGPRs was no faster).  Items with different keys take the
+// one-item path.
 // ------------------------------------------------------------------------------------------------
 // MAC arithmetic, one policy per target modulus (uniform per workgroup).  Each accumulates sum_i x_i * k_i for the two
-// key polynomials (k0, k1) and two adjacent coefficients (.x, .y); the instruction count is what matters -- under the
-// two-stream overlap the whole key switch is VALU-issue bound, and the 128-bit form below was a quarter of all VALU
-// instructions of the operation (SQ_INSTS_VALU, round 2):
+// key polynomials (k0, k1) and two adjacent coefficients (.x, .y).  The kernel waits for HBM either way (its own time
+// did not change), but the 128-bit form was a quarter of all VALU instructions of the operation (SQ_INSTS_VALU,
+// round 2), issue slots it took from the transform kernels of the neighbouring chunk:
 //   MacF  FP64-policy moduli (q < 2^41).  Scratch x holds the UNFINISHED transform value as a double (|x| < 2^45,
 //         hefx_ntt.cuh: no canonicalisation in the digit NTTs either); x*k mod q is the exact 6-instruction FP64 modmul
 //         with a result in (-0.52q, 0.52q), the L results add exactly, one canonicalisation at the end.
