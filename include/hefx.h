@@ -139,7 +139,9 @@ int hefx_multiply_batch(hefx_context *ctx, int L, int n, const uint64_t *const *
  *      in and out may alias (rotate_vector_inplace). */
 int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_t galois_elt,
                       const uint64_t *d_key, uint64_t *d_ct_out, void *stream);
-/* n independent (ciphertext, element, key) triples in one launch sequence. */
+/* n independent (ciphertext, element, key) triples in one launch sequence.  "Independent" is meant: no item may read
+ * another item's output (an item's own input and output may be the same buffer); the engine processes the items in an
+ * order of its choosing (grouped by key, so that neighbours share their key loads). */
 int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                             const uint32_t *galois_elts, const uint64_t *const *d_keys,
                             uint64_t *const *d_ct_out, void *stream);
