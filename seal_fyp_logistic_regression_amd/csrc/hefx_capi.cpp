@@ -923,7 +923,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     if (sub <= 0 || sub > chunk) sub = chunk;
     // fused digit-NTT + MAC kernel (no x scratch at all) when enabled and N <= 16384 (longer rows do not fit the
     // 8-coefficient-per-thread workgroup); the launcher takes sub < 0 as "fused"
-    const bool fused = c->fused && c->logn <= 14;
+    // (never for a hoisted batch: its shared digit x modulus products live in the x scratch the fused kernel does without)
+    const bool fused = c->fused && c->logn <= 14 && !hoist;
     // hoisting (explicit, hefx_*_hoisted): every item rotates the same source, decomposed once per chunk
     if (hoist) {
         if (relin) return fail(HEFX_ERR_INVALID, "hoisting applies to rotations only");
