@@ -50,9 +50,10 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 # VALU issue model (profiles/r01_valu_issue_rates.txt, tools/ubench_valu.hip): cycles one SIMD
 # spends per wave-butterfly (64 butterflies) -- Harvey/Shoup on 60-bit primes vs the exact-FMA FP64 butterfly on
 # primes < 2^41 -- and the machine: 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock.
-# Integer butterfly as built now: 21 instructions -- 7 v_mad_u64_u32 (5.65 cycles), 2 v_mul_hi_u32 (4.5), 12 others (4.0)
-# = 97 cycles (mid-round 2: 25 instructions, 105 cycles); FP64 butterfly: 8 instructions at 4.75 = 38, priced at 40.
-VALU_CYC_INT, VALU_CYC_F64 = 97.0, 40.0
+# Integer butterfly as built now (21 instructions, 7 of them v_mad_u64_u32): 81 cycles measured in isolation, 105 for the
+# form the compiler makes of x*w - h*q (tools/ubench_bfly.hip, profiles/r02_butterfly_ubench.txt; the mid-round-2 code was
+# the latter); FP64 butterfly: 8 instructions at 4.75 = 38, priced at 40.
+VALU_CYC_INT, VALU_CYC_F64 = 81.0, 40.0
 SIMDS, CLOCK_HZ = 1024, 2.4e9
 
 

@@ -1,0 +1,122 @@
+// Micro-benchmark: the integer Cooley-Tukey butterfly of hefx_ntt.cuh (ArithU64::ct) in its two forms, on gfx950.
+//   form 0  what the compiler makes of  t = y*w - hi(y*w')*q;  a = csub(x, 4q) on the borrow;  x' = a + t;  y' = a + 4q - t
+//   form 1  the tree's form: t = y*w + h*(2^64 - q) as six v_mad_u64_u32 and one 32-bit add, a = x + (2^64 - 4q) / compare /
+//           two selects (hefx_modarith.cuh: mul_sub_lo64, csubn)
+// Every thread runs radix-16 passes over sixteen registers with one (uniform) twiddle per round; 4 waves per SIMD on every
+// CU, like the transform kernels.  Prints nanoseconds and SIMD cycles (at 2.4 GHz) per wave-butterfly.
+// build + run (GPU box):  hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_bfly.hip -o gpurun_out/ubench_bfly && gpurun_out/ubench_bfly
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+typedef unsigned long long u64;
+
+__device__ __forceinline__ u64 under2(u64 x, u64 ws)
+{
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)ws, w1 = (uint32_t)(ws >> 32);
+    return (u64)x1 * w1 + ((u64)__umulhi(x0, w1) + (u64)__umulhi(x1, w0));
+}
+__device__ __forceinline__ u64 csub(u64 x, u64 m)
+{
+    u64 d;
+    return __builtin_usubll_overflow(x, m, &d) ? x : d;
+}
+__device__ __forceinline__ u64 csubn(u64 x, u64 nm)
+{
+    const u64 d = x + nm;
+    return d > x ? x : d;
+}
+__device__ __forceinline__ u64 mul_sub_lo64(u64 x, u64 w, u64 h, u64 nq)
+{
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    const uint32_t h0 = (uint32_t)h, h1 = (uint32_t)(h >> 32);
+    uint32_t n0 = (uint32_t)nq, n1 = (uint32_t)(nq >> 32);
+    asm("" : "+v"(n0), "+v"(n1));
+    u64 u = (u64)x0 * w1;
+    u = (u64)x1 * w0 + u;
+    u = (u64)h0 * n1 + u;
+    u = (u64)h1 * n0 + u;
+    asm("" : "+v"(u));
+    u64 a = (u64)x0 * w0;
+    a = (u64)h0 * n0 + a;
+    uint32_t ahi;
+    asm("v_add_u32 %0, %1, %2" : "=v"(ahi) : "v"((uint32_t)(a >> 32)), "v"((uint32_t)u));
+    return (u64)(uint32_t)a | ((u64)ahi << 32);
+}
+
+template <int FORM>
+__global__ __launch_bounds__(256) void k(u64 *p, const ulonglong2 *tw, u64 q, u64 nq, int rounds)
+{
+    u64 v[16];
+    u64 *mine = p + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    for (int i = 0; i < 16; ++i) v[i] = mine[i];
+    const u64 q4 = 4 * q, nq4 = nq << 2;
+    for (int r = 0; r < rounds; ++r) {
+        const ulonglong2 w = tw[r & 63];
+#pragma unroll
+        for (int s = 8; s >= 1; s >>= 1)
+#pragma unroll
+            for (int i = 0; i < 16; ++i)
+                if (!(i & s)) {
+                    u64 a, t;
+                    if (FORM == 0) {
+                        a = csub(v[i], q4);
+                        t = v[i + s] * w.x - under2(v[i + s], w.y) * q;
+                    } else {
+                        a = csubn(v[i], nq4);
+                        t = mul_sub_lo64(v[i + s], w.x, under2(v[i + s], w.y), nq);
+                    }
+                    v[i] = a + t;
+                    v[i + s] = a + q4 - t;
+                }
+    }
+    for (int i = 0; i < 16; ++i) mine[i] = v[i];
+}
+
+template <int FORM>
+static double run(u64 *d, const ulonglong2 *tw, u64 q, int rounds, int blocks)
+{
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0);
+    hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<FORM>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, rounds);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int it = 0; it < 5; ++it) hipLaunchKernelGGL(k<FORM>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, rounds);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    return ms / 5;
+}
+
+int main()
+{
+    const u64 q = 0xffffffffffd8001ull;
+    const int blocks = 256 * 4, rounds = 512;  // 4 workgroups of 4 waves per CU: 4 waves per SIMD
+    u64 *d;
+    ulonglong2 *tw;
+    hipMalloc(&d, (size_t)blocks * 256 * 16 * 8);
+    hipMalloc(&tw, 64 * sizeof(ulonglong2));
+    std::vector<u64> h((size_t)blocks * 256 * 16);
+    u64 s = 88172645463325252ull;
+    for (auto &x : h) {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        x = s % q;
+    }
+    hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+    std::vector<ulonglong2> ht(64);
+    for (auto &t : ht) {
+        s ^= s << 13, s ^= s >> 7, s ^= s << 17;
+        t.x = s % q;
+        t.y = (u64)(((unsigned __int128)t.x << 64) / q);
+    }
+    hipMemcpy(tw, ht.data(), 64 * sizeof(ulonglong2), hipMemcpyHostToDevice);
+    const double wave_bf = (double)blocks * 4 * rounds * 32 / (256.0 * 4);  // wave-butterflies per SIMD
+    const double m0 = run<0>(d, tw, q, rounds, blocks), m1 = run<1>(d, tw, q, rounds, blocks);
+    printf("compiler's form : %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", m0, m0 * 1e6 / wave_bf,
+           m0 * 1e-3 * 2.4e9 / wave_bf);
+    printf("multiply-add form: %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", m1, m1 * 1e6 / wave_bf,
+           m1 * 1e-3 * 2.4e9 / wave_bf);
+    return 0;
+}
