@@ -819,13 +819,22 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
 #endif
         constexpr int GS = HEFX_EPI, NG = 16 / GS, NBUF = HEFX_EPI_PIPE ? 2 : 1;
         u64 a[NBUF][GS], sadd[NBUF][GS], pp[NBUF][GS];
+        // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
+        // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
+        static_assert(C::R >= 1 && GS % 2 == 0, "record layout");
         auto fetch = [&](int g, int bufi) {
 #pragma unroll
-            for (int r = 0; r < GS; ++r) {
+            for (int r = 0; r < GS; r += 2) {
                 const int idx = C::idx_io(t, GS * g + r);
-                a[bufi][r] = acc[idx];
-                sadd[bufi][r] = addin(idx);
-                pp[bufi][r] = pt ? pt[idx] : 0;
+                const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+                ulonglong2 sv = make_ulonglong2(0, 0);
+                if (has_add)
+                    sv = elt == 1u ? *reinterpret_cast<const ulonglong2 *>(addrow + off + idx)
+                                   : gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
+                const ulonglong2 pv = pt ? *reinterpret_cast<const ulonglong2 *>(pt + idx) : make_ulonglong2(0, 0);
+                a[bufi][r] = av.x, a[bufi][r + 1] = av.y;
+                sadd[bufi][r] = sv.x, sadd[bufi][r + 1] = sv.y;
+                pp[bufi][r] = pv.x, pp[bufi][r + 1] = pv.y;
             }
         };
         if (HEFX_EPI_EARLY) {
