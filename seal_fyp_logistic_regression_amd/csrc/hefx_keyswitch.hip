@@ -849,9 +849,13 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
             const int cur = HEFX_EPI_PIPE ? (g & 1) : 0;
             if (HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
 #pragma unroll
-            for (int r = 0; r < GS; ++r)
-                dst[C::idx_io(t, GS * g + r)] =
-                    md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], pt != nullptr, cx, T, sp, j, mc);
+            for (int r = 0; r < GS; r += 2) {  // one 16-byte store per record
+                ulonglong2 o;
+                o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], pt != nullptr, cx, T, sp, j, mc);
+                o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], pt != nullptr, cx,
+                                  T, sp, j, mc);
+                *reinterpret_cast<ulonglong2 *>(dst + C::idx_io(t, GS * g + r)) = o;
+            }
             if (!HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, 0);
         }
     }
