@@ -1020,19 +1020,30 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * QC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * QC::N + off;
     // the epilogue's operands do not depend on the transform: fetched before it, they travel while it runs
+    // (registers (r, r+1), r even, are one 16-byte record in every idx_out layout: one gathered pair per record)
     u64 a[8], sadd[8], pp[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < 8; r += 2) {
         const int idx = C::idx_out(t, r);
-        a[r] = acc[idx];
-        sadd[r] = !has_add ? 0 : addrow[elt == 1u ? (uint32_t)(off + idx) : galois_index((uint32_t)(off + idx), elt, LOGN)];
-        pp[r] = pt ? pt[idx] : 0;
+        const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+        ulonglong2 sv = make_ulonglong2(0, 0);
+        if (has_add)
+            sv = elt == 1u ? *reinterpret_cast<const ulonglong2 *>(addrow + off + idx)
+                           : gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
+        const ulonglong2 pv = pt ? *reinterpret_cast<const ulonglong2 *>(pt + idx) : make_ulonglong2(0, 0);
+        a[r] = av.x, a[r + 1] = av.y;
+        sadd[r] = sv.x, sadd[r + 1] = sv.y;
+        pp[r] = pv.x, pp[r + 1] = pv.y;
     }
     typename A::V f[8];
     quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
 #pragma unroll
-    for (int r = 0; r < 8; ++r)
-        dst[C::idx_out(t, r)] = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+    for (int r = 0; r < 8; r += 2) {
+        ulonglong2 o;
+        o.x = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
+        o.y = md_epilogue(A{}, f[r + 1], a[r + 1], sadd[r + 1], pp[r + 1], pt != nullptr, cx, T, sp, j, mc);
+        *reinterpret_cast<ulonglong2 *>(dst + C::idx_out(t, r)) = o;
+    }
 }
 
 template <int LOGN>
