@@ -165,16 +165,37 @@ def launch(args) -> int:
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
+    # poll: a rank that dies before or inside a barrier / collective leaves its peers blocked in RCCL for ever, so the
+    # first non-zero exit ends the others after a short grace period and its code is the run's
     rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
+    live = list(procs)
+    failed_at = None
+    while live:
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0:
+                rc = rc or abs(code) or 1
+                failed_at = failed_at or time.monotonic()
+        if failed_at is not None and live and time.monotonic() - failed_at > 15.0:
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+        time.sleep(0.2)
     return rc
 
 
 # ------------------------------------------------------------------------------------------------------------------
 # the sharded linear transform (SURVEY 8d "Scaling runs", 8e-i)
 # ------------------------------------------------------------------------------------------------------------------
-def lt_sharded_bench(local_rank: int, world: int, dims, reps: int):
+def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int = 0):
     """Linear_Transform_Plain at C3 with the reference's default (power-of-two, NAF-expanded) Galois keys: the serial
     one-call form on this rank, and -- with more than one rank -- the diagonal-sharded form with its one all-reduce.
     Same seeds on every rank => same keys, ciphertext and diagonals everywhere (what a broadcast at setup would give)."""
@@ -251,6 +272,32 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int):
                     except Exception:
                         pass
         out[f"d{d}"] = rec
+    # Linear_Transform_Plain with a DIRECT Galois key per step (keygen.galois_keys(steps)): d - 1 key switches, each with
+    # its own 7.9 MB key -- at d = 512 that is 4 GB of keys, the key-streaming case of SURVEY H5 (bit-exact to the
+    # op-by-op sequence with those keys; serial, rank-local)
+    if direct_d:
+        d = direct_d
+        rng = np.random.default_rng(2000 + d)
+        M, v = rng.uniform(-1, 1, (d, d)), rng.uniform(-1, 1, d)
+        diags = encoder.encode_many(list(alg.get_all_diagonals(M)), scale)
+        ct = enc.encrypt(encoder.encode(v, scale))
+        gk_direct = kg.galois_keys([-d] + list(range(1, d)))
+        r = alg.linear_transform_plain(ev, ct, diags, gk_direct)
+        eng.sync()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = alg.linear_transform_plain(ev, ct, diags, gk_direct)
+            eng.sync()
+            ts.append(time.perf_counter() - t0)
+        ms = sorted(ts)[len(ts) // 2] * 1e3
+        ks = alg_key_switches(ev, d, gk_direct)
+        kb = (len(primes) - 1) * 2 * len(primes) * N * 8
+        out[f"direct_keys_d{d}"] = {
+            "serial_ms": ms, "key_switches": ks, "galois_keys": len(gk_direct.keys), "key_bytes": len(gk_direct.keys) * kb,
+            "key_switches_per_s": ks / (ms * 1e-3), "key_GBps": ks * kb / (ms * 1e-3) / 1e9,
+            "decrypts_to_Mv": bool(np.allclose(encoder.decode(dec.decrypt(r))[:d].real, M @ v, atol=1e-3 * d))}
+        del gk_direct
     return out
 
 
@@ -270,6 +317,10 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline budget (0 disables)")
     ap.add_argument("--lt", default="16,512", help="dimensions of the (sharded) linear-transform leg; '' disables")
     ap.add_argument("--variant-keys", type=int, default=16, help="distinct Galois keys of the secondary pass; 0 disables")
+    ap.add_argument("--stream-keys", type=int, default=64, help="distinct Galois keys of the key-streaming pass (> 256 MiB "
+                    "of keys at C3); 0 disables")
+    ap.add_argument("--lt-direct", type=int, default=512, help="dimension of the direct-key Linear_Transform_Plain leg "
+                    "(one Galois key per step: 4 GB of keys at d = 512, C3); 0 disables")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -362,15 +413,17 @@ def main():
 
     dt, gpu_ms = timed(step, args.steps, args.warmup)
 
-    # what was timed is checked: first and last item of the batch against the CPU oracle (rank 0)
-    verified = None
+    # what was timed is checked: one item of EVERY chunk of the launch sequence (the engine cuts the batch into chunks of
+    # at most 256 items on alternating internal streams) plus the last item, word for word against the CPU oracle (rank 0)
+    verified, verified_items = None, []
     if rank == 0:
         try:
             from oracle import oracle as O
             o = O.Oracle(N, primes)
             hk = keyv[0].download()
+            verified_items = sorted({min(c0 + (7 * (c0 // 256)) % 256, B - 1) for c0 in range(0, B, 256)} | {0, B - 1})
             verified = all(bool((outs[i].download() == o.rotate_mulplain(cts[i].download(), 3, hk, pts[i].download())).all())
-                           for i in (0, B - 1))
+                           for i in verified_items)
         except Exception as ex:  # the oracle is the checker only; its absence must not hide the GPU number
             verified = f"not checked: {ex!r}"
 
@@ -383,13 +436,31 @@ def main():
     # steps with distinct keys: no key sharing between neighbouring items, nk keys competing for the caches)
     variants = {}
     if args.variant_keys > 1:
-        from oracle import oracle as O
-        velts = [O.galois_elt_from_step(N, 1 + (i % nk)) for i in range(B)]
+        from seal_fyp_logistic_regression_amd.seal import galois_elt_from_step
+        velts = [galois_elt_from_step(1 + (i % nk), N) for i in range(B)]
         vkeys = [keyv[i % nk] for i in range(B)]
         vsteps = max(3, args.steps // 10)
         vdt, _ = timed(lambda: e.rotate_multiply_plain_batch(L, cts, velts, vkeys, pts, outs), vsteps, 1)
         variants[f"distinct_keys_{nk}"] = {"value": B * vsteps * world / vdt, "steps": vsteps,
+                                           "key_bytes": nk * key_words * 8,
                                            "note": f"steps 1..{nk} round-robin, one uniform-random key each"}
+    # key-streaming regime: enough distinct keys that they cannot live in the 256 MiB Infinity Cache, so
+    # every key switch really pays its 2L(L+1)N key words from HBM -- the case `roofline.frac` prices
+    if args.stream_keys > 1:
+        from seal_fyp_logistic_regression_amd.seal import galois_elt_from_step
+        ns = args.stream_keys
+        skey = e.sample("uniform", hashlib.sha256(b"hefx-bench:stream-keys").digest(), 5, 2 * L * ns, k, 0)
+        skeyv = [skey.view(i * key_words, (L, 2, k, N)) for i in range(ns)]
+        selts = [galois_elt_from_step(1 + (i % ns), N) for i in range(B)]
+        skeys = [skeyv[i % ns] for i in range(B)]
+        ssteps = max(3, args.steps // 10)
+        sdt, sgpu = timed(lambda: e.rotate_multiply_plain_batch(L, cts, selts, skeys, pts, outs), ssteps, 1)
+        variants[f"key_streaming_{ns}"] = {
+            "value": B * ssteps * world / sdt, "steps": ssteps, "key_bytes": ns * key_words * 8,
+            "achieved_GBps_algorithmic": B * algorithmic_bytes_per_op(N, L) / (sgpu / ssteps * 1e-3) / 1e9,
+            "note": f"{ns} distinct keys = {ns * key_words * 8 / 2**20:.0f} MiB > the 256 MiB Infinity Cache: every "
+                    "group of items streams its key from HBM (items are processed grouped by key)"}
+        del skey, skeyv, skeys
 
     line = None
     if rank == 0:
@@ -402,7 +473,7 @@ def main():
         # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
         traffic, traffic_src = None, None
-        for rnd in ("r02", "r01"):
+        for rnd in ("r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_bench_pmc_traffic.json")
             if args.set == "C3" and os.path.exists(pmc):
                 try:
@@ -431,6 +502,7 @@ def main():
             "dtype": "u64",
             "data": "synthetic",
             "verified": verified,
+            "verified_items": verified_items,
             "config": {
                 "workload": f"{args.set}: N={N}, coeff_modulus bits "
                             f"{[p.bit_length() for p in primes]}, level L={L} (k={k}); per step and per GPU "
@@ -449,6 +521,16 @@ def main():
                 "traffic": traffic,
                 "traffic_source": traffic_src,
                 "algorithmic_GB_per_step": B * bytes_op / 1e9,  # same basis as `traffic` (one step = one launch sequence)
+                # what the HBM really does: measured traffic / step time against the same peak, and the
+                # bytes the unit cannot avoid once the shared Galois key lives in the caches (ct in 2LN + pt LN + ct out
+                # 2LN words) with the ratio of measured traffic to them
+                "hbm_measured": None if traffic is None else {
+                    "GBps": traffic / (step_ms * 1e-3), "frac_of_peak": traffic / (step_ms * 1e-3) / HBM_PEAK_GBS,
+                    "frac_of_achievable_6300": traffic / (step_ms * 1e-3) / 6300.0,
+                    "bytes_per_op": traffic * 1e9 / B,
+                    "over_algorithmic": traffic * 1e9 / B / bytes_op,
+                    "over_compulsory_cache_adjusted": traffic * 1e9 / B / (8 * N * L * 5)},
+                "compulsory_bytes_per_op_cache_adjusted": 8 * N * L * 5,
                 "launch": "one step = the key-switch launch sequence over the whole batch "
                           f"({nchunks} chunks); achieved = {B} ops x {bytes_op} B / {step_ms:.3f} ms (HIP events)",
                 "dominant_kernel": dom,
@@ -493,17 +575,17 @@ def main():
         dims = [int(x) for x in args.lt.split(",") if x]
         del big_ct, big_pt, big_out, cts, pts, outs
 
-        def bail():
+        def bail():  # the headline line still goes out, but a wedged exchange is a FAILED run: exit 3 on every rank
             if rank == 0:
                 line["lt_sharded"] = {"error": "timed out after 300 s (the headline measurement is unaffected)"}
                 emit()
-            os._exit(0)
+            os._exit(3)
 
         dog = threading.Timer(300.0, bail)
         dog.daemon = True
         dog.start()
         try:
-            lt = lt_sharded_bench(local_rank, world, dims, reps=3)
+            lt = lt_sharded_bench(local_rank, world, dims, reps=3, direct_d=args.lt_direct)
         except Exception as ex:
             lt = {"error": repr(ex)[:400]}
         dog.cancel()

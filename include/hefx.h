@@ -141,7 +141,9 @@ int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_
                       const uint64_t *d_key, uint64_t *d_ct_out, void *stream);
 /* n independent (ciphertext, element, key) triples in one launch sequence.  "Independent" is meant: no item may read
  * another item's output (an item's own input and output may be the same buffer); the engine processes the items in an
- * order of its choosing (grouped by key, so that neighbours share their key loads). */
+ * order of its choosing (grouped by key, so that neighbours share their key loads).  A batch that breaks the rule --
+ * d_ct_in[j] == d_ct_out[i] for i != j, or two items with the same output -- is refused with HEFX_ERR_INVALID before
+ * anything is submitted. */
 int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                             const uint32_t *galois_elts, const uint64_t *const *d_keys,
                             uint64_t *const *d_ct_out, void *stream);

@@ -17,6 +17,7 @@
 #include <vector>
 
 #include <dlfcn.h>
+#include <link.h>
 
 #include "hefx_internal.h"
 
@@ -202,10 +203,11 @@ struct hefx_context {
     KsProf prof{nullptr, nullptr, 0, 0};
     size_t prof_chunks = 0;
     int sub = 0;  // items per K2+MAC sub-chunk; 0 = auto (HEFX_SUB overrides)
-    // fused digit-NTT + MAC kernel (HEFX_FUSED=1).  Off by default: bit-exact, removes the x scratch entirely, but at
-    // N=16384 its 1024-thread workgroup spills (64 VGPRs of accumulators + transform state under the 128 cap) and
-    // measured 1.75x slower than the two-kernel path on MI355X (profiles/README.md).
+    // hybrid fused digit-NTT + MAC kernel (ks_ntt_macf_kernel): the FP64-policy target moduli accumulate their key
+    // products in registers, only the integer-policy targets' digit x modulus products travel through scratch x.
+    // HEFX_FUSED=0/1 overrides the default.
     bool fused = false;
+    std::vector<uint8_t> is_f64;  // per prime: FP64 policy in use (mirror of T.modsf[j].q != 0)
 };
 
 static int ensure_scratch(hefx_context *c, size_t words)
@@ -324,7 +326,10 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         // FP64 policy (exact FMA modmul) for primes below 2^41; HEFX_NO_FP64=1 forces the integer policy
         ModConstF &f = modsf[j];
         memset(&f, 0, sizeof f);
+        c->is_f64.resize((size_t)k);
+        c->is_f64[(size_t)j] = 0;
         if ((q >> 41) == 0 && !getenv("HEFX_NO_FP64")) {
+            c->is_f64[(size_t)j] = 1;
             const double qd = (double)q;
             f.q = qd;
             f.qinv = 1.0 / qd;
@@ -924,7 +929,16 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // fused digit-NTT + MAC kernel (no x scratch at all) when enabled and N <= 16384 (longer rows do not fit the
     // 8-coefficient-per-thread workgroup); the launcher takes sub < 0 as "fused"
     // (never for a hoisted batch: its shared digit x modulus products live in the x scratch the fused kernel does without)
-    const bool fused = c->fused && c->logn <= 14 && !hoist;
+    bool fused = c->fused && c->logn <= 14 && !hoist;
+    int fused_code = 0;
+    if (fused) {
+        int nf = 0;
+        for (int j = 0; j < L; ++j) nf += c->is_f64[(size_t)j];
+        const bool special_f = c->is_f64[(size_t)c->k - 1];
+        nf += special_f;
+        fused_code = nf | ((special_f ? 0 : 1) << 8);
+        if (nf == 0) fused = false;  // nothing to fuse: every target modulus is integer-policy
+    }
     // hoisting (explicit, hefx_*_hoisted): every item rotates the same source, decomposed once per chunk
     if (hoist) {
         if (relin) return fail(HEFX_ERR_INVALID, "hoisting applies to rotations only");
@@ -946,6 +960,23 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             any_alias |= ct_in[i] == ct_out[i];
         }
     }
+    // Items run in key-grouped order on several internal streams, so no item may read another item's output: a
+    // dependent chain handed over as ONE batch (ct_out[i] == ct_in[j], i != j) would silently give wrong bits.  Refused
+    // here, before anything is submitted (O(n) on the host).  An item's own in-place rotation (i == j) is fine, and so
+    // are items that share a source.
+    if (n > 1) {
+        std::unordered_map<const void *, int> outs;
+        outs.reserve((size_t)n * 2);
+        for (int i = 0; i < n; ++i) {
+            auto ins = outs.emplace((const void *)ct_out[i], i);
+            if (!ins.second) return fail(HEFX_ERR_INVALID, "two items of a key-switch batch write the same output");
+        }
+        for (int j = 0; j < n; ++j) {
+            auto it = outs.find((const void *)ct_in[j]);
+            if (it != outs.end() && it->second != j)
+                return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: one item's input is another item's output");
+        }
+    }
     // The items of a batch are independent, so they are PROCESSED grouped by key (stable order inside a group): items
     // that share a Galois key become neighbours -- the MAC loads the key once for two neighbours, and a chunk touches
     // few keys, which then stay in L2 / Infinity Cache.  A linear transform's rotations arrive step by step, i.e. keys
@@ -962,9 +993,9 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     }
     auto src = [&](int i) { return ord.empty() ? i : ord[(size_t)i]; };
     const int cmax = n < chunk ? n : chunk;
-    const size_t half_words = per * (size_t)cmax + (fused ? 0 : ks_x_words(c, L, sub < cmax ? sub : cmax)) +
-                              (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
+    const size_t x_words = ks_x_words(c, L, fused || sub > cmax ? cmax : sub);
+    const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (two) {
@@ -995,7 +1026,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         S.acc = S.d + (size_t)cnt * L * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.x = S.u + (size_t)cnt * 2 * N;
-        S.alias = S.x + (fused ? 0 : ks_x_words(c, L, sub < cnt ? sub : cnt));
+        S.alias = S.x + ks_x_words(c, L, fused || sub > cnt ? cnt : sub);
         bool chunk_alias = false;
         for (int i = 0; i < cnt; ++i) {
             KsItem &it = hb[i];
@@ -1039,7 +1070,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         const bool quarter = small && !fused && nchunks == 1 &&
                              (quarter_force >= 0 ? quarter_force != 0 : cnt * 2 * L * (L + 1) <= 256);
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
-        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 : sub, hoist, chunk_alias, small ? hb : nullptr,
+        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, hoist, chunk_alias, small ? hb : nullptr,
                                       quarter, cs, prof));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
@@ -1240,13 +1271,29 @@ RcclApi &rccl()
     static RcclApi api = [] {
         RcclApi a;
         void *h = nullptr;
+        // The copy the process already uses, if any -- found by walking the loaded objects, because a host such as
+        // torch maps its own build by path / RPATH (torch/lib/librccl.so), which a bare-name RTLD_NOLOAD lookup misses;
+        // two RCCL builds in one process is what this avoids.
+        std::string mapped;
+        dl_iterate_phdr(
+            [](struct dl_phdr_info *info, size_t, void *out) -> int {
+                const char *nm = info->dlpi_name;
+                if (nm && strstr(nm, "librccl.so")) {
+                    *static_cast<std::string *>(out) = nm;
+                    return 1;
+                }
+                return 0;
+            },
+            &mapped);
+        if (!mapped.empty()) h = dlopen(mapped.c_str(), RTLD_NOW | RTLD_NOLOAD);
         for (const char *name : {"librccl.so.1", "librccl.so"}) {
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);  // the copy the process already uses, if any
             if (h) break;
+            h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
         }
+        // none loaded yet: load one privately (RTLD_LOCAL: its symbols must not interpose on a copy loaded later)
         for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             if (h) break;
-            h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
         }
         if (!h) {
             a.why = std::string("librccl not found: ") + (dlerror() ? dlerror() : "");

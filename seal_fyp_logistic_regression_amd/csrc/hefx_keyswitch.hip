@@ -176,12 +176,11 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 // (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
-                                                                             int item0, int stream_x, KsScratch S)
+__device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int rows, int item0, int stream_x,
+                                              const KsScratch &S, u64 *lds)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
-    extern __shared__ __align__(16) u64 lds[];
     int g, jj, h;
     group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
     if (g >= rows) return;
@@ -380,6 +379,22 @@ struct MacF {
     }
 };
 
+__device__ __forceinline__ bool slot_is_f64(const DevTables &T, int L, int jj)
+{
+    return T.modsf[jj < L ? jj : T.k - 1].q != 0.0;
+}
+// the y-th integer-policy target slot among 0..L (block-uniform scalar loop)
+__device__ __forceinline__ int nth_int_slot(const DevTables &T, int L, int y)
+{
+    int jj = 0;
+    for (;; ++jj) {
+        if (slot_is_f64(T, L, jj)) continue;
+        if (y == 0) break;
+        --y;
+    }
+    return jj;
+}
+
 // policy of target modulus m in a key switch over L digits (block-uniform); f(policy tag) runs the templated body
 template <class F>
 __device__ __forceinline__ void mac_dispatch(const DevTables &T, int m, int L, const F &f)
@@ -432,15 +447,14 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
     }
 }
 
+// one MAC unit: target slot jj, the item pair (bl0, bl0 + 1) of the (sub-)chunk, pair index w of the row
 template <bool STREAM>
-__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
-                                                     int item0, int count, KsScratch S)
+__device__ __forceinline__ void mac_unit(const DevTables &T, const KsItem *__restrict__ items, int L, int relin, int item0,
+                                         int count, const KsScratch &S, int jj, int bl0, size_t w)
 {
     const int logn = T.logn;
     const size_t n = (size_t)1 << logn;
-    const int jj = blockIdx.y, bl0 = 2 * blockIdx.z;
     const int m = jj < L ? jj : T.k - 1;
-    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
     // digit i in slot jj: its transform to that modulus from scratch x -- or, for its own prime (i == jj), the
     // Galois-permuted input row itself, gathered from the source ciphertext
     auto xload = [&](int bl, int i, size_t ww) -> ulonglong2 {
@@ -470,6 +484,24 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
             if (k1) mac_items<P, 1, STREAM>(T, k1, L, jj, m, n, w, bl0 + 1, xload, accrow);
         }
     });
+}
+
+template <bool STREAM>
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+                                                     int item0, int count, int int_only, KsScratch S)
+{
+    // int_only: the FP64-policy target slots were accumulated by ks_ntt_macf_kernel; blockIdx.y counts the others
+    const int jj = int_only ? nth_int_slot(T, L, blockIdx.y) : (int)blockIdx.y;
+    mac_unit<STREAM>(T, items, L, relin, item0, count, S, jj, 2 * blockIdx.z, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// (2) as a launch
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_digits_kernel(DevTables T, int L, int rows,
+                                                                             int item0, int stream_x, KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    ntt_digit_row<LOGN>(T, L, rows, item0, stream_x, S, lds);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -588,12 +620,19 @@ __global__ __launch_bounds__(256) void lt2_c0_kernel(DevTables T, const KsItem *
 }
 
 // ------------------------------------------------------------------------------------------------
-// (2+3 fused) acc[b][c][jj] = sum_i NTT_m([d[b][i]]_m) * key[i][c][m] for one half h of one target modulus jj:
-// the workgroup walks the L digits, transforms each one (8 coefficients per thread, hefx_ntt8.cuh) and multiplies
-// the result straight into two 128-bit accumulators per coefficient that live in registers for the whole loop.
-// The digit x modulus products ("x", L(L+1) rows per item -- the largest scratch array of the unfused path, written
-// by (2) and re-read by (3) at HBM speed) are never stored.  All 2(L+1) workgroups of an item share an XCD, so the
-// L digit rows they all read are served by that XCD's L2.
+// (2+3 fused, hybrid) -- the digit x modulus products of the FP64-policy target moduli are never stored.
+// One launch, two kinds of workgroup (N/16 threads, eight coefficients per thread, hefx_ntt8.cuh):
+//   role F  (item b, FP64 target slot jj, half h): walks the L digits, transforms each one to modulus m in the FP64
+//           policy and multiplies the UNFINISHED transform value straight into two FP64 accumulators per coefficient
+//           (MacF arithmetic: the exact six-instruction modmul, |term| < 0.52 q, the L terms add exactly) that live in
+//           registers for the whole loop -- 32 VGPRs, where the 128-bit accumulators of a 60-bit target need 64 and
+//           spilled (round 2).  acc[b][c][jj] = canon(sum_i NTT_m([d_i]_m) * key[i][c][m]), the same integer sum as
+//           ks_ntt_digits + ks_mac, hence the same bits.
+//   role I  (item b, digit i, integer-policy target slot jj != i, half h): the plain digit transform, canonical words
+//           to scratch x -- only these rows still travel (9 of 25 at C3); ks_mac_kernel then runs over the integer
+//           target slots alone (int_only).
+// All workgroups of an item share an XCD (the L digit rows they read are then served by that XCD's L2); the long
+// role-F workgroups of an item come first.  x traffic per op at C3: 25 rows written + 25 read -> 9 + 9.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 struct FusedCfg {
@@ -603,77 +642,129 @@ struct FusedCfg {
     static constexpr int T = C::T;  // N/16 threads
     static constexpr size_t LDS_BYTES = sizeof(u64) * C::LDS_WORDS;
 };
-
 template <int LOGN>
-__global__ __launch_bounds__(FusedCfg<LOGN>::T, (FusedCfg<LOGN>::T >= 1024 ? 4 : 2)) void ks_ntt_mac_kernel(
-    DevTables T, const KsItem *__restrict__ items, int L, int relin, int groups, KsScratch S)
+__global__ __launch_bounds__(FusedCfg<LOGN>::T, 4) void ks_ntt_macf_kernel(DevTables T, const KsItem *__restrict__ items, int L,
+                                                                         int relin, int groups, int nf, int per_item,
+                                                                         int stream_x, KsScratch S)
 {
     using FC = FusedCfg<LOGN>;
     using C = typename FC::C;
     extern __shared__ __align__(16) u64 lds[];
-    int b, jj, h;
-    group_decode(blockIdx.x, L + 1, b, jj, h);  // b = item; jj = target modulus slot (L = special prime)
+    const int xq = blockIdx.x & 7, rest = blockIdx.x >> 3;
+    const int slot = rest % per_item, b = (rest / per_item) * 8 + xq;
     if (b >= groups) return;
     const int t = threadIdx.x;
+    const int h = slot & 1, role = slot >> 1;
+    const size_t off = (size_t)h * FC::H;
+    static_assert(C::T % 2 == 0, "EO loader assumes an even thread count");
+    // coefficient j = idx_nat(t, r) = t + T r of a row stored [evens | odds]: parity is the thread's
+    const uint32_t e0 = (uint32_t)((t & 1) * FC::H + (t >> 1));
+    if (role < nf) {
+        // ---- role F ----
+        int jj = 0;
+        for (int cnt = 0;; ++jj) {
+            if (!slot_is_f64(T, L, jj)) continue;
+            if (cnt == role) break;
+            ++cnt;
+        }
+        const int m = jj < L ? jj : T.k - 1;
+        const ModConst mc = T.mods[m];
+        const ArithF64::Ctx cx = ArithF64::make(T.modsf[m]);
+        const double *__restrict__ tw = T.twf + ((size_t)m << LOGN);
+        const KsItem it = items[b];
+        double a0[8], a1[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a0[r] = a1[r] = 0.0;
+        for (int i = 0; i < L; ++i) {
+            double f[8];
+            if (i == jj) {  // the digit in NTT form modulo its own prime: the (rotated) input row itself
+                const u64 *__restrict__ xr = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * FC::N;
+                const uint32_t elt = relin ? 1u : item_elt(it);
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) {
+                    const uint32_t rec = (uint32_t)((off + C::idx_out(t, r)) >> 1);
+                    const ulonglong2 v = elt == 1u ? reinterpret_cast<const ulonglong2 *>(xr)[rec] : gather_pair(xr, rec, elt, LOGN);
+                    f[r] = ArithF64::from_u64(v.x);
+                    f[r + 1] = ArithF64::from_u64(v.y);
+                }
+            } else {
+                const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * FC::N;
+                const InMode mode = {false, T.modsf[i].q == 0.0, false, 0};
+                auto ld = [&](int r, u64 &x, u64 &y) {
+                    const uint32_t e = e0 + (uint32_t)(C::T / 2) * (uint32_t)r;
+                    x = dd[e];
+                    y = dd[e + FC::H / 2];
+                };
+                split8_fwd_raw<LOGN, ArithF64>(f, ld, mode, mc, lds, tw, cx, t, h);
+            }
+            const u64 *__restrict__ k0 = it.key + ((size_t)i * 2 * T.k + m) * FC::N + off;
+            const u64 *__restrict__ k1 = k0 + (size_t)T.k * FC::N;
+            HEFX_STAGE_FENCE();  // keeps the key loads (32 VGPRs) from being hoisted above the transform
+            ulonglong2 kv0[4], kv1[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                kv0[r] = *reinterpret_cast<const ulonglong2 *>(k0 + C::idx_out(t, 2 * r));
+                kv1[r] = *reinterpret_cast<const ulonglong2 *>(k1 + C::idx_out(t, 2 * r));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a0[2 * r] += ArithF64::mm(f[2 * r], ArithF64::from_u64(kv0[r].x), cx);
+                a0[2 * r + 1] += ArithF64::mm(f[2 * r + 1], ArithF64::from_u64(kv0[r].y), cx);
+                a1[2 * r] += ArithF64::mm(f[2 * r], ArithF64::from_u64(kv1[r].x), cx);
+                a1[2 * r + 1] += ArithF64::mm(f[2 * r + 1], ArithF64::from_u64(kv1[r].y), cx);
+            }
+            // the next digit's first exchange reuses the LDS words this transform's last pass read
+            if (i != jj) __syncthreads();
+        }
+        u64 *__restrict__ o0 = S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * FC::N + off;
+        u64 *__restrict__ o1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * FC::N + off;
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            *reinterpret_cast<ulonglong2 *>(o0 + C::idx_out(t, r)) =
+                make_ulonglong2(ArithF64::canon(a0[r], cx), ArithF64::canon(a0[r + 1], cx));
+            *reinterpret_cast<ulonglong2 *>(o1 + C::idx_out(t, r)) =
+                make_ulonglong2(ArithF64::canon(a1[r], cx), ArithF64::canon(a1[r + 1], cx));
+        }
+        return;
+    }
+    // ---- role I ----
+    int rr = role - nf, jj = 0;
+    for (;; ++jj) {
+        if (slot_is_f64(T, L, jj)) continue;
+        const int nd = jj < L ? L - 1 : L;  // digits that are transformed to this slot
+        if (rr < nd) break;
+        rr -= nd;
+    }
+    int i = rr;
+    if (jj < L && i >= jj) ++i;
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
-    const ModConstF mf = T.modsf[m];
-    const NttTables nt = ntt_tables(T, m);
-    const KsItem it = items[b];
-    const size_t off = (size_t)h * FC::H;
-    u64 a0l[8], a0h[8], a1l[8], a1h[8];
+    const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * FC::N;
+    const InMode mode = {T.mods[i].q > mc.q, false, false, 0};
+    auto ld = [&](int r, u64 &x, u64 &y) {
+        const uint32_t e = e0 + (uint32_t)(C::T / 2) * (uint32_t)r;
+        x = dd[e];
+        y = dd[e + FC::H / 2];
+    };
+    u64 v[8];
+    fwd_int_dispatch(mc, [&](auto pol) {
+        using A = decltype(pol);
+        const typename A::Ctx cx = A::make(mc);
+        split8_fwd_raw<LOGN, A>(v, ld, mode, mc, lds, T.tw + ((size_t)m << LOGN), cx, t, h);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) a0l[r] = a0h[r] = a1l[r] = a1h[r] = 0;
-    for (int i = 0; i < L; ++i) {
-        u64 xv[8];
-        if (i == jj) {  // the digit is already in NTT form modulo its own prime: the (rotated) input row itself
-            const u64 *__restrict__ xr = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * FC::N;
-            const uint32_t elt = relin ? 1u : item_elt(it);
+        for (int r = 0; r < 8; ++r) v[r] = A::fwd_finish(v[r], cx);
+    });
+    u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * FC::N + off;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) xv[r] = xr[galois_index((uint32_t)(off + C::idx_out(t, r)), elt, LOGN)];
+    for (int r = 0; r < 8; r += 2) {
+        const u64 w0 = v[r], w1 = v[r + 1];
+        u64 *p = xd + C::idx_out(t, r);
+        if (stream_x) {
+            __builtin_nontemporal_store(w0, p);
+            __builtin_nontemporal_store(w1, p + 1);
         } else {
-            const u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * FC::N;
-            const bool reduce = mf.q != 0.0 ? T.modsf[i].q == 0.0 : T.mods[i].q > mc.q;
-            auto ld = [&](int r, u64 &x, u64 &y) {
-                const int e = eo(C::idx_nat(t, r), FC::H);
-                x = dd[e];
-                y = dd[e + FC::H / 2];
-                if (reduce) {
-                    x = barrett64(x, mc.q, mc.r1);
-                    y = barrett64(y, mc.q, mc.r1);
-                }
-            };
-            if (mf.q != 0.0)
-                split8_fwd_a<LOGN, ArithF64>(xv, ld, lds, nt.twf, ArithF64::make(mf), t, h);
-            else
-                split8_fwd_a<LOGN, ArithU64>(xv, ld, lds, nt.tw, ArithU64::make(mc), t, h);
-            __syncthreads();  // the next digit's first exchange reuses the LDS this one just read
+            *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(w0, w1);
         }
-        const u64 *__restrict__ k0 = it.key + ((size_t)i * 2 * T.k + m) * FC::N + off;
-        const u64 *__restrict__ k1 = k0 + (size_t)T.k * FC::N;
-        HEFX_STAGE_FENCE();
-#pragma unroll
-        for (int g = 0; g < 2; ++g) {  // two batches of four: the key words are only live for one batch
-            u64 kv0[4], kv1[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                kv0[r] = k0[C::idx_out(t, 4 * g + r)];
-                kv1[r] = k1[C::idx_out(t, 4 * g + r)];
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                mac128(a0l[4 * g + r], a0h[4 * g + r], xv[4 * g + r], kv0[r]);
-                mac128(a1l[4 * g + r], a1h[4 * g + r], xv[4 * g + r], kv1[r]);
-            }
-            HEFX_STAGE_FENCE();
-        }
-    }
-    u64 *__restrict__ o0 = S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * FC::N + off;
-    u64 *__restrict__ o1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * FC::N + off;
-#pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        o0[C::idx_out(t, r)] = barrett128(a0l[r], a0h[r], mc);
-        o1[C::idx_out(t, r)] = barrett128(a1l[r], a1h[r], mc);
     }
 }
 
@@ -707,11 +798,12 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
 // (5) out[b][c][j] = (acc[b][c][j] - NTT_j((u mod q_j) - (P/2 mod q_j))) * P^-1 + add-in, optionally * pt.
 // The epilogue runs in the row's arithmetic policy directly on the unfinished transform values.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 md_epilogue(ArithU64, u64 f, u64 acc, u64 sadd, u64 pt, bool has_pt,
-                                           const ArithU64::Ctx &cx, const DevTables &T, int sp, int j,
+template <bool L16>
+__device__ __forceinline__ u64 md_epilogue(ArithU64T<L16>, u64 f, u64 acc, u64 sadd, u64 pt, bool has_pt,
+                                           const typename ArithU64T<L16>::Ctx &cx, const DevTables &T, int sp, int j,
                                            const ModConst &mc)
 {
-    return ArithU64::moddown(f, acc, sadd, pt, has_pt, cx, T.invmod[(size_t)sp * T.k + j], mc);
+    return ArithU64T<L16>::moddown(f, acc, sadd, pt, has_pt, cx, T.invmod[(size_t)sp * T.k + j], mc);
 }
 __device__ __forceinline__ u64 md_epilogue(ArithF64, double f, u64 acc, u64 sadd, u64 pt, bool has_pt,
                                            const ArithF64::Ctx &cx, const DevTables &T, int sp, int j,
@@ -817,7 +909,25 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
 #ifndef HEFX_EPI_EARLY
 #define HEFX_EPI_EARLY 0
 #endif
-        constexpr int GS = HEFX_EPI, NG = 16 / GS, NBUF = HEFX_EPI_PIPE ? 2 : 1;
+        // the FP64-policy rows (8 of 10 at C3) leave registers free under the kernel's cap -- their values, twiddles and
+        // constants are half as wide as the integer policy's -- so they can afford what the integer rows cannot
+#ifndef HEFX_EPI_F64
+#define HEFX_EPI_F64 HEFX_EPI
+#endif
+#ifndef HEFX_EPI_F64_PIPE
+#define HEFX_EPI_F64_PIPE HEFX_EPI_PIPE
+#endif
+#ifndef HEFX_EPI_F64_EARLY
+#define HEFX_EPI_F64_EARLY HEFX_EPI_EARLY
+#endif
+#ifndef HEFX_EPI_F64_PRE  // 1: the first group's operands are fetched BEFORE the transform (they do not depend on it)
+#define HEFX_EPI_F64_PRE 0
+#endif
+        constexpr int GS = A::IS_F64 ? HEFX_EPI_F64 : HEFX_EPI, NG = 16 / GS;
+        constexpr bool PIPE = A::IS_F64 ? HEFX_EPI_F64_PIPE : HEFX_EPI_PIPE;
+        constexpr bool EARLY = A::IS_F64 ? HEFX_EPI_F64_EARLY : HEFX_EPI_EARLY;
+        constexpr bool PRE = A::IS_F64 && HEFX_EPI_F64_PRE;
+        constexpr int NBUF = PIPE ? 2 : 1;
         u64 a[NBUF][GS], sadd[NBUF][GS], pp[NBUF][GS];
         // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
         // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
@@ -837,7 +947,10 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                 pp[bufi][r] = pv.x, pp[bufi][r + 1] = pv.y;
             }
         };
-        if (HEFX_EPI_EARLY) {
+        if constexpr (PRE) {
+            fetch(0, 0);
+            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+        } else if constexpr (EARLY) {
             auto hook = [&]() { fetch(0, 0); };
             split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, decltype(hook)>(f, ld, mode, mc, lds, tw, cx, t, h, hook);
         } else {
@@ -846,8 +959,8 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
-            const int cur = HEFX_EPI_PIPE ? (g & 1) : 0;
-            if (HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
+            const int cur = PIPE ? (g & 1) : 0;
+            if (PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
 #pragma unroll
             for (int r = 0; r < GS; r += 2) {  // one 16-byte store per record
                 ulonglong2 o;
@@ -856,7 +969,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                                   T, sp, j, mc);
                 *reinterpret_cast<ulonglong2 *>(dst + C::idx_io(t, GS * g + r)) = o;
             }
-            if (!HEFX_EPI_PIPE && g + 1 < NG) fetch(g + 1, 0);
+            if (!PIPE && g + 1 < NG) fetch(g + 1, 0);
         }
     }
 }
@@ -1147,7 +1260,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                            n * L, scr);
         mark(3);
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, rl, 0,
-                           n, scr);
+                           n, 0, scr);
         mark(4);
         hipLaunchKernelGGL((ks_moddown_intt_q_kernel<LOGN>), dim3(quarter_grid(n * 2)), dim3(TQ), ldsq, s, T, L, n * 2, scr);
         mark(5);
@@ -1156,6 +1269,10 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(-1);
         return hipGetLastError();
     }
+    static const int force_stream_x = getenv("HEFX_STREAM_X") ? atoi(getenv("HEFX_STREAM_X")) : -1;
+    auto stream_x_of = [&](int m) {  // x of m items against the 256 MB Infinity Cache: beyond it, stream x
+        return force_stream_x >= 0 ? force_stream_x : ((size_t)m * L * (L + 1) * SC::N * 8 > ((size_t)256 << 20) ? 1 : 0);
+    };
     if (alias) {  // in-place rotations: their inputs move to scratch first (see ks_alias_copy_kernel)
         mark(0);
         hipLaunchKernelGGL(ks_alias_copy_kernel, dim3(SC::N / 2 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L);
@@ -1167,13 +1284,31 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     else
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, rl, 0,
                            n * L, scr);
-    if (sub < 0) {  // fused digit-NTT + MAC (LOGN <= 14): x is never materialised
+    if (sub < 0) {  // hybrid fused digit-NTT + MAC (LOGN <= 14): only the integer-policy targets' products travel
         if constexpr (LOGN <= 14) {
             static PerDeviceOnce fattr;
-            if (fattr.first()) set_lds(ks_ntt_mac_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
+            if (fattr.first()) set_lds(ks_ntt_macf_kernel<LOGN>, FusedCfg<LOGN>::LDS_BYTES);
+            // sub = -1 - (nf | special_int << 8), from ks_run: nf = FP64-policy target slots among 0..L at this level,
+            // special_int = the special prime is an integer-policy slot
+            const int code = -sub - 1, nf = code & 0xff;
+            const bool special_int = (code >> 8) & 1;
+            const int nint = L + 1 - nf;  // integer-policy target slots
+            // digits transformed to an integer slot: L - 1 for a data prime, L for the special prime
+            const int pairs = special_int ? (nint - 1) * (L - 1) + L : nint * (L - 1);
+            const int per_item = 2 * (nf + pairs);
+            const int stream_x = (size_t)n * pairs * SC::N * 8 > ((size_t)256 << 20) ? 1 : 0;
             mark(6);
-            hipLaunchKernelGGL((ks_ntt_mac_kernel<LOGN>), dim3(group_grid(n, L + 1)), dim3(FusedCfg<LOGN>::T),
-                               FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, rl, n, scr);
+            hipLaunchKernelGGL((ks_ntt_macf_kernel<LOGN>), dim3(((n + 7) / 8) * 8 * per_item), dim3(FusedCfg<LOGN>::T),
+                               FusedCfg<LOGN>::LDS_BYTES, s, T, batch, L, rl, n, nf, per_item, stream_x, scr);
+            if (nint > 0) {
+                mark(3);
+                if (stream_x)
+                    hipLaunchKernelGGL(ks_mac_kernel<true>, dim3(SC::N / 2 / 256, nint, (n + 1) / 2), dim3(256), 0, s, T, batch,
+                                       L, rl, 0, n, 1, scr);
+                else
+                    hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, nint, (n + 1) / 2), dim3(256), 0, s, T, batch,
+                                       L, rl, 0, n, 1, scr);
+            }
         }
     } else
     // digit x modulus products only ever exist for `sub` items: K2 writes them, the MAC consumes them right away
@@ -1181,17 +1316,16 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         const int m = n - item0 < sub ? n - item0 : sub;
         mark(2);
         // x of this (sub-)chunk against the 256 MB Infinity Cache: beyond it, stream x (HEFX_STREAM_X=0/1 overrides)
-        static const int force = getenv("HEFX_STREAM_X") ? atoi(getenv("HEFX_STREAM_X")) : -1;
-        const int stream_x = force >= 0 ? force : ((size_t)m * L * (L + 1) * SC::N * 8 > ((size_t)256 << 20) ? 1 : 0);
+        const int stream_x = stream_x_of(m);
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds_ntt, s, T, L, m * L,
                            item0, stream_x, scr);
         mark(3);
         if (stream_x)
             hipLaunchKernelGGL(ks_mac_kernel<true>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
-                               L, rl, item0, m, scr);
+                               L, rl, item0, m, 0, scr);
         else
             hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,
-                               L, rl, item0, m, scr);
+                               L, rl, item0, m, 0, scr);
     }
     mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, scr);
@@ -1264,6 +1398,12 @@ static hipError_t launch_lt2_moddown_t(const DevTables &T, int L, const KsItem *
     return hipGetLastError();
 }
 
+// -DHEFX_ONLY_LOGN=14: development builds that instantiate one ring size only (a fifth of the compile time)
+#ifdef HEFX_ONLY_LOGN
+#define HEFX_DISPATCH_SPLIT(logn, CALL) \
+    if ((logn) == HEFX_ONLY_LOGN) return CALL(HEFX_ONLY_LOGN); \
+    return hipErrorInvalidValue;
+#else
 #define HEFX_DISPATCH_SPLIT(logn, CALL)       \
     switch (logn) {                           \
         case 11: return CALL(11);             \
@@ -1273,6 +1413,7 @@ static hipError_t launch_lt2_moddown_t(const DevTables &T, int L, const KsItem *
         case 15: return CALL(15);             \
         default: return hipErrorInvalidValue; \
     }
+#endif
 
 hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,
                                 const KsScratch &scr, const u64 *ct_new, u64 *partial_s, u64 *partial_c0, u64 *cbuf,
@@ -1369,13 +1510,18 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     const u64 *__restrict__ src = (tab ? tab[ci] + (size_t)pi * L * SC::N : in + (size_t)poly * L * SC::N) + (size_t)j * SC::N + off;
     u64 *__restrict__ dst = (tab ? const_cast<u64 *>(tab[count + ci]) + (size_t)pi * (L - 1) * SC::N
                                  : out + (size_t)poly * (L - 1) * SC::N) + (size_t)j * SC::N + off;
-    u64 a[16];
+    // operands in two batches of eight (all sixteen at once spilled next to the two integer forward policies)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) a[r] = src[C::idx_io(t, r)];
+    for (int g = 0; g < 16; g += 8) {
+        u64 a[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const u64 z = submod(a[r], v[r], q);
-        dst[C::idx_io(t, r)] = csub(shoup_lazy(z, qinv.x, qinv.y, mc.nq), q);
+        for (int r = 0; r < 8; ++r) a[r] = src[C::idx_io(t, g + r)];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const u64 z = submod(a[r], v[g + r], q);
+            dst[C::idx_io(t, g + r)] = csub(shoup_lazy(z, qinv.x, qinv.y, mc.nq), q);
+        }
+        HEFX_STAGE_FENCE();
     }
 }
 

@@ -91,7 +91,18 @@ struct NttCfg {
 // ------------------------------------------------------------------------------------------------
 // policy: 64-bit integers, Harvey/Shoup
 // ------------------------------------------------------------------------------------------------
-struct ArithU64 {
+// L16 (round 3): the forward transform of a prime below 2^60 -- every prime SEAL can produce -- keeps its values in
+// [0,16q) and makes the conditional subtraction (by 8q) in every OTHER stage only:
+//   even stage (none):  inputs < 12q, x' = x + t < 16q, y' = x + 4q - t < 16q            (t = w*y lazy, < 4q)
+//   odd stage  (by 8q): inputs < 16q -> a < 8q, x' = a + t < 12q, y' = a + 4q - t < 12q
+// 16q <= 2^64 needs q <= 2^60.  Four instructions fewer in half the stages: 80.0 -> 71.7 SIMD cycles per wave-butterfly
+// in isolation (tools/ubench_bfly.hip form 4, profiles/r03_butterfly_ubench.txt).  The 61-bit primes the engine also
+// admits keep the [0,8q) form (L16 = false); the inverse transform has no such slack (its sums double per stage).
+// Used where it measured faster in the kernels -- the digit transforms of the key switch (ks_ntt_digits: -3 % VALU
+// instructions at C3, -10 % kernel time at N = 32768); the mod-down epilogue kernels got slower with a second integer
+// path (registers: 111 -> 129 VGPRs at N = 8192, one wave per SIMD fewer) and keep the [0,8q) form.
+template <bool L16>
+struct ArithU64T {
     typedef u64 V;
     typedef ulonglong2 TW;  // {w, floor(w*2^64/q)}
     // Lazy ranges (q < 2^61, so 8q < 2^64): forward values live in [0,8q), inverse values in [0,4q).  The twiddle
@@ -101,7 +112,7 @@ struct ArithU64 {
     // canonical, so the bits are those of any exact arithmetic.
     struct Ctx {
         u64 q, two_q, four_q;
-        u64 nq, n2q, n4q;  // 2^64 - q, - 2q, - 4q (shoup_lazy4, csubn)
+        u64 nq, n2q, n4q, n8q;  // 2^64 - q, - 2q, - 4q, - 8q (shoup_lazy4, csubn)
         u64 ninv, ninv_s, ilw, ilw_s;
     };
     __device__ static __forceinline__ Ctx make(const ModConst &mc)
@@ -113,16 +124,22 @@ struct ArithU64 {
         c.nq = mc.nq;
         c.n2q = mc.nq << 1;
         c.n4q = mc.nq << 2;
+        c.n8q = mc.nq << 3;
         c.ninv = mc.ninv;
         c.ninv_s = mc.ninv_s;
         c.ilw = mc.ilw;
         c.ilw_s = mc.ilw_s;
         return c;
     }
-    // forward butterfly, inputs/outputs in [0,8q)
-    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
+    // forward butterfly of stage `stage` (0 = the first stage of the core; a compile-time constant once the cores'
+    // loops are unrolled).  L16 = false: inputs/outputs in [0,8q).  L16: see the policy's header.
+    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c, int stage)
     {
-        u64 a = csubn(x, c.n4q);                      // [0,4q)
+        u64 a;
+        if (L16)
+            a = (stage & 1) ? csubn(x, c.n8q) : x;    // [0,8q) or [0,12q)
+        else
+            a = csubn(x, c.n4q);                      // [0,4q)
         u64 t = shoup_lazy4(y, w.x, w.y, c.nq);          // [0,4q), y any 64-bit word
         x = a + t;
         y = a + c.four_q - t;
@@ -169,7 +186,8 @@ struct ArithU64 {
     // difference of two values of the inverse range [0,4q), results back in [0,4q).
     __device__ static __forceinline__ V ct_sel(V x, V y, const TW &wh, const Ctx &c)  // wh = half_twiddle(w, c, h)
     {
-        return csubn(x, c.n4q) + shoup_lazy4(y, wh.x, wh.y, c.nq);
+        // L16: x < 5q as it is; 5q + 4q < 12q, a valid input of the core's stage 0
+        return (L16 ? x : csubn(x, c.n4q)) + shoup_lazy4(y, wh.x, wh.y, c.nq);
     }
     __device__ static __forceinline__ V inv_add(V x, V y, const Ctx &c) { return csubn(x + y, c.n4q); }
     __device__ static __forceinline__ V inv_sub_mul(V x, V y, const TW &w, const Ctx &c)
@@ -187,6 +205,7 @@ struct ArithU64 {
     }
     __device__ static __forceinline__ u64 fwd_finish(V x, const Ctx &c)
     {
+        if (L16) x = csubn(x, c.n8q);  // < 16q -> < 8q
         return csubn(csubn(csubn(x, c.n4q), c.n2q), c.nq);
     }
     // what the key MAC reads from scratch for a row of this policy (hefx_keyswitch.hip, MacL / MacW): canonical words
@@ -196,6 +215,7 @@ struct ArithU64 {
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const ulonglong2 &pinv, const ModConst &mc)
     {
+        if (L16) f = csubn(f, c.n8q);                    // < 16q -> < 8q
         u64 z = acc + c.four_q - csubn(f, c.n4q);      // < 5q (no 9q intermediate: primes may reach 2^61)
         z = shoup_lazy(z, pinv.x, pinv.y, c.nq) + sadd;   // < 3q
         if (has_pt) return mulmod(z, pt, mc);            // product < 3q*q < q*2^64: Barrett128 gives [0,q)
@@ -203,6 +223,17 @@ struct ArithU64 {
     }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return csubn(x, c.nq); }
 };
+typedef ArithU64T<false> ArithU64;   // any prime below 2^61; every inverse transform
+typedef ArithU64T<true> ArithU64L;   // forward transforms of primes below 2^60
+// f(policy tag) with the forward integer policy the modulus admits (block-uniform)
+template <class F>
+__device__ __forceinline__ void fwd_int_dispatch(const ModConst &mc, const F &f)
+{
+    if (mc.q >> 60)
+        f(ArithU64{});
+    else
+        f(ArithU64L{});
+}
 
 // ------------------------------------------------------------------------------------------------
 // policy: exact integers in doubles, FMA modmul (q < 2^41)
@@ -241,7 +272,7 @@ struct ArithF64 {
     {
         return __builtin_fma(-__builtin_rint(x * c.qinv), c.q, x);
     }
-    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c)
+    __device__ static __forceinline__ void ct(V &x, V &y, const TW &w, const Ctx &c, int /*stage*/)
     {
         const double t = mm(y, w, c);
         const double a = x;
@@ -390,7 +421,7 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 if (e & half) continue;
-                A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (4 - u))], cx);
+                A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (4 - u))], cx, 4 * p + u);
             }
         }
         if (p + 1 < C::FP)
@@ -420,7 +451,7 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
                     A::ct(v[c * C::G + e], v[c * C::G + (e | half)],
-                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx);
+                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx, 4 * C::FP + u);
                 }
             }
         }
@@ -614,6 +645,11 @@ __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMo
 {
     if (mf.q != 0.0)
         split_fwd_a<LOGN, ArithF64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
+    else if constexpr (MACOP)  // the digit transforms of the key switch: the lighter L16 butterfly where the prime admits it
+        fwd_int_dispatch(mc, [&](auto pol) {
+            using A = decltype(pol);
+            split_fwd_a<LOGN, A, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, A::make(mc), t, h);
+        });
     else
         split_fwd_a<LOGN, ArithU64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
 }

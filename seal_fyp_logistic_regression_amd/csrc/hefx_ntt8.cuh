@@ -1,6 +1,6 @@
-// hefx_ntt8.cuh -- forward NTT core with EIGHT coefficients per thread (radix-8 passes), used by the fused
-// "digit NTT + key MAC" kernel: with 8 coefficients per thread the two 128-bit accumulators per coefficient
-// (64 VGPRs) fit next to the transform's working set, which they do not with 16.
+// hefx_ntt8.cuh -- NTT cores with EIGHT coefficients per thread (radix-8 passes), used by the fused
+// "digit NTT + key MAC" kernel (two FP64 accumulators per coefficient = 32 VGPRs next to the transform's working set,
+// where sixteen coefficients per thread would need 64) and by the quarter-row kernels of the small-batch path.
 // Same conventions as hefx_ntt.cuh (policies ArithU64 / ArithF64, twiddle prefix `pre`, one-pass-ahead twiddle
 // prefetch, one barrier per LDS exchange, padding G words every 8*G words -> conflict-free b64 accesses).
 #pragma once
@@ -89,7 +89,7 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if (e & half) continue;
-                A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (3 - u))], cx);
+                A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (3 - u))], cx, 3 * p + u);
             }
         }
         HEFX_STAGE_FENCE();
@@ -119,31 +119,37 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
                 for (int e = 0; e < C::G; ++e) {
                     if (e & half) continue;
                     A::ct(v[c * C::G + e], v[c * C::G + (e | half)],
-                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx);
+                          w[c * (C::G - 1) + (1 << u) - 1 + (e >> (C::R - u))], cx, 3 * C::FP + u);
                 }
             }
         }
     }
 }
 
-// Half h of a forward transform of size 2^LOGN for one digit: ld(r, x, y) delivers coefficients idx_nat(t,r) and
-// +N/2 (reduced as the policy requires); out[r] = canonical NTT value at h*N/2 + idx_out(t,r).
+// Half h of a forward transform of size 2^LOGN: ld(r, x, y) delivers the raw words of coefficients idx_nat(t,r) and
+// idx_nat(t,r) + N/2, `mode` says how they become inputs (reduction in the row's policy); on return
+// f[r] = UNFINISHED NTT value at h*N/2 + idx_out(t,r) (A::fwd_finish / A::mac_operand make it a stored word).
 template <int LOGN, class A, class LD>
-__device__ __forceinline__ void split8_fwd_a(u64 (&out)[8], const LD &ld, u64 *lds,
-                                             const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                             int h)
+__device__ __forceinline__ void split8_fwd_raw(typename A::V (&f)[8], const LD &ld, const InMode &mode,
+                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
+                                               const typename A::Ctx &cx, int t, int h)
 {
-    typename A::V f[8];
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
-    u64 x[8], y[8];
+    auto stage = [&](auto red) {
+        constexpr bool RED = decltype(red)::value;
+        u64 x[8], y[8];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) ld(r, x[r], y[r]);
+        for (int r = 0; r < 8; ++r) ld(r, x[r], y[r]);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) f[r] = A::ct_half(A::from_u64(x[r]), A::from_u64(y[r]), w1, cx);
-    HEFX_STAGE_FENCE();
+        for (int r = 0; r < 8; ++r)
+            f[r] = A::ct_half(A::template input<RED>(x[r], mode, cx, mc), A::template input<RED>(y[r], mode, cx, mc), w1, cx);
+        HEFX_STAGE_FENCE();
+    };
+    if (A::IS_F64 ? mode.red_f64 : mode.red_int)
+        stage(std::true_type{});
+    else
+        stage(std::false_type{});
     ntt8_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) out[r] = A::fwd_finish(f[r], cx);
 }
 
 // Inverse core with eight coefficients per thread: v[r] = NTT value idx_out(t,r) on entry (U64: [0,4q); F64: |v| < 2^45),

@@ -764,10 +764,14 @@ class Evaluator:
     # ---- the same operation over many independent ciphertexts (the rows of a data set): one engine launch per
     # list where the backend offers it, otherwise the per-item calls -- identical checks and bits either way
     def _uniform(self, cts):
+        if not cts:  # an empty list is trivially uniform; the callers below return before touching cts[0]
+            return True
         L, size, scale = cts[0].parms_id(), cts[0].size(), cts[0].scale
         return all(c._parms_id == L and c._size == size and c._scale == scale for c in cts)
 
     def multiply_many(self, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext]) -> List[Ciphertext]:
+        if not As:  # a rank that owns no unit of a sharded product (parallel.py)
+            return []
         f = getattr(self.be, "multiply_batch", None)
         if f is None or not (self._uniform(As) and self._uniform(Bs)) or any(a.data is b.data for a, b in zip(As, Bs)):
             return [self.multiply(a, b) for a, b in zip(As, Bs)]
@@ -782,6 +786,8 @@ class Evaluator:
 
     def relinearize_many_inplace(self, cts: Sequence[Ciphertext], relin_keys: KSwitchKeys):
         f = getattr(self.be, "relinearize_batch", None)
+        if not cts:
+            return cts
         if f is None or not self._uniform(cts) or cts[0].size() != 3:
             for c in cts:
                 self.relinearize_inplace(c, relin_keys)
@@ -793,6 +799,8 @@ class Evaluator:
 
     def rescale_to_next_many_inplace(self, cts: Sequence[Ciphertext]):
         f = getattr(self.be, "rescale_batch", None)
+        if not cts:
+            return cts
         if f is None or not self._uniform(cts) or cts[0].parms_id() < 2:
             for c in cts:
                 self.rescale_to_next_inplace(c)
@@ -805,6 +813,8 @@ class Evaluator:
 
     def add_pairs(self, As: Sequence[Ciphertext], Bs: Sequence[Ciphertext]) -> List[Ciphertext]:
         f = getattr(self.be, "add_batch", None)
+        if not As:
+            return []
         if f is None or not (self._uniform(As) and self._uniform(Bs)) or As[0].size() != Bs[0].size():
             return [self.add(a, b) for a, b in zip(As, Bs)]
         a, b = As[0], Bs[0]

@@ -106,7 +106,9 @@ def _worker_config5(rank, world, port, q):
         from seal_fyp_logistic_regression_amd import seal as S
         rng = np.random.default_rng(4)
         out = {}
-        for name, N, n in (("n4_c3", 16384, 4), ("n64_c5", 32768, 64)):
+        # n = 2: dimension - 1 = 1 < world, so rank 1 owns no Step-2 unit and contributes the zero ciphertext (its batched
+        # rescale / product helpers see empty lists -- the HIP backend has the batch entry points the CPU twin lacks)
+        for name, N, n in (("n2_c3", 16384, 2), ("n4_c3", 16384, 4), ("n64_c5", 32768, 64)):
             parms = S.EncryptionParameters("ckks")
             parms.set_poly_modulus_degree(N)
             parms.set_coeff_modulus(S.CoeffModulus.Create(N, [60, 40, 40, 40, 40, 60]))
@@ -138,7 +140,8 @@ def _worker_config5(rank, world, port, q):
 def test_config5_sparse_matrix_product_sharded_world2():
     """BASELINE config 5 (matrix_mult_benchmark.cpp:13-71; 64 x 64 at N = 32768) in its sharded form on the HIP engine:
     Step 2 split by k over two ranks (sharing the box's GPU, rendezvous over gloo), one all-reduce of the size-3 sum;
-    bits equal the serial sparse product at n = 4 (C3) and n = 64 (C5), and the n = 64 result decrypts to A.B."""
+    bits equal the serial sparse product at n = 2 (a rank without a unit), n = 4 (C3) and n = 64 (C5), and the results
+    decrypt to A.B."""
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

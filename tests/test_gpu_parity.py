@@ -327,6 +327,19 @@ def test_invalid_arguments_raise(c2):
         e.apply_galois(4, a, 3, key)  # level above top data level
     with pytest.raises(ValueError):
         e.rescale_to_next(1, 2, a)
+    # a dependent chain handed over as ONE batch is refused (items run key-grouped on several streams): item 1 reads
+    # item 0's output / two items write one output; sharing a SOURCE and an item's own in-place rotation are fine
+    b, c = e.empty(2, 3, 8192), e.empty(2, 3, 8192)
+    with pytest.raises(ValueError, match="independent"):
+        e.apply_galois_batch(3, [a, b], [3, 3], [key, key], [b, c])
+    with pytest.raises(ValueError, match="same output"):
+        e.apply_galois_batch(3, [a, a], [3, 9], [key, key], [b, b])
+    e.apply_galois_batch(3, [a, a], [3, 3], [key, key], [b, c])
+    assert (b.download() == c.download()).all()
+    want = b.download()
+    a2 = e.copy(a)
+    e.apply_galois_batch(3, [a2, a], [3, 3], [key, key], [a2, c])   # item 0 in place
+    assert (a2.download() == want).all()
 
 
 def test_alternative_launch_paths_bit_exact(c3):

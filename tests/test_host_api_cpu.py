@@ -377,3 +377,28 @@ def test_default_keygenerator_and_encryptor_draw_fresh_os_randomness():
     dec = S.Decryptor(ctx, kg1.secret_key())
     got = S.CKKSEncoder(ctx).decode(dec.decrypt(e2.encrypt(pt)))[:4]
     assert np.allclose(got.real, np.arange(4.0), atol=1e-4)
+
+
+def test_batched_helpers_accept_empty_lists(env):
+    """A rank that owns no unit of a sharded product (parallel.cc_matrix_multiplication_sparse_sharded with
+    dimension - 1 < world) hands empty lists to the batched Evaluator helpers; on a backend that HAS the batch entry
+    points (the HIP engine) they used to index cts[0].  Stubs stand in for those entry points here: they must not be
+    reached, and every helper must return an empty result."""
+    ev, be = env["ev"], env["ev"].be
+    def boom(*a, **k):
+        raise AssertionError("batch entry point called for an empty list")
+    names = ("multiply_batch", "relinearize_batch", "rescale_batch", "add_batch")
+    saved = {n: getattr(be, n, None) for n in names}
+    try:
+        for n in names:
+            setattr(be, n, boom)
+        assert ev.multiply_many([], []) == []
+        assert ev.rescale_to_next_many_inplace([]) == []
+        assert ev.relinearize_many_inplace([], env["rk"]) == []
+        assert ev.add_pairs([], []) == []
+    finally:
+        for n, f in saved.items():
+            if f is None:
+                delattr(be, n)
+            else:
+                setattr(be, n, f)

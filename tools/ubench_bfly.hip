@@ -16,6 +16,15 @@ __device__ __forceinline__ u64 under2(u64 x, u64 ws)
     const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)ws, w1 = (uint32_t)(ws >> 32);
     return (u64)x1 * w1 + ((u64)__umulhi(x0, w1) + (u64)__umulhi(x1, w0));
 }
+// the same under-estimate with the two cross high words taken from full 64-bit multiply-adds instead of v_mul_hi_u32
+// (quarter-rate on gfx950: 8.5 cycles per wave-instruction against 5.65 for v_mad_u64_u32, profiles/r01_valu_issue_rates.txt)
+__device__ __forceinline__ u64 under2m(u64 x, u64 ws)
+{
+    const uint32_t x0 = (uint32_t)x, x1 = (uint32_t)(x >> 32), w0 = (uint32_t)ws, w1 = (uint32_t)(ws >> 32);
+    u64 t = (u64)x0 * w1, u = (u64)x1 * w0;
+    asm("" : "+v"(t), "+v"(u));  // keep the full products: the optimiser would go back to v_mul_hi_u32
+    return (u64)x1 * w1 + ((t >> 32) + (u >> 32));
+}
 __device__ __forceinline__ u64 csub(u64 x, u64 m)
 {
     u64 d;
@@ -50,7 +59,10 @@ __global__ __launch_bounds__(256) void k(u64 *p, const ulonglong2 *tw, u64 q, u6
     u64 v[16];
     u64 *mine = p + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
     for (int i = 0; i < 16; ++i) v[i] = mine[i];
-    const u64 q4 = 4 * q, nq4 = nq << 2;
+    const u64 q4 = 4 * q, nq4 = nq << 2, nq8 = nq << 3;
+    // forms 3, 4: values in [0,16q) (q < 2^60): the conditional subtraction (by 8q) only in every other stage --
+    // stage without: in < 12q, out < 16q; stage with: in < 16q -> < 8q, out < 12q
+    constexpr bool LAZY16 = FORM >= 3, MADQ = FORM == 2 || FORM == 3;
     for (int r = 0; r < rounds; ++r) {
         const ulonglong2 w = tw[r & 63];
 #pragma unroll
@@ -63,8 +75,11 @@ __global__ __launch_bounds__(256) void k(u64 *p, const ulonglong2 *tw, u64 q, u6
                         a = csub(v[i], q4);
                         t = v[i + s] * w.x - under2(v[i + s], w.y) * q;
                     } else {
-                        a = csubn(v[i], nq4);
-                        t = mul_sub_lo64(v[i + s], w.x, under2(v[i + s], w.y), nq);
+                        if (LAZY16)
+                            a = (s == 8 || s == 2) ? v[i] : csubn(v[i], nq8);
+                        else
+                            a = csubn(v[i], nq4);
+                        t = mul_sub_lo64(v[i + s], w.x, MADQ ? under2m(v[i + s], w.y) : under2(v[i + s], w.y), nq);
                     }
                     v[i] = a + t;
                     v[i + s] = a + q4 - t;
@@ -113,7 +128,29 @@ int main()
     }
     hipMemcpy(tw, ht.data(), 64 * sizeof(ulonglong2), hipMemcpyHostToDevice);
     const double wave_bf = (double)blocks * 4 * rounds * 32 / (256.0 * 4);  // wave-butterflies per SIMD
+    // every form computes the same residues: check them against form 1 on a short run from the same input
+    auto residues = [&](auto runner) {
+        hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
+        runner();
+        hipDeviceSynchronize();
+        std::vector<u64> o(4096);
+        hipMemcpy(o.data(), d, o.size() * 8, hipMemcpyDeviceToHost);
+        for (auto &x : o) x %= q;
+        return o;
+    };
+    const auto r1 = residues([&] { hipLaunchKernelGGL(k<1>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
+    const auto r2 = residues([&] { hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
+    const auto r3 = residues([&] { hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
+    const auto r4 = residues([&] { hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
+    printf("residues equal to form 1: form 2 %d, form 3 %d, form 4 %d\n", r1 == r2, r1 == r3, r1 == r4);
+    hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     const double m0 = run<0>(d, tw, q, rounds, blocks), m1 = run<1>(d, tw, q, rounds, blocks);
+    for (int f = 2; f <= 4; ++f) {
+        const double m = f == 2 ? run<2>(d, tw, q, rounds, blocks) : f == 3 ? run<3>(d, tw, q, rounds, blocks) : run<4>(d, tw, q, rounds, blocks);
+        printf("form %d (%s%s): %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", f,
+               f == 2 || f == 3 ? "quotient by multiply-adds" : "v_mul_hi quotient", f >= 3 ? ", 16q lazy range" : "", m,
+               m * 1e6 / wave_bf, m * 1e-3 * 2.4e9 / wave_bf);
+    }
     printf("compiler's form : %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", m0, m0 * 1e6 / wave_bf,
            m0 * 1e-3 * 2.4e9 / wave_bf);
     printf("multiply-add form: %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", m1, m1 * 1e6 / wave_bf,
