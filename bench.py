@@ -237,6 +237,7 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         ok = bool(np.allclose(encoder.decode(dec.decrypt(serial))[:d].real, M @ v, atol=1e-3 * d))
         rec = {"serial_ms": serial_ms, "decrypts_to_Mv": ok, "key_switches_serial": alg_key_switches(ev, d, gk)}
         if world > 1:
+            par.ENGINE_COMM = "off"   # this leg: the exchange through torch.distributed (in place on the payload)
             sharded, sharded_ms = timed(lambda: par.linear_transform_plain_sharded(ev, ct, diags, gk))
             same = bool((bits(serial) == bits(sharded)).all())
             t = [sharded_ms, 1.0 if same else 0.0]
@@ -256,6 +257,7 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
                 # the scaling run): the same transform with the exchange behind the C-ABI (hefx_allreduce_sum: RCCL called by libhefx
                 # itself, in place on the payload) instead of torch.distributed; reported next to it, never fatal
                 try:
+                    par.ENGINE_COMM = "on"
                     par.init_engine_comm(ev)
                     via, via_ms = timed(lambda: par.linear_transform_plain_sharded(ev, ct, diags, gk))
                     tt = torch.tensor([via_ms, 1.0 if bool((bits(serial) == bits(via)).all()) else 0.0],

@@ -285,6 +285,24 @@ int main()
               "LR loop with forced mid-chain flushes (3 MB pending budget) == call-by-call execution");
         CHECK(std::get<2>(lazy) >= (std::size_t)rows * (3 + 2 * size) && std::get<2>(eager) == 0,
               "the whole loop stays recorded until add_many (encode / plaintext mod_switch do not flush)");
+        // several devices behind the same program (SEAL_SHIM_DEVICES): the rows are independent sub-graphs, dealt over
+        // two / three engine contexts (sharing the GPUs that exist), inputs replicated, results copied home -- the
+        // bits of the one-device run; a second pass reuses the cached replicas of the keys
+        auto e = context->engine();
+        const int old_ndev = e->ndev;
+        for (int nd : {2, 3}) {
+            e->live();
+            e->ndev = nd;
+            const auto multi = run(true, (std::size_t)8192 << 20), again = run(true, (std::size_t)8192 << 20);
+            CHECK(std::get<0>(multi) == std::get<0>(eager) && std::get<1>(multi) == std::get<1>(eager) &&
+                      std::get<0>(again) == std::get<0>(eager) && std::get<1>(again) == std::get<1>(eager),
+                  (nd == 2 ? "LR loop over 2 engine contexts (SEAL_SHIM_DEVICES) == call-by-call execution, bit for bit"
+                           : "LR loop over 3 engine contexts == call-by-call execution, bit for bit"));
+            CHECK((int)e->dev_ctx.size() >= nd && e->dev_ctx[nd - 1] != nullptr && !e->replicas[1].empty(),
+                  "the extra contexts exist and hold replicas of the shared inputs");
+        }
+        e->live();
+        e->ndev = old_ndev;
     }
 
     // SEAL's error behaviour at the boundary

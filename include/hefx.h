@@ -72,6 +72,15 @@ int hefx_free(hefx_context *ctx, void *d_ptr);
 int hefx_upload(hefx_context *ctx, void *d_dst, const void *h_src, size_t bytes, void *stream);
 int hefx_download(hefx_context *ctx, void *h_dst, const void *d_src, size_t bytes, void *stream); /* blocks */
 int hefx_copy(hefx_context *ctx, void *d_dst, const void *d_src, size_t bytes, void *stream);
+/* between two contexts, possibly on different GPUs (hipMemcpyPeerAsync; a plain device copy when both contexts share a
+ * device): asynchronous on `stream` of the SOURCE context's device (null: its default stream), i.e. ordered after the
+ * source context's work that produced the bytes.  What lets one host process spread independent sub-graphs of the
+ * reference's loops (logistic_regression_ckks.cpp:217-229, matrix_mult_benchmark.cpp:41-43) over the GPUs of a node
+ * and bring the results together (include/seal/seal.h, SEAL_SHIM_DEVICES). */
+int hefx_copy_peer(hefx_context *dst_ctx, void *d_dst, hefx_context *src_ctx, const void *d_src, size_t bytes,
+                   void *stream);
+/* the HIP device a context lives on */
+int hefx_context_device(const hefx_context *ctx);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
 int hefx_stream_sync(hefx_context *ctx, void *stream);
 

@@ -25,6 +25,7 @@
 #include <ctime>
 #include <cstdio>
 #include <initializer_list>
+#include <functional>
 #include <map>
 #include <tuple>
 #include <memory>
@@ -144,6 +145,29 @@ struct Engine {
     std::vector<std::uint64_t> primes;
     std::mutex mu;
 
+    // ---- several devices behind one SEAL program (SEAL_SHIM_DEVICES=n) ------------------------------------------
+    // The reference's callers are single-process C++ whose loops are embarrassingly parallel: 2000 independent
+    // observation rows (logistic_regression_ckks.cpp:217-229), 2(n-1) independent linear transforms
+    // (matrix_mult_benchmark.cpp:41-43).  The recorder below already holds them as a dependency graph, so a submission
+    // cuts the graph into its connected sub-graphs, deals them over `ndev` engine contexts (one per GPU; context 0 is
+    // the program's home device where every payload lives), replicates the external inputs a sub-graph reads (keys and
+    // shared ciphertexts once, kept while their owner lives), runs all devices' batches concurrently and copies back
+    // the results somebody outside the graph still holds (hefx_copy_peer = hipMemcpyPeerAsync).  Every node is a
+    // deterministic function of its inputs: same bits on any device.  With fewer GPUs than SEAL_SHIM_DEVICES the extra
+    // contexts share the existing ones (d mod hefx_device_count()) -- how the path is exercised on a one-GPU box.
+    struct Node;
+    int ndev = 1;
+    std::vector<hefx_context *> dev_ctx;  // [ndev], dev_ctx[0] == ctx_raw; created on first multi-device submission
+    struct Replica {
+        std::weak_ptr<Buf> owner;  // the home buffer; a recycled address with another owner is a miss
+        std::uint64_t *p;
+        std::size_t words;
+    };
+    std::vector<std::map<const std::uint64_t *, Replica>> replicas;  // per device > 0: home pointer -> copy
+    inline hefx_context *device_context(int d);
+    inline void flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
+                            int max_depth);
+
     // ---- deferred evaluation ------------------------------------------------------------------------------
     // The reference issues its ciphertext operations one call at a time -- helper.h:252-257 (rotate_vector,
     // multiply_plain, next diagonal ...), and logistic_regression_ckks.cpp:217-229 -> helper.h:432-476 (per observation
@@ -229,6 +253,7 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     if (const char *d = std::getenv("HEFX_DEVICE")) dev = std::atoi(d);
     check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx_raw));
     if (const char *l = std::getenv("SEAL_SHIM_LAZY")) e->lazy = std::atoi(l) != 0;
+    if (const char *nd = std::getenv("SEAL_SHIM_DEVICES")) e->ndev = std::max(1, std::min(64, std::atoi(nd)));
     // the one SEAL semantic that could not be verified offline: SEAL_SHIM_RESCALE=round switches
     // rescale_to_next from the floor division (3.4.x as App. A.9 reads it; default) to round-to-nearest (3.5+)
     if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
@@ -306,6 +331,20 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     return out;
 }
 
+// One device's share of a submission: its nodes of K (by dependency depth), depths depth_first .. depth_last, all nodes
+// of one depth, kind and level as ONE batched C-ABI call on `cx`.  in(p) translates an input pointer of the home device
+// to this device, out(i) is where node i's result goes.
+template <class In, class Out>
+inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vector<Engine::Node> &K,
+                         const std::vector<std::vector<int>> &by_depth, const std::vector<char> &fused_rot,
+                         const std::vector<char> &fused_mul, int depth_first, int depth_last, const In &in, const Out &out);
+inline std::vector<std::vector<int>> nodes_by_depth(const std::vector<Engine::Node> &K, const std::vector<int> &ids, int max_depth)
+{
+    std::vector<std::vector<int>> by_depth(max_depth + 1);
+    for (int i : ids) by_depth[K[i].depth].push_back(i);
+    return by_depth;
+}
+
 inline void Engine::flush()
 {
     std::vector<Node> K;
@@ -331,69 +370,15 @@ inline void Engine::flush()
         fused_rot[i] = 1;
         fused_mul[k.mulpt_consumer] = 1;
     }
-    std::vector<std::vector<int>> by_depth(max_depth + 1);
-    for (std::size_t i = 0; i < K.size(); ++i) by_depth[K[i].depth].push_back((int)i);
-    std::vector<const std::uint64_t *> va, vb, vc;
-    std::vector<std::uint64_t *> vo;
-    std::vector<std::uint32_t> ve;
     try {
-        for (int depth = 0; depth <= max_depth; ++depth) {
-            // groups of this depth: (kind, fused?, L, size, shared key)
-            std::map<std::tuple<int, int, int, int, const std::uint64_t *>, std::vector<int>> groups;
-            for (int i : by_depth[depth]) {
-                const Node &k = K[i];
-                if (fused_mul[i]) continue;  // runs inside its rotation
-                const std::uint64_t *shared = k.kind == Node::RELIN ? k.b->p : nullptr;
-                groups[std::make_tuple((int)k.kind, (int)fused_rot[i], k.L, k.size, shared)].push_back(i);
-            }
-            for (auto &g : groups) {
-                const int kind = std::get<0>(g.first), fz = std::get<1>(g.first), L = std::get<2>(g.first),
-                          size = std::get<3>(g.first);
-                const std::vector<int> &ids = g.second;
-                const int n = (int)ids.size();
-                va.clear(), vb.clear(), vc.clear(), vo.clear(), ve.clear();
-                ++stats.calls;
-                for (int i : ids) {
-                    const Node &k = K[i];
-                    va.push_back(k.a->p);
-                    if (k.b) vb.push_back(k.b->p);
-                    ve.push_back(k.elt);
-                    if (fz) {
-                        const Node &m = K[k.mulpt_consumer];
-                        vc.push_back(m.b->p);
-                        vo.push_back(m.dst->p);
-                    } else {
-                        vo.push_back(k.dst->p);
-                    }
-                }
-                switch (kind) {
-                    case Node::ROT:
-                        if (fz)
-                            check(hefx_rotate_multiply_plain_batch(ctx_raw, L, n, va.data(), ve.data(), vb.data(), vc.data(),
-                                                                   vo.data(), nullptr));
-                        else
-                            check(hefx_apply_galois_batch(ctx_raw, L, n, va.data(), ve.data(), vb.data(), vo.data(), nullptr));
-                        break;
-                    case Node::MULPT:
-                        check(hefx_multiply_plain_batch(ctx_raw, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
-                        break;
-                    case Node::MULCT:
-                        check(hefx_multiply_batch(ctx_raw, L, n, va.data(), vb.data(), vo.data(), nullptr));
-                        break;
-                    case Node::RELIN:
-                        check(hefx_relinearize_batch(ctx_raw, L, n, va.data(), std::get<4>(g.first), vo.data(), nullptr));
-                        break;
-                    case Node::RESCALE:
-                        check(hefx_rescale_to_next_batch(ctx_raw, L, size, n, va.data(), vo.data(), nullptr));
-                        break;
-                    case Node::ADD:
-                        check(hefx_add_batch(ctx_raw, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
-                        break;
-                    case Node::SUB:
-                        check(hefx_sub_batch(ctx_raw, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
-                        break;
-                }
-            }
+        if (ndev > 1)
+            flush_multi(K, fused_rot, fused_mul, max_depth);
+        else {
+            std::vector<int> all(K.size());
+            for (std::size_t i = 0; i < K.size(); ++i) all[i] = (int)i;
+            submit_nodes(ctx_raw, stats, K, nodes_by_depth(K, all, max_depth), fused_rot, fused_mul, 0, max_depth,
+                         [](const std::uint64_t *p_) { return p_; },
+                   [&](int i) { return K[i].dst->p; });
         }
     } catch (const std::exception &ex) {
         // results recorded with the failed batch (and everything after it) were never computed: every later use of
@@ -408,6 +393,227 @@ inline void Engine::flush()
         std::fprintf(stderr, "[seal shim] +%.3f s submission %zu: %zu operations, %d dependency levels, %.1f ms host time\n",
                      (double)std::clock() / CLOCKS_PER_SEC, stats.flushes, K.size(), max_depth + 1, dt * 1e3);
 }
+template <class In, class Out>
+inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vector<Engine::Node> &K,
+                         const std::vector<std::vector<int>> &by_depth, const std::vector<char> &fused_rot,
+                         const std::vector<char> &fused_mul, int depth_first, int depth_last, const In &in, const Out &out)
+{
+    using Node = Engine::Node;
+    std::vector<const std::uint64_t *> va, vb, vc;
+    std::vector<std::uint64_t *> vo;
+    std::vector<std::uint32_t> ve;
+    for (int depth = depth_first; depth <= depth_last; ++depth) {
+        if (by_depth[depth].empty()) continue;
+        // groups of this depth: (kind, fused?, L, size, shared key)
+        std::map<std::tuple<int, int, int, int, const std::uint64_t *>, std::vector<int>> groups;
+        for (int i : by_depth[depth]) {
+            const Node &k = K[i];
+            if (fused_mul[i]) continue;  // runs inside its rotation
+            const std::uint64_t *shared = k.kind == Node::RELIN ? k.b->p : nullptr;
+            groups[std::make_tuple((int)k.kind, (int)fused_rot[i], k.L, k.size, shared)].push_back(i);
+        }
+        for (auto &g : groups) {
+            const int kind = std::get<0>(g.first), fz = std::get<1>(g.first), L = std::get<2>(g.first),
+                      size = std::get<3>(g.first);
+            const std::vector<int> &gi = g.second;
+            const int n = (int)gi.size();
+            va.clear(), vb.clear(), vc.clear(), vo.clear(), ve.clear();
+            ++stats.calls;
+            for (int i : gi) {
+                const Node &k = K[i];
+                va.push_back(in(k.a->p));
+                if (k.b) vb.push_back(in(k.b->p));
+                ve.push_back(k.elt);
+                if (fz) {
+                    const Node &m = K[k.mulpt_consumer];
+                    vc.push_back(in(m.b->p));
+                    vo.push_back(out(k.mulpt_consumer));
+                } else {
+                    vo.push_back(out(i));
+                }
+            }
+            switch (kind) {
+                case Node::ROT:
+                    if (fz)
+                        check(hefx_rotate_multiply_plain_batch(cx, L, n, va.data(), ve.data(), vb.data(), vc.data(), vo.data(),
+                                                               nullptr));
+                    else
+                        check(hefx_apply_galois_batch(cx, L, n, va.data(), ve.data(), vb.data(), vo.data(), nullptr));
+                    break;
+                case Node::MULPT:
+                    check(hefx_multiply_plain_batch(cx, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
+                    break;
+                case Node::MULCT:
+                    check(hefx_multiply_batch(cx, L, n, va.data(), vb.data(), vo.data(), nullptr));
+                    break;
+                case Node::RELIN:
+                    check(hefx_relinearize_batch(cx, L, n, va.data(), in(std::get<4>(g.first)), vo.data(), nullptr));
+                    break;
+                case Node::RESCALE:
+                    check(hefx_rescale_to_next_batch(cx, L, size, n, va.data(), vo.data(), nullptr));
+                    break;
+                case Node::ADD:
+                    check(hefx_add_batch(cx, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
+                    break;
+                case Node::SUB:
+                    check(hefx_sub_batch(cx, L, size, n, va.data(), vb.data(), vo.data(), nullptr));
+                    break;
+            }
+        }
+    }
+}
+
+inline hefx_context *Engine::device_context(int d)
+{
+    if (dev_ctx.empty()) {
+        dev_ctx.assign((std::size_t)ndev, nullptr);
+        dev_ctx[0] = ctx_raw;
+        replicas.resize((std::size_t)ndev);
+    }
+    if ((int)dev_ctx.size() < ndev) {  // ndev was raised after the first submission (tests)
+        dev_ctx.resize((std::size_t)ndev, nullptr);
+        replicas.resize((std::size_t)ndev);
+    }
+    if (!dev_ctx[d]) {
+        const int have = std::max(1, hefx_device_count());
+        const int home = hefx_context_device(ctx_raw);
+        hefx_context *cx = nullptr;
+        check(hefx_context_create(n, primes.data(), (int)primes.size(), (home + d) % have, &cx));
+        check(hefx_set_rescale_mode(cx, hefx_get_rescale_mode(ctx_raw)));
+        dev_ctx[d] = cx;
+    }
+    return dev_ctx[d];
+}
+
+inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
+                                int max_depth)
+{
+    const int nk = (int)K.size();
+    // connected sub-graphs of the recorded dependencies (shared EXTERNAL inputs -- keys, the weight ciphertext -- do not
+    // connect: they are replicated)
+    std::map<const std::uint64_t *, int> producer;
+    for (int i = 0; i < nk; ++i) producer[K[i].dst->p] = i;
+    std::vector<int> root(nk);
+    for (int i = 0; i < nk; ++i) root[i] = i;
+    std::function<int(int)> find = [&](int x) { return root[x] == x ? x : root[x] = find(root[x]); };
+    auto unite = [&](int a_, int b_) { root[find(a_)] = find(b_); };
+    for (int i = 0; i < nk; ++i)
+        for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
+            if (!*inp) continue;
+            auto p_ = producer.find((*inp)->p);
+            if (p_ != producer.end() && p_->second != i) unite(i, p_->second);
+        }
+    // cost of a sub-graph = its key switches (everything else is cheap); heaviest first onto the least loaded device
+    std::map<int, std::pair<long, std::vector<int>>> comps;
+    for (int i = 0; i < nk; ++i) {
+        auto &c_ = comps[find(i)];
+        c_.first += (K[i].kind == Node::ROT || K[i].kind == Node::RELIN) ? 16 : 1;
+        c_.second.push_back(i);
+    }
+    std::vector<std::pair<long, int>> order;
+    for (auto &c_ : comps) order.emplace_back(-c_.second.first, c_.first);
+    std::sort(order.begin(), order.end());
+    std::vector<long> load((std::size_t)ndev, 0);
+    std::vector<std::vector<int>> share((std::size_t)ndev);
+    std::vector<int> dev_of(nk, 0);
+    for (auto &o : order) {
+        const int d = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        load[d] += -o.first;
+        for (int i : comps[o.second].second) {
+            share[d].push_back(i);
+            dev_of[i] = d;
+        }
+    }
+    // references from inside the graph: a result nobody else holds is not copied home
+    std::vector<int> inner(nk, 0);
+    for (int i = 0; i < nk; ++i)
+        for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
+            if (!*inp) continue;
+            auto p_ = producer.find((*inp)->p);
+            if (p_ != producer.end()) ++inner[p_->second];
+        }
+    // per device > 0: result buffers of its nodes, replicas of the external inputs they read
+    std::vector<std::uint64_t *> tmp(nk, nullptr);
+    struct Cleanup {
+        Engine *e;
+        std::vector<std::uint64_t *> &tmp;
+        std::vector<int> &dev_of;
+        ~Cleanup()
+        {
+            for (std::size_t i = 0; i < tmp.size(); ++i)
+                if (tmp[i]) (void)hefx_free(e->dev_ctx[dev_of[i]], tmp[i]);
+        }
+    } cleanup{this, tmp, dev_of};
+    (void)device_context(0);
+    bool copied_in = false;
+    for (int d = 1; d < ndev; ++d) {
+        if (share[d].empty()) continue;
+        hefx_context *cx = device_context(d);
+        auto &rep = replicas[d];
+        for (auto it = rep.begin(); it != rep.end();) {  // replicas whose home buffer is gone
+            if (it->second.owner.expired()) {
+                (void)hefx_free(cx, it->second.p);
+                it = rep.erase(it);
+            } else
+                ++it;
+        }
+        for (int i : share[d]) {
+            void *p_ = nullptr;
+            const int rc = hefx_malloc(cx, K[i].dst->words * 8, &p_);
+            if (rc != HEFX_OK) raise(rc);
+            tmp[i] = static_cast<std::uint64_t *>(p_);
+            for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
+                if (!*inp || producer.count((*inp)->p)) continue;
+                auto hit = rep.find((*inp)->p);
+                if (hit != rep.end() && hit->second.owner.lock().get() == inp->get()) continue;
+                if (hit != rep.end()) {
+                    (void)hefx_free(cx, hit->second.p);
+                    rep.erase(hit);
+                }
+                void *r_ = nullptr;
+                const int rc2 = hefx_malloc(cx, (*inp)->words * 8, &r_);
+                if (rc2 != HEFX_OK) raise(rc2);
+                check(hefx_copy_peer(cx, r_, ctx_raw, (*inp)->p, (*inp)->words * 8, nullptr));  // on the home stream
+                rep[(*inp)->p] = Replica{*inp, static_cast<std::uint64_t *>(r_), (*inp)->words};
+                copied_in = true;
+            }
+        }
+    }
+    // the replicas were copied on the home device's stream, behind whatever produced them
+    if (copied_in) check(hefx_stream_sync(ctx_raw, nullptr));
+    // all devices advance depth by depth; every call is asynchronous on its own device
+    std::vector<std::vector<std::vector<int>>> by_depth((std::size_t)ndev);
+    for (int d = 0; d < ndev; ++d) by_depth[d] = nodes_by_depth(K, share[d], max_depth);
+    for (int depth = 0; depth <= max_depth; ++depth)
+        for (int d = 0; d < ndev; ++d) {
+            if (share[d].empty()) continue;
+            hefx_context *cx = dev_ctx[d];
+            auto &rep = replicas[d];
+            if (d == 0)
+                submit_nodes(cx, stats, K, by_depth[d], fused_rot, fused_mul, depth, depth,
+                             [](const std::uint64_t *p_) { return p_; }, [&](int i) { return K[i].dst->p; });
+            else
+                submit_nodes(cx, stats, K, by_depth[d], fused_rot, fused_mul, depth, depth,
+                             [&](const std::uint64_t *p_) -> const std::uint64_t * {
+                                 auto pr = producer.find(p_);
+                                 if (pr != producer.end()) return tmp[pr->second];
+                                 return rep.at(p_).p;
+                             },
+                             [&](int i) { return tmp[i]; });
+        }
+    // results that are visible outside the graph go home (on the producing device's stream), then the host waits for
+    // the other devices: the home device's later work must find them complete
+    for (int d = 1; d < ndev; ++d) {
+        if (share[d].empty()) continue;
+        for (int i : share[d]) {
+            if (fused_rot[i]) continue;  // the rotation inside a fused product was never written
+            if (K[i].dst.use_count() - 1 - inner[i] <= 0) continue;
+            check(hefx_copy_peer(ctx_raw, K[i].dst->p, dev_ctx[d], tmp[i], K[i].dst->words * 8, nullptr));
+        }
+        check(hefx_stream_sync(dev_ctx[d], nullptr));
+    }
+}
+
 inline BufPtr upload(const std::shared_ptr<Engine> &e, const std::vector<std::uint64_t> &h)
 {
     BufPtr b = new_buf(e, h.size());

@@ -45,6 +45,8 @@ _SIGS = {
     "hefx_upload": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "hefx_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "hefx_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "hefx_copy_peer": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "hefx_context_device": (_i, [_vp]),
     "hefx_memset_zero": (_i, [_vp, _vp, _sz, _vp]),
     "hefx_stream_sync": (_i, [_vp, _vp]),
     "hefx_ntt_forward": (_i, [_vp, _vp, _i, _i, _i, _vp]),

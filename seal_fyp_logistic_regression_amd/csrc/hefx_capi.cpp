@@ -575,6 +575,19 @@ extern "C" int hefx_copy(hefx_context *c, void *d_dst, const void *d_src, size_t
     HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return HEFX_OK;
 }
+extern "C" int hefx_copy_peer(hefx_context *dst, void *d_dst, hefx_context *src, const void *d_src, size_t bytes,
+                              void *stream)
+{
+    if (!dst) return fail(HEFX_ERR_INVALID, "null destination context");
+    CTXCHK(src);  // the copy is submitted on the source device
+    if (!d_dst || !d_src) return fail(HEFX_ERR_INVALID, "null pointer");
+    if (dst->device == src->device)
+        HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else
+        HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, (hipStream_t)stream));
+    return HEFX_OK;
+}
+extern "C" int hefx_context_device(const hefx_context *c) { return c ? c->device : -1; }
 extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
 {
     CTXCHK(c);

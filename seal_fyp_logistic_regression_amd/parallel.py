@@ -10,6 +10,7 @@ transform, never one per diagonal.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Sequence
 
 import numpy as np
@@ -39,6 +40,41 @@ def init_engine_comm(ev: Evaluator, group=None) -> None:
     eng.comm_init(world, rank, box[0])
 
 
+# How the exchange runs on the HIP engine (HEFX_ENGINE_COMM = auto | on | off; bench.py sets the attribute directly):
+#   auto  under torch's "nccl" backend (one device per rank, the precondition of RCCL) the engine attaches its OWN
+#         communicator on first use (init_engine_comm) and every exchange is hefx_allreduce_sum -- RCCL in place on the
+#         payload plus the local canonicalisation, nothing of it in Python; any other backend takes the torch path
+#   on    require the engine communicator (raise if it cannot be attached);   off   always the torch path
+ENGINE_COMM = os.environ.get("HEFX_ENGINE_COMM", "auto")
+
+
+class _DeviceWords:
+    """zero-copy view of an engine buffer for torch (torch.as_tensor reads __cuda_array_interface__): the collective
+    runs in place on the payload, no staging tensor"""
+
+    def __init__(self, ptr: int, nwords: int):
+        self.__cuda_array_interface__ = {"shape": (nwords,), "typestr": "<i8", "data": (int(ptr), False), "version": 3,
+                                         "strides": None}
+
+
+def _engine_comm_ready(ev: Evaluator, group, world: int) -> bool:
+    eng = ev.be.engine
+    if eng.comm_world == world:
+        return True
+    if ENGINE_COMM == "off" or eng.comm_world:
+        return False
+    import torch.distributed as dist
+    if ENGINE_COMM == "on" or dist.get_backend(group) == "nccl":
+        try:
+            init_engine_comm(ev, group)
+        except Exception:
+            if ENGINE_COMM == "on":
+                raise
+            return False
+        return eng.comm_world == world
+    return False
+
+
 def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertext:
     """sum of every rank's `ct` (same level/scale/size), bit-identical to a serial add_many"""
     import torch
@@ -47,19 +83,23 @@ def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertex
     world = dist.get_world_size(group)
     if world > 8:
         raise ValueError("the wrap-free uint64 sum argument holds for at most 8 addends of < 2^61")
-    if be.name == "hip" and be.engine.comm_world == world:  # communicator behind the C-ABI (init_engine_comm)
+    if be.name == "hip" and _engine_comm_ready(ev, group, world):  # communicator behind the C-ABI
         out = be.engine.copy(ct.data)
         be.engine.allreduce_sum(L, size, out)
         return Ciphertext()._set(out, size, L, ct.scale)
     if be.name == "hip":
-        from .engine import DeviceArray
+        # torch path: the collective runs IN PLACE on a copy of the payload, viewed as a torch tensor without staging.
+        # Engine calls and torch both submit to the device's default stream, so the copy is ordered before the
+        # collective and the canonicalisation after it; only a caller that has moved torch to another stream pays a wait.
         eng = be.engine
-        t = torch.empty(size * L * N, dtype=torch.int64, device=torch.device("cuda", eng.device))
-        eng.copy_raw(t.data_ptr(), ct.data.ptr, t.numel() * 8)   # default stream, ordered before the collective
+        out = eng.copy(ct.data)
+        t = torch.as_tensor(_DeviceWords(out.ptr, size * L * N), device=torch.device("cuda", eng.device))
+        cur = torch.cuda.current_stream(torch.device("cuda", eng.device))
+        if cur.cuda_stream != 0:
+            eng.sync()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-        torch.cuda.current_stream().synchronize()
-        out = DeviceArray(eng, (size, L, N))
-        eng.copy_raw(out.ptr, t.data_ptr(), t.numel() * 8)
+        if cur.cuda_stream != 0:
+            cur.synchronize()
         eng.reduce_canonical(L, size, out, addends=world)
         data = out
     else:  # oracle-backed twin (tests, gloo)

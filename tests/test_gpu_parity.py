@@ -261,7 +261,7 @@ def test_rotate_multiply_plain_batch_bit_exact(c3):
     from oracle import oracle as O
     o, e, _ = c3
     L = 5
-    n = 19  # > one chunk, ragged tail
+    n = 19  # one (partial) chunk since chunks hold up to 256 items; the multi-chunk default path: test_gpu_round3.py
     keys = {s: _rand_key(o, 1000 + s) for s in (1, 2)}
     dkeys = {s: e.to_device(k) for s, k in keys.items()}
     cts = [o.uniform(L, 2, 200 + i) for i in range(n)]
