@@ -46,6 +46,22 @@ struct KsWaves {
 
 namespace hefx {
 
+// 16-byte streaming (nontemporal) accesses: one global_load/store_dwordx4 nt per record.  As two 8-byte accesses a
+// streamed row costs twice the memory instructions, and 8-byte nt / sc1 accesses run at 0.54-0.70 x the 16-byte rate
+// (MI355X_MICROARCH.md, inter-workgroup visibility table).
+typedef u64 u64x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ulonglong2 nt_load16(const u64 *p)
+{
+    const u64x2_t v = __builtin_nontemporal_load(reinterpret_cast<const u64x2_t *>(p));
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void nt_store16(u64 *p, u64 a, u64 b)
+{
+    u64x2_t v;
+    v.x = a, v.y = b;
+    __builtin_nontemporal_store(v, reinterpret_cast<u64x2_t *>(p));
+}
+
 template <int LOGN>
 struct SplitCfg {
     using C = NttCfg<LOGN - 1>;  // the per-workgroup sub-transform
@@ -208,10 +224,11 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
     if (stream_x) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) __builtin_nontemporal_store(v[r], xd + C::idx_io(t, r));
+        for (int r = 0; r < 16; r += 2) nt_store16(xd + C::idx_io(t, r), v[r], v[r + 1]);  // (r, r+1) are one record
     } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) xd[C::idx_io(t, r)] = v[r];
+        for (int r = 0; r < 16; r += 2)
+            *reinterpret_cast<ulonglong2 *>(xd + C::idx_io(t, r)) = make_ulonglong2(v[r], v[r + 1]);
     }
 }
 
@@ -411,10 +428,8 @@ template <bool STREAM>
 __device__ __forceinline__ void mac_store(u64 *acc0, u64 *acc1, size_t w, const ulonglong2 &r0, const ulonglong2 &r1)
 {
     if (STREAM) {
-        __builtin_nontemporal_store(r0.x, acc0 + 2 * w);
-        __builtin_nontemporal_store(r0.y, acc0 + 2 * w + 1);
-        __builtin_nontemporal_store(r1.x, acc1 + 2 * w);
-        __builtin_nontemporal_store(r1.y, acc1 + 2 * w + 1);
+        nt_store16(acc0 + 2 * w, r0.x, r0.y);
+        nt_store16(acc1 + 2 * w, r1.x, r1.y);
     } else {
         reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
         reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
@@ -465,10 +480,7 @@ __device__ __forceinline__ void mac_unit(const DevTables &T, const KsItem *__res
         }
         const ulonglong2 *xp = reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)bl * L + i) * (L + 1) + jj) * n) + ww;
         if (STREAM) {  // read exactly once
-            ulonglong2 v;
-            v.x = __builtin_nontemporal_load(&xp->x);
-            v.y = __builtin_nontemporal_load(&xp->y);
-            return v;
+            return nt_load16(reinterpret_cast<const u64 *>(xp));
         }
         return *xp;
     };
@@ -760,8 +772,7 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, 4) void ks_ntt_macf_kernel(DevTa
         const u64 w0 = v[r], w1 = v[r + 1];
         u64 *p = xd + C::idx_out(t, r);
         if (stream_x) {
-            __builtin_nontemporal_store(w0, p);
-            __builtin_nontemporal_store(w1, p + 1);
+            nt_store16(p, w0, w1);
         } else {
             *reinterpret_cast<ulonglong2 *>(p) = make_ulonglong2(w0, w1);
         }
@@ -798,18 +809,35 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
 // (5) out[b][c][j] = (acc[b][c][j] - NTT_j((u mod q_j) - (P/2 mod q_j))) * P^-1 + add-in, optionally * pt.
 // The epilogue runs in the row's arithmetic policy directly on the unfinished transform values.
 // ------------------------------------------------------------------------------------------------
+// P^-1 mod q_j in the row's policy.  Fetched ONCE per workgroup (md_pinv) and handed to the epilogue by value: read
+// from the table inside the per-record epilogue it was re-loaded after every store to the output (the compiler cannot
+// prove the table and the output distinct), each load followed by s_waitcnt vmcnt(0) -- which also waited for the
+// stores just issued (found in the ISA, round 3; this is where much of the kernel's parked wave time went).
+struct PinvU {
+    ulonglong2 v;
+};
+struct PinvF {
+    double2 v;
+};
+template <bool L16>
+__device__ __forceinline__ PinvU md_pinv(ArithU64T<L16>, const DevTables &T, int sp, int j)
+{
+    return PinvU{T.invmod[(size_t)sp * T.k + j]};
+}
+__device__ __forceinline__ PinvF md_pinv(ArithF64, const DevTables &T, int sp, int j)
+{
+    return PinvF{T.invmodf[(size_t)sp * T.k + j]};
+}
 template <bool L16>
 __device__ __forceinline__ u64 md_epilogue(ArithU64T<L16>, u64 f, u64 acc, u64 sadd, u64 pt, bool has_pt,
-                                           const typename ArithU64T<L16>::Ctx &cx, const DevTables &T, int sp, int j,
-                                           const ModConst &mc)
+                                           const typename ArithU64T<L16>::Ctx &cx, const PinvU &pinv, const ModConst &mc)
 {
-    return ArithU64T<L16>::moddown(f, acc, sadd, pt, has_pt, cx, T.invmod[(size_t)sp * T.k + j], mc);
+    return ArithU64T<L16>::moddown(f, acc, sadd, pt, has_pt, cx, pinv.v, mc);
 }
 __device__ __forceinline__ u64 md_epilogue(ArithF64, double f, u64 acc, u64 sadd, u64 pt, bool has_pt,
-                                           const ArithF64::Ctx &cx, const DevTables &T, int sp, int j,
-                                           const ModConst &)
+                                           const ArithF64::Ctx &cx, const PinvF &pinv, const ModConst &)
 {
-    return ArithF64::moddown(f, acc, sadd, pt, has_pt, cx, T.invmodf[(size_t)sp * T.k + j]);
+    return ArithF64::moddown(f, acc, sadd, pt, has_pt, cx, pinv.v);
 }
 
 template <int LOGN, class A>
@@ -823,6 +851,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const int sp = T.k - 1;
     const u64 q = mc.q;
     const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
+    const auto pinv = md_pinv(A{}, T, sp, j);
     const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
     // u < P is reduced modulo q_j and (P/2 mod q_j) subtracted in the row's policy (exact for any 64-bit word)
     const InMode mode = {true, true, true, half_j};
@@ -837,139 +866,81 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const u64 *__restrict__ addrow = it.c_in + ((size_t)(relin ? c : 0) * L + j) * SC::N;
     const bool has_add = relin || c == 0;
     const uint32_t elt = relin ? 1u : item_elt(it);
-    auto addin = [&](int idx) -> u64 {
-        if (!has_add) return 0;
-        return addrow[elt == 1u ? (uint32_t)(off + idx) : galois_index((uint32_t)(off + idx), elt, LOGN)];
-    };
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
-    if constexpr (C::R == 0) {
-        // N = 8192: split_fwd_raw delivers the pair layout idx_io (record t + T*g = two adjacent words per lane, lanes
-        // adjacent; NttCfg::idx_io): 16-byte operand loads and stores, 1 KiB contiguous per instruction
-        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
-#pragma unroll
-        for (int g0 = 0; g0 < 8; g0 += 4) {
-            ulonglong2 a[4], sa[4], pp[4];
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int rec = t + C::T * (g0 + g);
-                a[g] = reinterpret_cast<const ulonglong2 *>(acc)[rec];
-                sa[g] = !has_add ? make_ulonglong2(0, 0)
-                        : elt == 1u ? reinterpret_cast<const ulonglong2 *>(addrow + off)[rec]
-                                    : gather_pair(addrow, (uint32_t)(off / 2 + rec), elt, LOGN);
-                pp[g] = pt ? reinterpret_cast<const ulonglong2 *>(pt)[rec] : make_ulonglong2(0, 0);
-            }
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                ulonglong2 o;
-                o.x = md_epilogue(A{}, f[2 * (g0 + g)], a[g].x, sa[g].x, pp[g].x, pt != nullptr, cx, T, sp, j, mc);
-                o.y = md_epilogue(A{}, f[2 * (g0 + g) + 1], a[g].y, sa[g].y, pp[g].y, pt != nullptr, cx, T, sp, j, mc);
-                reinterpret_cast<ulonglong2 *>(dst)[t + C::T * (g0 + g)] = o;
-            }
-        }
-    } else if constexpr (KsWaves<LOGN>::FWD <= 2) {
-        // 256-VGPR builds (N <= 8192): the epilogue's operands are independent of the transform, so the first group's
-        // loads are issued BEFORE it (they land while the butterflies run) and the groups are software-pipelined --
-        // the loads of group g+1 are in flight while group g is computed and stored.  At the 128-VGPR cap of
-        // N = 16384 the extra buffers spill and cost more than they hide.
-        u64 a[2][4], sadd[2][4], pp[2][4];
-        auto fetch = [&](int hh, int bufi) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int idx = C::idx_io(t, 4 * hh + r);
-                a[bufi][r] = acc[idx];
-                sadd[bufi][r] = addin(idx);
-                pp[bufi][r] = pt ? pt[idx] : 0;
-            }
-        };
-        fetch(0, 0);
-        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
-#pragma unroll
-        for (int hh = 0; hh < 4; ++hh) {
-            const int cur = hh & 1;
-            if (hh + 1 < 4) fetch(hh + 1, cur ^ 1);
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                dst[C::idx_io(t, 4 * hh + r)] = md_epilogue(A{}, f[4 * hh + r], a[cur][r], sadd[cur][r], pp[cur][r],
-                                                             pt != nullptr, cx, T, sp, j, mc);
-        }
-    } else {
-        // 128-VGPR builds (N >= 16384).  Epilogue knobs (experiments; defaults are what the tree ships):
-        //   HEFX_EPI       operands fetched per group (4, 8 or 16 of the thread's 16 coefficients)
-        //   HEFX_EPI_PIPE  1: the next group's operands are fetched before the current group is computed
-        //   HEFX_EPI_EARLY 1: the first group's operands are fetched after the transform's last LDS exchange, i.e.
-        //                  they travel while its final stages compute
+    {
+        // Epilogue knobs (experiments; defaults are what the tree ships):
+        //   HEFX_EPI       operands fetched per group (2, 4, 8 or 16 of the thread's 16 coefficients)
+        //   HEFX_EPI_PIPE  1: the next group's operands are fetched before the current group is computed and stored;
+        //                  default in the 256-VGPR builds (N <= 8192), where the second buffer is free
+        // Every ring size ends its forward transform in the pair layout idx_io (two adjacent words per lane, lanes
+        // adjacent): 16-byte operand loads and stores, 1 KiB contiguous per instruction.
 #ifndef HEFX_EPI
 #define HEFX_EPI 4
 #endif
 #ifndef HEFX_EPI_PIPE
-#define HEFX_EPI_PIPE 0
+#define HEFX_EPI_PIPE (KsWaves<LOGN>::FWD <= 2)
 #endif
-#ifndef HEFX_EPI_EARLY
-#define HEFX_EPI_EARLY 0
-#endif
-        // the FP64-policy rows (8 of 10 at C3) leave registers free under the kernel's cap -- their values, twiddles and
-        // constants are half as wide as the integer policy's -- so they can afford what the integer rows cannot
 #ifndef HEFX_EPI_F64
 #define HEFX_EPI_F64 HEFX_EPI
 #endif
 #ifndef HEFX_EPI_F64_PIPE
 #define HEFX_EPI_F64_PIPE HEFX_EPI_PIPE
 #endif
-#ifndef HEFX_EPI_F64_EARLY
-#define HEFX_EPI_F64_EARLY HEFX_EPI_EARLY
-#endif
-#ifndef HEFX_EPI_F64_PRE  // 1: the first group's operands are fetched BEFORE the transform (they do not depend on it)
-#define HEFX_EPI_F64_PRE 0
-#endif
         constexpr int GS = A::IS_F64 ? HEFX_EPI_F64 : HEFX_EPI, NG = 16 / GS;
         constexpr bool PIPE = A::IS_F64 ? HEFX_EPI_F64_PIPE : HEFX_EPI_PIPE;
-        constexpr bool EARLY = A::IS_F64 ? HEFX_EPI_F64_EARLY : HEFX_EPI_EARLY;
-        constexpr bool PRE = A::IS_F64 && HEFX_EPI_F64_PRE;
         constexpr int NBUF = PIPE ? 2 : 1;
-        u64 a[NBUF][GS], sadd[NBUF][GS], pp[NBUF][GS];
         // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
         // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
-        static_assert(C::R >= 1 && GS % 2 == 0, "record layout");
-        auto fetch = [&](int g, int bufi) {
+        static_assert(GS % 2 == 0, "record layout");
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+        // The epilogue is SPECIALISED on (add-in?, plaintext?) by one workgroup-uniform branch around it (round 3): with
+        // the two conditions tested per record inside the loop the loads sat in conditional blocks, and the compiler's
+        // wait-count insertion closed every such block with s_waitcnt vmcnt(0) -- a full drain, stores included, per
+        // record.  Straight-line bodies get counted waits.  The gather handles the identity too (galois_index(i, 1) = i),
+        // so "rotated or not" needs no branch either.
+        auto epilogue = [&](auto has_add_c, auto has_pt_c) {
+            constexpr bool HA = decltype(has_add_c)::value, HP = decltype(has_pt_c)::value;
+            u64 a[NBUF][GS], sadd[NBUF][GS], pp[NBUF][GS];
+            auto fetch = [&](int g, int bufi) {
 #pragma unroll
-            for (int r = 0; r < GS; r += 2) {
-                const int idx = C::idx_io(t, GS * g + r);
-                const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
-                ulonglong2 sv = make_ulonglong2(0, 0);
-                if (has_add)
-                    sv = elt == 1u ? *reinterpret_cast<const ulonglong2 *>(addrow + off + idx)
-                                   : gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
-                const ulonglong2 pv = pt ? *reinterpret_cast<const ulonglong2 *>(pt + idx) : make_ulonglong2(0, 0);
-                a[bufi][r] = av.x, a[bufi][r + 1] = av.y;
-                sadd[bufi][r] = sv.x, sadd[bufi][r + 1] = sv.y;
-                pp[bufi][r] = pv.x, pp[bufi][r + 1] = pv.y;
+                for (int r = 0; r < GS; r += 2) {
+                    const int idx = C::idx_io(t, GS * g + r);
+                    const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+                    ulonglong2 sv = make_ulonglong2(0, 0), pv = make_ulonglong2(0, 0);
+                    if constexpr (HA) sv = gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
+                    if constexpr (HP) pv = *reinterpret_cast<const ulonglong2 *>(pt + idx);
+                    a[bufi][r] = av.x, a[bufi][r + 1] = av.y;
+                    sadd[bufi][r] = sv.x, sadd[bufi][r + 1] = sv.y;
+                    pp[bufi][r] = pv.x, pp[bufi][r + 1] = pv.y;
+                }
+            };
+            fetch(0, 0);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                const int cur = PIPE ? (g & 1) : 0;
+                if (PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
+#pragma unroll
+                for (int r = 0; r < GS; r += 2) {  // one 16-byte store per record
+                    ulonglong2 o;
+                    o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], HP, cx, pinv, mc);
+                    o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], HP, cx, pinv, mc);
+                    *reinterpret_cast<ulonglong2 *>(dst + C::idx_io(t, GS * g + r)) = o;
+                }
+                if (!PIPE && g + 1 < NG) fetch(g + 1, 0);
             }
         };
-        if constexpr (PRE) {
-            fetch(0, 0);
-            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
-        } else if constexpr (EARLY) {
-            auto hook = [&]() { fetch(0, 0); };
-            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, decltype(hook)>(f, ld, mode, mc, lds, tw, cx, t, h, hook);
+        if (has_add) {
+            if (pt)
+                epilogue(std::true_type{}, std::true_type{});
+            else
+                epilogue(std::true_type{}, std::false_type{});
         } else {
-            split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
-            fetch(0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            const int cur = PIPE ? (g & 1) : 0;
-            if (PIPE && g + 1 < NG) fetch(g + 1, cur ^ 1);
-#pragma unroll
-            for (int r = 0; r < GS; r += 2) {  // one 16-byte store per record
-                ulonglong2 o;
-                o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], pt != nullptr, cx, T, sp, j, mc);
-                o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], pt != nullptr, cx,
-                                  T, sp, j, mc);
-                *reinterpret_cast<ulonglong2 *>(dst + C::idx_io(t, GS * g + r)) = o;
-            }
-            if (!PIPE && g + 1 < NG) fetch(g + 1, 0);
+            if (pt)
+                epilogue(std::false_type{}, std::true_type{});
+            else
+                epilogue(std::false_type{}, std::false_type{});
         }
     }
 }
@@ -1123,6 +1094,7 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
     using C = typename QC::C;
     const int sp = T.k - 1;
     const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
+    const auto pinv = md_pinv(A{}, T, sp, j);
     const InMode mode = {true, true, true, half_j};
     const EoQuadLoader<LOGN> ld{S.u + ((size_t)b * 2 + c) * QC::N, t};
     const size_t off = (size_t)part * QC::Q;
@@ -1132,30 +1104,51 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
     const uint32_t elt = relin ? 1u : item_elt(it);
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * QC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * QC::N + off;
-    // the epilogue's operands do not depend on the transform: fetched before it, they travel while it runs
-    // (registers (r, r+1), r even, are one 16-byte record in every idx_out layout: one gathered pair per record)
-    u64 a[8], sadd[8], pp[8];
+    // The epilogue's operands do not depend on the transform: fetched before it, they travel while it runs (registers
+    // (r, r+1), r even, are one 16-byte record in every idx_out layout: one gathered pair per record).  Fetch and
+    // epilogue are specialised on (add-in?, plaintext?) like the split-2 kernel's -- conditional loads cost a full
+    // s_waitcnt vmcnt(0) each -- which here means the transform sits inside the specialisation: four copies of the
+    // eight-coefficient core, a price the one-key-switch-at-a-time latency path is worth.
+    auto body = [&](auto has_add_c, auto has_pt_c) {
+        constexpr bool HA = decltype(has_add_c)::value, HP = decltype(has_pt_c)::value;
+        u64 a[8], sadd[8], pp[8];
+        auto fetch = [&]() {
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-        const int idx = C::idx_out(t, r);
-        const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
-        ulonglong2 sv = make_ulonglong2(0, 0);
-        if (has_add)
-            sv = elt == 1u ? *reinterpret_cast<const ulonglong2 *>(addrow + off + idx)
-                           : gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
-        const ulonglong2 pv = pt ? *reinterpret_cast<const ulonglong2 *>(pt + idx) : make_ulonglong2(0, 0);
-        a[r] = av.x, a[r + 1] = av.y;
-        sadd[r] = sv.x, sadd[r + 1] = sv.y;
-        pp[r] = pv.x, pp[r + 1] = pv.y;
-    }
-    typename A::V f[8];
-    quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
+            for (int r = 0; r < 8; r += 2) {
+                const int idx = C::idx_out(t, r);
+                const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+                ulonglong2 sv = make_ulonglong2(0, 0), pv = make_ulonglong2(0, 0);
+                if constexpr (HA) sv = gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
+                if constexpr (HP) pv = *reinterpret_cast<const ulonglong2 *>(pt + idx);
+                a[r] = av.x, a[r + 1] = av.y;
+                sadd[r] = sv.x, sadd[r + 1] = sv.y;
+                pp[r] = pv.x, pp[r + 1] = pv.y;
+            }
+        };
+        // 1024-thread workgroups (N = 32768) are capped at 128 VGPRs: there the operands are fetched after the transform
+        constexpr bool PRE = QC::T < 1024;
+        if constexpr (PRE) fetch();
+        typename A::V f[8];
+        quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
+        if constexpr (!PRE) fetch();
 #pragma unroll
-    for (int r = 0; r < 8; r += 2) {
-        ulonglong2 o;
-        o.x = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], pt != nullptr, cx, T, sp, j, mc);
-        o.y = md_epilogue(A{}, f[r + 1], a[r + 1], sadd[r + 1], pp[r + 1], pt != nullptr, cx, T, sp, j, mc);
-        *reinterpret_cast<ulonglong2 *>(dst + C::idx_out(t, r)) = o;
+        for (int r = 0; r < 8; r += 2) {
+            ulonglong2 o;
+            o.x = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], HP, cx, pinv, mc);
+            o.y = md_epilogue(A{}, f[r + 1], a[r + 1], sadd[r + 1], pp[r + 1], HP, cx, pinv, mc);
+            *reinterpret_cast<ulonglong2 *>(dst + C::idx_out(t, r)) = o;
+        }
+    };
+    if (has_add) {
+        if (pt)
+            body(std::true_type{}, std::true_type{});
+        else
+            body(std::true_type{}, std::false_type{});
+    } else {
+        if (pt)
+            body(std::false_type{}, std::true_type{});
+        else
+            body(std::false_type{}, std::false_type{});
     }
 }
 

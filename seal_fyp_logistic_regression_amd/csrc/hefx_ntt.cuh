@@ -229,10 +229,14 @@ typedef ArithU64T<true> ArithU64L;   // forward transforms of primes below 2^60
 template <class F>
 __device__ __forceinline__ void fwd_int_dispatch(const ModConst &mc, const F &f)
 {
+#ifdef HEFX_NO_L16  // A/B knob (tools/build_variant.sh): the [0,8q) butterfly everywhere
+    f(ArithU64{});
+#else
     if (mc.q >> 60)
         f(ArithU64{});
     else
         f(ArithU64L{});
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -16,6 +16,6 @@ python tools/encode_bench.py > $out/encode.txt 2>&1
 tools/run_reference_drivers.sh $out/drivers > $out/drivers.log 2>&1
 # the reference's LR driver over 2000 rows, recorded and call by call
 python tools/make_lr_csv.py 2000 drivers/_ref/pulsar_stars_copy.csv
-( cd drivers/_ref && ( time SEAL_SHIM_STATS=1 timeout 300 ./logistic_regression_ckks ) > ../../$out/lr_driver_2000.txt 2>&1; ( time SEAL_SHIM_LAZY=0 timeout 300 ./logistic_regression_ckks ) > ../../$out/lr_driver_2000_eager.txt 2>&1; rm -f pulsar_stars_copy.csv )
+( cd drivers/_ref && ( time SEAL_SHIM_STATS=1 timeout 300 ./logistic_regression_ckks ) > ../../$out/lr_driver_2000.txt 2>&1; ( time SEAL_SHIM_LAZY=0 timeout 300 ./logistic_regression_ckks ) > ../../$out/lr_driver_2000_eager.txt 2>&1; ( time SEAL_SHIM_STATS=1 SEAL_SHIM_DEVICES=2 timeout 300 ./logistic_regression_ckks ) > ../../$out/lr_driver_2000_devices2.txt 2>&1; rm -f pulsar_stars_copy.csv )
 for f in $out/lr_driver_2000*.txt; do tail -n 40 $f > $f.tail; mv $f.tail $f; done
 ls $out
