@@ -61,6 +61,8 @@ struct KsItem {
 };
 constexpr uint32_t KS_ALIASED = 1;
 
+// (global-address-space accessors gld8 / gld16 / gst16 ...: hefx_modarith.cuh)
+
 // NTT-domain index map of the automorphism X -> X^elt: out[i] = in[galois_index(i)], with
 // galois_index(i) = bitrev(((elt * (2 bitrev(i) + 1)) mod 2N - 1) / 2).  Two v_bfrev, one 24-bit multiply: cheaper
 // than a table lookup and no table to keep cache-resident.  Structure the kernels rely on: positions 2j and 2j+1 map

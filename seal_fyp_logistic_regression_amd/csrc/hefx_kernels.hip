@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void add_many_kernel(DevTables T, int L, size_
         const u64 q = T.mods[(int)(row % (size_t)L)].q;
         ulonglong2 acc = accumulate ? out[w] : make_ulonglong2(0, 0);
         for (int i = 0; i < n; ++i) {
-            ulonglong2 x = reinterpret_cast<const ulonglong2 *>(g.p[i])[w];
+            ulonglong2 x = gld16(g.p[i] + 2 * w);
             acc.x = addmod(acc.x, x.x, q);
             acc.y = addmod(acc.y, x.y, q);
         }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void add_many_table_kernel(DevTables T, int L,
         const u64 q = T.mods[(int)(row % (size_t)L)].q;
         ulonglong2 acc = make_ulonglong2(0, 0);
         for (int i = first; i < last; ++i) {
-            const ulonglong2 x = reinterpret_cast<const ulonglong2 *>(ptrs[i])[w];
+            const ulonglong2 x = gld16(ptrs[i] + 2 * w);
             acc.x = addmod(acc.x, x.x, q);
             acc.y = addmod(acc.y, x.y, q);
         }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void mulplain_sum_kernel(DevTables T, int L, i
     const size_t total_pairs = poly_pairs * (size_t)size;
     const int gi = blockIdx.y;
     const int first = gi * group, last = first + group < n ? first + group : n;
-    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + gi]));
+    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>((const_cast<u64 *>(tab[2 * n + gi])));
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
          w += (size_t)gridDim.x * blockDim.x) {
         const size_t wp = w % poly_pairs;  // the plaintext word every poly of the ciphertext meets
@@ -243,8 +243,8 @@ __global__ __launch_bounds__(256) void mulplain_sum_kernel(DevTables T, int L, i
             ulonglong2 c[4], p[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                c[u] = reinterpret_cast<const ulonglong2 *>(tab[i + u])[w];
-                p[u] = reinterpret_cast<const ulonglong2 *>(tab[n + i + u])[wp];
+                c[u] = gld16(tab[i + u] + 2 * w);
+                p[u] = gld16(tab[n + i + u] + 2 * wp);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -258,15 +258,15 @@ __global__ __launch_bounds__(256) void mulplain_sum_kernel(DevTables T, int L, i
             }
         }
         for (; i < last; ++i) {
-            const ulonglong2 c = reinterpret_cast<const ulonglong2 *>(tab[i])[w];
-            const ulonglong2 p = reinterpret_cast<const ulonglong2 *>(tab[n + i])[wp];
+            const ulonglong2 c = gld16(tab[i] + 2 * w);
+            const ulonglong2 p = gld16(tab[n + i] + 2 * wp);
             mac128(xl, xh, c.x, p.x);
             mac128(yl, yh, c.y, p.y);
         }
         ulonglong2 r;
         r.x = barrett128(xl, xh, mc);
         r.y = barrett128(yl, yh, mc);
-        out[w] = r;
+        gst16(out + w, r);
     }
 }
 
@@ -318,9 +318,9 @@ __global__ __launch_bounds__(256) void multiply_kernel(DevTables T, int L, size_
             mac128(lo, hi, a1.y, b0.y);
             c1.y = barrett128(lo, hi, mc);
         }
-        out[w] = c0;
-        out[w + pairs_per_poly] = c1;
-        out[w + 2 * pairs_per_poly] = c2;
+        gst16(out + w, c0);
+        gst16(out + w + pairs_per_poly, c1);
+        gst16(out + w + 2 * pairs_per_poly, c2);
     }
 }
 
@@ -343,13 +343,13 @@ __global__ __launch_bounds__(256) void multiply_table_kernel(DevTables T, int L,
 {
     const int logn = T.logn;
     const int item = blockIdx.y;
-    const ulonglong2 *__restrict__ a = reinterpret_cast<const ulonglong2 *>(tab[item]);
-    const ulonglong2 *__restrict__ b = reinterpret_cast<const ulonglong2 *>(tab[n + item]);
-    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + item]));
+    const ulonglong2 *__restrict__ a = reinterpret_cast<const ulonglong2 *>((tab[item]));
+    const ulonglong2 *__restrict__ b = reinterpret_cast<const ulonglong2 *>((tab[n + item]));
+    ulonglong2 *__restrict__ out = reinterpret_cast<ulonglong2 *>((const_cast<u64 *>(tab[2 * n + item])));
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < pairs_per_poly;
          w += (size_t)gridDim.x * blockDim.x) {
         const ModConst mc = T.mods[(int)(w >> (logn - 1))];
-        const ulonglong2 a0 = a[w], a1 = a[w + pairs_per_poly], b0 = b[w], b1 = b[w + pairs_per_poly];
+        const ulonglong2 a0 = gld16(a + w), a1 = gld16(a + w + pairs_per_poly), b0 = gld16(b + w), b1 = gld16(b + w + pairs_per_poly);
         ulonglong2 c0, c1, c2;
         c0.x = mulmod(a0.x, b0.x, mc);
         c0.y = mulmod(a0.y, b0.y, mc);
@@ -363,9 +363,9 @@ __global__ __launch_bounds__(256) void multiply_table_kernel(DevTables T, int L,
         mac128(lo, hi, a0.y, b1.y);
         mac128(lo, hi, a1.y, b0.y);
         c1.y = barrett128(lo, hi, mc);
-        out[w] = c0;
-        out[w + pairs_per_poly] = c1;
-        out[w + 2 * pairs_per_poly] = c2;
+        gst16(out + w, c0);
+        gst16(out + w + pairs_per_poly, c1);
+        gst16(out + w + 2 * pairs_per_poly, c2);
     }
 }
 
@@ -388,17 +388,17 @@ __global__ __launch_bounds__(256) void addsub_table_kernel(DevTables T, int L, s
 {
     const int logn = T.logn;
     const int item = blockIdx.y;
-    const ulonglong2 *a = reinterpret_cast<const ulonglong2 *>(tab[item]);
-    const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(tab[n + item]);
-    ulonglong2 *out = reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(tab[2 * n + item]));
+    const ulonglong2 *a = reinterpret_cast<const ulonglong2 *>((tab[item]));
+    const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>((tab[n + item]));
+    ulonglong2 *out = reinterpret_cast<ulonglong2 *>((const_cast<u64 *>(tab[2 * n + item])));
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
          w += (size_t)gridDim.x * blockDim.x) {
         const u64 q = T.mods[(int)((w >> (logn - 1)) % (size_t)L)].q;
-        const ulonglong2 x = a[w], y = b[w];
+        const ulonglong2 x = gld16(a + w), y = gld16(b + w);
         ulonglong2 r;
         r.x = SUB ? submod(x.x, y.x, q) : addmod(x.x, y.x, q);
         r.y = SUB ? submod(x.y, y.y, q) : addmod(x.y, y.y, q);
-        out[w] = r;
+        gst16(out + w, r);
     }
 }
 

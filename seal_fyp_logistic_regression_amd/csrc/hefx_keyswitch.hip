@@ -113,7 +113,7 @@ __device__ static __forceinline__ uint32_t eo_nat(int t, int r)
 __device__ __forceinline__ ulonglong2 gather_pair(const u64 *__restrict__ src, uint32_t j, uint32_t elt, int logn)
 {
     const uint32_t p = galois_index(2u * j, elt, logn);
-    const ulonglong2 v = reinterpret_cast<const ulonglong2 *>(src)[p >> 1];
+    const ulonglong2 v = gld16(src + 2 * (size_t)(p >> 1));
     return (p & 1u) ? make_ulonglong2(v.y, v.x) : v;
 }
 __device__ __forceinline__ uint32_t item_elt(const KsItem &it) { return it.elt ? it.elt : 1u; }
@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void ks_alias_copy_kernel(DevTables T, const K
     if (!(it.flags & KS_ALIASED)) return;
     const size_t n = (size_t)1 << T.logn;
     const size_t w = (size_t)blockIdx.y * n + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;  // row = blockIdx.y < 2L
-    *reinterpret_cast<ulonglong2 *>(const_cast<u64 *>(it.c_in) + w) = *reinterpret_cast<const ulonglong2 *>(it.c_out + w);
+    gst16(const_cast<u64 *>(it.c_in) + w, gld16(it.c_out + w));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -431,34 +431,87 @@ __device__ __forceinline__ void mac_store(u64 *acc0, u64 *acc1, size_t w, const 
         nt_store16(acc0 + 2 * w, r0.x, r0.y);
         nt_store16(acc1 + 2 * w, r1.x, r1.y);
     } else {
-        reinterpret_cast<ulonglong2 *>(acc0)[w] = r0;
-        reinterpret_cast<ulonglong2 *>(acc1)[w] = r1;
+        gst16(acc0 + 2 * w, r0);
+        gst16(acc1 + 2 * w, r1);
     }
 }
 
-// NI consecutive items (bl .. bl+NI-1) that share `key`; xload(bl, i, w) = record w of digit i's row for this modulus
-template <class P, int NI, bool STREAM, class XL, class AR>
+// NI consecutive items that share `key`.  own[e] / own_elt[e]: item e's input row for digit jj's own prime and its
+// Galois element (1: no rotation), used when jj < L; xrow(e, i): digit i's transformed row for this modulus in scratch x;
+// acc0 / acc1: the two accumulator rows of item e.
+// Shape of the loop (round 3, after reading the ISA): the own-prime term is peeled out in front, so the body over the
+// other digits has no conditional loads -- the old form tested i == jj per digit, re-read the item descriptor from
+// memory inside that branch and closed every conditional block with s_waitcnt vmcnt(0): 52 full drains and not one
+// counted wait in the kernel -- and the operands of digit i+1 are requested before digit i is accumulated.
+template <class P, int NI, bool STREAM, class XR>
 __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, int L, int jj, int m, size_t n, size_t w,
-                                          int bl, const XL &xload, const AR &accrow)
+                                          const u64 *const (&own)[NI], const uint32_t (&own_elt)[NI], const XR &xrow,
+                                          u64 *const (&acc0)[NI], u64 *const (&acc1)[NI])
 {
     const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
+    const int logn = T.logn;
+    const size_t kpoly = (size_t)T.k * n;
     P A[NI];
-    for (int i = 0; i < L; ++i) {
-        const u64 *kbase = key + ((size_t)i * 2 * T.k + m) * n;
-        ulonglong2 xb[NI];
+    auto load_k = [&](int i, ulonglong2 &k0, ulonglong2 &k1) {
+        const u64 *kb = key + ((size_t)i * 2 * T.k + m) * n;
+        k0 = gld16(kb + 2 * w);
+        k1 = gld16(kb + kpoly + 2 * w);
+    };
+    auto load_x = [&](int i, ulonglong2 (&xb)[NI]) {
 #pragma unroll
-        for (int e = 0; e < NI; ++e) xb[e] = xload(bl + e, i, w);
-        const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
-        const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
+        for (int e = 0; e < NI; ++e) {
+            const u64 *xp = xrow(e, i) + 2 * w;
+            xb[e] = STREAM ? nt_load16(xp) : gld16(xp);  // read exactly once
+        }
+    };
+    if (jj < L) {  // the digit in NTT form modulo its own prime: the (rotated) input row itself, gathered
+        ulonglong2 xb[NI], k0, k1;
+#pragma unroll
+        for (int e = 0; e < NI; ++e) xb[e] = gather_pair(own[e], (uint32_t)w, own_elt[e], logn);
+        load_k(jj, k0, k1);
         const typename P::K k = P::kin(k0, k1, cx);
 #pragma unroll
-        for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[e], i == jj, cx), k, cx);
+        for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[e], true, cx), k, cx);
+    }
+#ifndef HEFX_MAC_GROUP
+#define HEFX_MAC_GROUP 1
+#endif
+    // the other digits, HEFX_MAC_GROUP at a time: the operands of a whole group are requested up front in straight-line
+    // code, so the waits inside the group are COUNTED (digit g is accumulated while digits g+1.. are still in flight).
+    // A software-pipelined rolled loop does not get that: the wait-count pass merges the pending loads that cross the
+    // loop's back edge into s_waitcnt vmcnt(0).  Four covers the non-own digits of L = 5 in one group.
+    constexpr int G = HEFX_MAC_GROUP;
+    auto digit_at = [&](int r) { return r < jj ? r : r + 1; };  // r-th digit other than jj
+    const int nd = jj < L ? L - 1 : L;
+    int r0 = 0;
+    for (; r0 + G <= nd; r0 += G) {
+        ulonglong2 xb[G][NI], k0[G], k1[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            load_x(digit_at(r0 + g), xb[g]);
+            load_k(digit_at(r0 + g), k0[g], k1[g]);
+        }
+        HEFX_STAGE_FENCE();  // the scheduler otherwise sinks every load next to its use (one digit in flight at a time)
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const typename P::K k = P::kin(k0[g], k1[g], cx);
+#pragma unroll
+            for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[g][e], false, cx), k, cx);
+        }
+    }
+    for (; r0 < nd; ++r0) {  // remainder, one digit at a time
+        ulonglong2 xb[NI], k0, k1;
+        load_x(digit_at(r0), xb);
+        load_k(digit_at(r0), k0, k1);
+        const typename P::K k = P::kin(k0, k1, cx);
+#pragma unroll
+        for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[e], false, cx), k, cx);
     }
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         ulonglong2 r0, r1;
         A[e].result(r0, r1, cx);
-        mac_store<STREAM>(accrow(bl + e, 0), accrow(bl + e, 1), w, r0, r1);
+        mac_store<STREAM>(acc0[e], acc1[e], w, r0, r1);
     }
 }
 
@@ -467,33 +520,29 @@ template <bool STREAM>
 __device__ __forceinline__ void mac_unit(const DevTables &T, const KsItem *__restrict__ items, int L, int relin, int item0,
                                          int count, const KsScratch &S, int jj, int bl0, size_t w)
 {
-    const int logn = T.logn;
-    const size_t n = (size_t)1 << logn;
+    const size_t n = (size_t)1 << T.logn;
     const int m = jj < L ? jj : T.k - 1;
-    // digit i in slot jj: its transform to that modulus from scratch x -- or, for its own prime (i == jj), the
-    // Galois-permuted input row itself, gathered from the source ciphertext
-    auto xload = [&](int bl, int i, size_t ww) -> ulonglong2 {
-        if (i == jj) {
-            const KsItem it = items[item0 + bl];
-            const u64 *src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * n;
-            return relin ? reinterpret_cast<const ulonglong2 *>(src)[ww] : gather_pair(src, (uint32_t)ww, item_elt(it), logn);
-        }
-        const ulonglong2 *xp = reinterpret_cast<const ulonglong2 *>(S.x + (((size_t)bl * L + i) * (L + 1) + jj) * n) + ww;
-        if (STREAM) {  // read exactly once
-            return nt_load16(reinterpret_cast<const u64 *>(xp));
-        }
-        return *xp;
-    };
+    const bool two = bl0 + 1 < count;
+    // both descriptors once, up front (the second one of an odd tail repeats the first: loads stay unconditional)
+    const KsItem it0 = items[item0 + bl0], it1 = items[item0 + bl0 + (two ? 1 : 0)];
+    const int ownrow = jj < L ? jj : 0;  // jj == L has no own-prime term; the pointer is then unused
+    const u64 *const own[2] = {it0.c_in + ((size_t)(relin ? 2 * L : L) + ownrow) * n,
+                               it1.c_in + ((size_t)(relin ? 2 * L : L) + ownrow) * n};
+    const uint32_t own_elt[2] = {relin ? 1u : item_elt(it0), relin ? 1u : item_elt(it1)};
+    auto xrow2 = [&](int e, int i) { return S.x + (((size_t)(bl0 + e) * L + i) * (L + 1) + jj) * n; };
     auto accrow = [&](int bl, int c) { return S.acc + (((size_t)(item0 + bl) * 2 + c) * (L + 1) + jj) * n; };
-    const u64 *k0 = items[item0 + bl0].key;
-    const u64 *k1 = bl0 + 1 < count ? items[item0 + bl0 + 1].key : nullptr;
+    u64 *const acc0[2] = {accrow(bl0, 0), accrow(bl0 + 1, 0)}, *const acc1[2] = {accrow(bl0, 1), accrow(bl0 + 1, 1)};
     mac_dispatch(T, m, L, [&](auto pol) {
         using P = decltype(pol);
-        if (k1 == k0) {
-            mac_items<P, 2, STREAM>(T, k0, L, jj, m, n, w, bl0, xload, accrow);
+        if (two && it1.key == it0.key) {
+            mac_items<P, 2, STREAM>(T, it0.key, L, jj, m, n, w, own, own_elt, xrow2, acc0, acc1);
         } else {
-            mac_items<P, 1, STREAM>(T, k0, L, jj, m, n, w, bl0, xload, accrow);
-            if (k1) mac_items<P, 1, STREAM>(T, k1, L, jj, m, n, w, bl0 + 1, xload, accrow);
+            const u64 *const o0[1] = {own[0]}, *const o1[1] = {own[1]};
+            const uint32_t e0[1] = {own_elt[0]}, e1[1] = {own_elt[1]};
+            u64 *const a00[1] = {acc0[0]}, *const a01[1] = {acc1[0]}, *const a10[1] = {acc0[1]}, *const a11[1] = {acc1[1]};
+            mac_items<P, 1, STREAM>(T, it0.key, L, jj, m, n, w, o0, e0, [&](int, int i) { return xrow2(0, i); }, a00, a01);
+            if (two)
+                mac_items<P, 1, STREAM>(T, it1.key, L, jj, m, n, w, o1, e1, [&](int, int i) { return xrow2(1, i); }, a10, a11);
         }
     });
 }
@@ -535,15 +584,15 @@ __device__ __forceinline__ void mac_gathered(P &A, const typename P::Ctx &cx, co
                                              const u64 *__restrict__ c1, const KsScratch &S, int L, int jj, int m,
                                              size_t n, size_t w)
 {
-    const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
+    const uint2 pi = gld_u32x2(it.perm + 2 * w);
     for (int i = 0; i < L; ++i) {
         const u64 *__restrict__ xrow = i == jj ? c1 + (size_t)i * n : S.x + ((size_t)i * (L + 1) + jj) * n;
         ulonglong2 xb;
-        xb.x = xrow[pi.x];
-        xb.y = xrow[pi.y];
+        xb.x = gld8(xrow + pi.x);
+        xb.y = gld8(xrow + pi.y);
         const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
-        const ulonglong2 k0 = reinterpret_cast<const ulonglong2 *>(kbase)[w];
-        const ulonglong2 k1 = reinterpret_cast<const ulonglong2 *>(kbase + (size_t)T.k * n)[w];
+        const ulonglong2 k0 = gld16(kbase + 2 * w);
+        const ulonglong2 k1 = gld16(kbase + (size_t)T.k * n + 2 * w);
         A.mac(P::xin(xb, i == jj, cx), P::kin(k0, k1, cx), cx);
     }
 }
@@ -600,7 +649,7 @@ __global__ __launch_bounds__(256) void lt2_mac_kernel(DevTables T, const KsItem 
             const KsItem it = items[l];
             P A;
             mac_gathered(A, cx, T, it, src_c1, S, L, jj, m, n, w);
-            tot.mac_diag(A, reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)m * n)[w], cx);  // key-level plaintext row m
+            tot.mac_diag(A, gld16(it.pt + (size_t)m * n + 2 * w), cx);  // key-level plaintext row m
         }
         ulonglong2 r0, r1;
         tot.result(r0, r1, cx);
@@ -622,10 +671,10 @@ __global__ __launch_bounds__(256) void lt2_c0_kernel(DevTables T, const KsItem *
     const u64 *__restrict__ row = c0 + (size_t)j * n;
     for (int l = l0; l < l1; ++l) {
         const KsItem it = items[l];
-        const uint2 pi = reinterpret_cast<const uint2 *>(it.perm)[w];
-        const ulonglong2 dg = reinterpret_cast<const ulonglong2 *>(it.pt + (size_t)j * n)[w];
-        mac128(xl, xh, row[pi.x], dg.x);
-        mac128(yl, yh, row[pi.y], dg.y);
+        const uint2 pi = gld_u32x2(it.perm + 2 * w);
+        const ulonglong2 dg = gld16(it.pt + (size_t)j * n + 2 * w);
+        mac128(xl, xh, gld8(row + pi.x), dg.x);
+        mac128(yl, yh, gld8(row + pi.y), dg.y);
     }
     reinterpret_cast<ulonglong2 *>(partial + ((size_t)ch * L + j) * n)[w] =
         make_ulonglong2(barrett128(xl, xh, mc), barrett128(yl, yh, mc));
@@ -695,7 +744,7 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, 4) void ks_ntt_macf_kernel(DevTa
 #pragma unroll
                 for (int r = 0; r < 8; r += 2) {
                     const uint32_t rec = (uint32_t)((off + C::idx_out(t, r)) >> 1);
-                    const ulonglong2 v = elt == 1u ? reinterpret_cast<const ulonglong2 *>(xr)[rec] : gather_pair(xr, rec, elt, LOGN);
+                    const ulonglong2 v = gather_pair(xr, rec, elt, LOGN);
                     f[r] = ArithF64::from_u64(v.x);
                     f[r + 1] = ArithF64::from_u64(v.y);
                 }
@@ -715,8 +764,8 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, 4) void ks_ntt_macf_kernel(DevTa
             ulonglong2 kv0[4], kv1[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                kv0[r] = *reinterpret_cast<const ulonglong2 *>(k0 + C::idx_out(t, 2 * r));
-                kv1[r] = *reinterpret_cast<const ulonglong2 *>(k1 + C::idx_out(t, 2 * r));
+                kv0[r] = gld16(k0 + C::idx_out(t, 2 * r));
+                kv1[r] = gld16(k1 + C::idx_out(t, 2 * r));
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -907,10 +956,10 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
 #pragma unroll
                 for (int r = 0; r < GS; r += 2) {
                     const int idx = C::idx_io(t, GS * g + r);
-                    const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+                    const ulonglong2 av = gld16(acc + idx);
                     ulonglong2 sv = make_ulonglong2(0, 0), pv = make_ulonglong2(0, 0);
                     if constexpr (HA) sv = gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
-                    if constexpr (HP) pv = *reinterpret_cast<const ulonglong2 *>(pt + idx);
+                    if constexpr (HP) pv = gld16(pt + idx);
                     a[bufi][r] = av.x, a[bufi][r + 1] = av.y;
                     sadd[bufi][r] = sv.x, sadd[bufi][r + 1] = sv.y;
                     pp[bufi][r] = pv.x, pp[bufi][r + 1] = pv.y;
@@ -926,7 +975,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                     ulonglong2 o;
                     o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], HP, cx, pinv, mc);
                     o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], HP, cx, pinv, mc);
-                    *reinterpret_cast<ulonglong2 *>(dst + C::idx_io(t, GS * g + r)) = o;
+                    gst16(dst + C::idx_io(t, GS * g + r), o);
                 }
                 if (!PIPE && g + 1 < NG) fetch(g + 1, 0);
             }
@@ -1011,7 +1060,7 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_intt_digits_q_kernel(D
     const uint32_t elt = relin ? 1u : item_elt(it);
     u64 v[8];
     quarter_inv<LOGN>(v, [src, elt](int j) {
-        return elt == 1u ? reinterpret_cast<const ulonglong2 *>(src)[j] : gather_pair(src, (uint32_t)j, elt, LOGN);
+        return gather_pair(src, (uint32_t)j, elt, LOGN);
     }, lds, ntt_tables(T, i), T.mods[i], T.modsf[i], t, part);
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * QC::N;
 #pragma unroll
@@ -1116,10 +1165,10 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
 #pragma unroll
             for (int r = 0; r < 8; r += 2) {
                 const int idx = C::idx_out(t, r);
-                const ulonglong2 av = *reinterpret_cast<const ulonglong2 *>(acc + idx);
+                const ulonglong2 av = gld16(acc + idx);
                 ulonglong2 sv = make_ulonglong2(0, 0), pv = make_ulonglong2(0, 0);
                 if constexpr (HA) sv = gather_pair(addrow, (uint32_t)((off + idx) >> 1), elt, LOGN);
-                if constexpr (HP) pv = *reinterpret_cast<const ulonglong2 *>(pt + idx);
+                if constexpr (HP) pv = gld16(pt + idx);
                 a[r] = av.x, a[r + 1] = av.y;
                 sadd[r] = sv.x, sadd[r + 1] = sv.y;
                 pp[r] = pv.x, pp[r + 1] = pv.y;
@@ -1136,7 +1185,7 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
             ulonglong2 o;
             o.x = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], HP, cx, pinv, mc);
             o.y = md_epilogue(A{}, f[r + 1], a[r + 1], sadd[r + 1], pp[r + 1], HP, cx, pinv, mc);
-            *reinterpret_cast<ulonglong2 *>(dst + C::idx_out(t, r)) = o;
+            gst16(dst + C::idx_out(t, r), o);
         }
     };
     if (has_add) {
@@ -1508,11 +1557,16 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     for (int g = 0; g < 16; g += 8) {
         u64 a[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a[r] = src[C::idx_io(t, g + r)];
+        for (int r = 0; r < 8; r += 2) {  // (r, r+1) are one 16-byte record
+            const ulonglong2 rec = gld16(src + C::idx_io(t, g + r));
+            a[r] = rec.x, a[r + 1] = rec.y;
+        }
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-            const u64 z = submod(a[r], v[g + r], q);
-            dst[C::idx_io(t, g + r)] = csub(shoup_lazy(z, qinv.x, qinv.y, mc.nq), q);
+        for (int r = 0; r < 8; r += 2) {
+            ulonglong2 o;
+            o.x = csub(shoup_lazy(submod(a[r], v[g + r], q), qinv.x, qinv.y, mc.nq), q);
+            o.y = csub(shoup_lazy(submod(a[r + 1], v[g + r + 1], q), qinv.x, qinv.y, mc.nq), q);
+            gst16(dst + C::idx_io(t, g + r), o);
         }
         HEFX_STAGE_FENCE();
     }

@@ -34,6 +34,39 @@ struct NttTables {
     const double *twf, *itwf;    // [N] of this modulus (FP64 policy)
 };
 
+// Pointers that a kernel READS FROM DEVICE MEMORY -- the fields of an item descriptor, the entries of a pointer table
+// -- are GENERIC pointers to the compiler (only pointer kernel arguments, also inside by-value argument structs, are
+// known to be global), and every access through a generic pointer is a FLAT instruction: it counts in vmcnt AND lgkmcnt
+// and completes out of order, so the only wait the compiler can place after one is the full drain
+// s_waitcnt vmcnt(0) lgkmcnt(0) -- no load of a later record stays in flight across the use of an earlier one, and a
+// store is waited for like a load.  Found in the ISA in round 3: 64 flat loads in ks_intt_digits, 84 in ks_mac (not one
+// counted wait in the whole kernel), 62 flat loads and ALL 59 stores of ks_moddown_finish.  The accessors below make
+// the access through a pointer in the global address space (the cast has to sit AT the access: laundering the pointer
+// through address space 1 and back is folded away; and the 16-byte forms go through a built-in vector type, because a
+// class-type load is a copy constructor on a generic reference).  Every buffer the engine is handed is device memory
+// (hipMalloc / hefx_malloc), so the claim is true by the ABI's contract.
+#define HEFX_GLOBAL_AS __attribute__((address_space(1)))
+typedef u64 hefx_u64x2 __attribute__((ext_vector_type(2)));
+typedef uint32_t hefx_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u64 gld8(const u64 *p) { return *(const HEFX_GLOBAL_AS u64 *)p; }
+__device__ __forceinline__ void gst8(u64 *p, u64 v) { *(HEFX_GLOBAL_AS u64 *)p = v; }
+__device__ __forceinline__ ulonglong2 gld16(const void *p)
+{
+    const hefx_u64x2 v = *(const HEFX_GLOBAL_AS hefx_u64x2 *)p;
+    return make_ulonglong2(v.x, v.y);
+}
+__device__ __forceinline__ void gst16(void *p, const ulonglong2 &v)
+{
+    hefx_u64x2 t;
+    t.x = v.x, t.y = v.y;
+    *(HEFX_GLOBAL_AS hefx_u64x2 *)p = t;
+}
+__device__ __forceinline__ uint2 gld_u32x2(const void *p)
+{
+    const hefx_u32x2 v = *(const HEFX_GLOBAL_AS hefx_u32x2 *)p;
+    return make_uint2(v.x, v.y);
+}
+
 __device__ __forceinline__ u64 mulhi64(u64 a, u64 b) { return __umul64hi(a, b); }
 
 

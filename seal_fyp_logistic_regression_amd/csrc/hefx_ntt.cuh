@@ -723,7 +723,7 @@ template <int LOGN, int NB = 2>
 __device__ __forceinline__ void split_inv(u64 (&v)[16], const ulonglong2 *__restrict__ pairs, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
 {
-    split_inv_ld<LOGN, NB>(v, [pairs](int j) { return pairs[j]; }, lds, nt, mc, mf, t, h);
+    split_inv_ld<LOGN, NB>(v, [pairs](int j) { return gld16(pairs + j); }, lds, nt, mc, mf, t, h);
 }
 
 }  // namespace hefx
