@@ -338,6 +338,8 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
             f.ilw = (double)m.ilw;
             f.ilw_r = (double)m.ilw / qd;
             f.c32 = (double)(((u64)1 << 32) % q);
+            const u64 c40 = ((u64)1 << 40) % q;
+            f.c40 = (q >> 39) == 1 && c40 < ((u64)1 << 23) ? (double)c40 : 0.0;  // only for 2^39 < q < 2^40 close to 2^40
             for (size_t i = 0; i < n; ++i) {
                 twf[(size_t)j * n + i] = (double)tw[(size_t)j * n + i].x;
                 itwf[(size_t)j * n + i] = (double)itw[(size_t)j * n + i].x;

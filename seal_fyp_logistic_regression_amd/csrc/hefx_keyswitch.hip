@@ -943,7 +943,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
         // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
         static_assert(GS % 2 == 0, "record layout");
-        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD>(f, ld, mode, mc, lds, tw, cx, t, h);
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, NoHook, true>(f, ld, mode, mc, lds, tw, cx, t, h);
         // The epilogue is SPECIALISED on (add-in?, plaintext?) by one workgroup-uniform branch around it (round 3): with
         // the two conditions tested per record inside the loop the loads sat in conditional blocks, and the compiler's
         // wait-count insertion closed every such block with s_waitcnt vmcnt(0) -- a full drain, stores included, per

@@ -25,7 +25,9 @@ struct ModConstF {
     double q, qinv;          // q and RN(1/q)
     double ninv, ninv_r;     // N^-1 mod q and RN(ninv/q)
     double ilw, ilw_r;       // (last inverse-stage twiddle * N^-1) mod q and RN(ilw/q)
-    double c32, pad1;        // 2^32 mod q (FP64 reduction of a 64-bit word: hi*c32 + lo)
+    double c32;              // 2^32 mod q (FP64 reduction of a 64-bit word: hi*c32 + lo)
+    double c40;              // 2^40 mod q when that is below 2^23 (q just under 2^40, SEAL's 40-bit primes), else 0:
+                             // a word x < 2^61 then reduces as (x >> 40)*c40 + (x mod 2^40) < 2^45 in ONE fma
 };
 
 // Twiddle tables of one modulus (integer and FP64 policies).

@@ -41,6 +41,7 @@ struct InMode {
     bool red_f64;  // FP64 policy: the word may exceed 2^52 (it comes from a prime that is not an FP64 prime)
     bool has_sub;
     u64 sub;       // canonical residue to subtract
+    bool below_2_61 = true;  // the words are residues of an admissible prime (< 2^61): the one-fma reduction applies
 };
 
 template <int LOGN>
@@ -196,7 +197,8 @@ struct ArithU64T {
     }
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     static constexpr bool IS_F64 = false;
-    template <bool RED>
+    __device__ static __forceinline__ bool fast_wide(const Ctx &) { return false; }
+    template <int RED>
     __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &mc)
     {
         if (RED) x = barrett64(x, mc.q, mc.r1);
@@ -248,7 +250,7 @@ struct ArithF64 {
     struct Ctx {
         double q, qinv;
         double ninv, ilw;
-        double c32;
+        double c32, c40;
     };
     __device__ static __forceinline__ Ctx make(const ModConstF &mf)
     {
@@ -258,6 +260,7 @@ struct ArithF64 {
         c.ninv = mf.ninv;
         c.ilw = mf.ilw;
         c.c32 = mf.c32;
+        c.c40 = mf.c40;
         return c;
     }
     // y*w mod q, exact, result in (-0.52q, 0.52q); y any integer with |y| < 2^45, w integer with |w| < 2^41:
@@ -324,14 +327,27 @@ struct ArithF64 {
     {
         return mm(__uint2double_rn((unsigned)(x >> 32)), c.c32, c) + __uint2double_rn((unsigned)x);
     }
+    // the same for a word x < 2^61 and a prime just below 2^40 (c.c40 = 2^40 mod q < 2^23, set by the host for exactly
+    // those primes): x = a 2^40 + r with a < 2^21, r < 2^40, and a*c40 + r < 2^44 + 2^40 < 2^45 is an exact integer in a
+    // double, congruent to x -- one shift, one conversion, one exponent splice and ONE fma (five instructions against
+    // nine), inside the |y| < 2^45 the modmul's exactness argument asks of a left operand.  Callers: the mod-down
+    // remainder (< P) and the digit of a 60-bit prime, both below 2^61 by construction.
+    __device__ static __forceinline__ V reduce_wide40(u64 x, const Ctx &c)
+    {
+        const double a = __uint2double_rn((unsigned)(x >> 40));
+        const double r = from_u64(x & 0xFFFFFFFFFFull);
+        return __builtin_fma(a, c.c40, r);
+    }
     static constexpr bool IS_F64 = true;
-    template <bool RED>
+    // RED: 0 none, 1 generic (any 64-bit word), 2 the one-fma form (x < 2^61, c.c40 != 0)
+    template <int RED>
     __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &)
     {
-        double v = RED ? reduce_wide(x, c) : from_u64(x);
+        double v = RED == 2 ? reduce_wide40(x, c) : RED == 1 ? reduce_wide(x, c) : from_u64(x);
         if (m.has_sub) v -= from_u64(m.sub);
         return v;
     }
+    __device__ static __forceinline__ bool fast_wide(const Ctx &c) { return c.c40 != 0.0; }
     __device__ static __forceinline__ u64 to_u64(double r)
     {
         return (u64)__double_as_longlong(r + 4503599627370496.0) & 0x000FFFFFFFFFFFFFull;
@@ -351,7 +367,10 @@ struct ArithF64 {
     {
         double z = from_u64(acc) - f;  // exact: |f| < 2^45
         z = mm(z, pinv.x, c) + from_u64(sadd);
-        if (has_pt) z = mm(z, from_u64(pt), c);
+        if (has_pt) {  // the product is already in (-0.52q, 0.52q): no re-centring before the sign fix-up
+            z = mm(z, from_u64(pt), c);
+            return to_u64(z < 0.0 ? z + c.q : z);
+        }
         return canon(z, c);
     }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
@@ -583,7 +602,9 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 // v[r] = NTT value at h*N/2 + idx_io(t,r), canonical.  Loads are issued in two batches of eight pairs.
 // NB = number of load batches of the first stage: 2 (eight pairs each) under the 128-VGPR cap, 1 (all sixteen pairs in
 // flight at once, one exposed memory latency instead of two) in the 256-VGPR builds.
-template <int LOGN, class A, class LD, int NB = 2, class HOOK = NoHook>
+// FAST40: also build the one-fma reduction of wide words (ArithF64::reduce_wide40) -- only where it pays for a third
+// first-stage variant in the kernel's register budget: the mod-down epilogue kernel, whose every input is wide
+template <int LOGN, class A, class LD, int NB = 2, class HOOK = NoHook, bool FAST40 = false>
 __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, const InMode &mode,
                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
                                               const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK())
@@ -592,17 +613,37 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
     // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
     // select per element (which would make every row pay for the reduction)
     constexpr int BS = 16 / NB;
+    // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
+    // select per element (which would make every row pay for the reduction)
     if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
+        bool fast = false;
+        if constexpr (FAST40 && A::IS_F64) fast = mode.below_2_61 && A::fast_wide(cx);
+        if (fast) {
+            if constexpr (FAST40 && A::IS_F64) {
 #pragma unroll
-        for (int g = 0; g < NB; ++g) {
-            u64 x[BS], y[BS];
+                for (int g = 0; g < NB; ++g) {
+                    u64 x[BS], y[BS];
 #pragma unroll
-            for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
+                    for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
 #pragma unroll
-            for (int r = 0; r < BS; ++r)
-                f[BS * g + r] = A::ct_half(A::template input<true>(x[r], mode, cx, mc),
-                                           A::template input<true>(y[r], mode, cx, mc), w1, cx);
-            HEFX_STAGE_FENCE();
+                    for (int r = 0; r < BS; ++r)
+                        f[BS * g + r] = A::ct_half(A::template input<2>(x[r], mode, cx, mc),
+                                                   A::template input<2>(y[r], mode, cx, mc), w1, cx);
+                    HEFX_STAGE_FENCE();
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < NB; ++g) {
+                u64 x[BS], y[BS];
+#pragma unroll
+                for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
+#pragma unroll
+                for (int r = 0; r < BS; ++r)
+                    f[BS * g + r] = A::ct_half(A::template input<1>(x[r], mode, cx, mc),
+                                               A::template input<1>(y[r], mode, cx, mc), w1, cx);
+                HEFX_STAGE_FENCE();
+            }
         }
     } else {
 #pragma unroll
@@ -612,8 +653,8 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
             for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
 #pragma unroll
             for (int r = 0; r < BS; ++r)
-                f[BS * g + r] = A::ct_half(A::template input<false>(x[r], mode, cx, mc),
-                                           A::template input<false>(y[r], mode, cx, mc), w1, cx);
+                f[BS * g + r] = A::ct_half(A::template input<0>(x[r], mode, cx, mc),
+                                           A::template input<0>(y[r], mode, cx, mc), w1, cx);
             HEFX_STAGE_FENCE();
         }
     }

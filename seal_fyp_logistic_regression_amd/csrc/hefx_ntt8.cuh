@@ -136,7 +136,7 @@ __device__ __forceinline__ void split8_fwd_raw(typename A::V (&f)[8], const LD &
 {
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
     auto stage = [&](auto red) {
-        constexpr bool RED = decltype(red)::value;
+        constexpr int RED = decltype(red)::value;
         u64 x[8], y[8];
 #pragma unroll
         for (int r = 0; r < 8; ++r) ld(r, x[r], y[r]);
@@ -146,9 +146,9 @@ __device__ __forceinline__ void split8_fwd_raw(typename A::V (&f)[8], const LD &
         HEFX_STAGE_FENCE();
     };
     if (A::IS_F64 ? mode.red_f64 : mode.red_int)
-        stage(std::true_type{});
+        stage(std::integral_constant<int, 1>{});
     else
-        stage(std::false_type{});
+        stage(std::integral_constant<int, 0>{});
     ntt8_fwd_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h);
 }
 
@@ -243,7 +243,7 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
     const int h0 = qd >> 1, h1 = qd & 1;
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h0), w2 = A::half_twiddle(tw[2 + h0], cx, h1);
     auto stage = [&](auto red) {
-        constexpr bool RED = decltype(red)::value;
+        constexpr int RED = decltype(red)::value;
         u64 x[8][4];
 #pragma unroll
         for (int r = 0; r < 8; ++r) ld(r, x[r][0], x[r][1], x[r][2], x[r][3]);
@@ -258,10 +258,14 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
         }
         HEFX_STAGE_FENCE();
     };
-    if (A::IS_F64 ? mode.red_f64 : mode.red_int)
-        stage(std::true_type{});
-    else
-        stage(std::false_type{});
+    if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
+        if (A::IS_F64 && mode.below_2_61 && A::fast_wide(cx))
+            stage(std::integral_constant<int, 2>{});
+        else
+            stage(std::integral_constant<int, 1>{});
+    } else {
+        stage(std::integral_constant<int, 0>{});
+    }
     ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 4 + qd);
 }
 
