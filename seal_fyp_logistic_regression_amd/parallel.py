@@ -93,11 +93,20 @@ def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertex
         # collective and the canonicalisation after it; only a caller that has moved torch to another stream pays a wait.
         eng = be.engine
         out = eng.copy(ct.data)
-        t = torch.as_tensor(_DeviceWords(out.ptr, size * L * N), device=torch.device("cuda", eng.device))
-        cur = torch.cuda.current_stream(torch.device("cuda", eng.device))
+        dev = torch.device("cuda", eng.device)
+        cur = torch.cuda.current_stream(dev)
+        try:
+            t = torch.as_tensor(_DeviceWords(out.ptr, size * L * N), device=dev)
+            staged = False
+        except Exception:  # a torch build without __cuda_array_interface__ support: one staging tensor, as in round 2
+            t = torch.empty(size * L * N, dtype=torch.int64, device=dev)
+            eng.copy_raw(t.data_ptr(), out.ptr, t.numel() * 8)
+            staged = True
         if cur.cuda_stream != 0:
             eng.sync()
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        if staged:
+            eng.copy_raw(out.ptr, t.data_ptr(), t.numel() * 8)
         if cur.cuda_stream != 0:
             cur.synchronize()
         eng.reduce_canonical(L, size, out, addends=world)

@@ -33,7 +33,8 @@ def test_bench_configuration_default_chunking_every_output_bit_exact():
     from seal_fyp_logistic_regression_amd import Engine
     from seal_fyp_logistic_regression_amd.seal import galois_elt_from_step
     for v in ("HEFX_CHUNK", "HEFX_SUB", "HEFX_STREAMS", "HEFX_STREAM_X", "HEFX_FUSED", "HEFX_NO_FP64", "HEFX_QUARTER"):
-        assert v not in os.environ, f"{v} is set: this test is about the default launch structure"
+        if v in os.environ:
+            pytest.skip(f"{v} is set: this test is about the DEFAULT launch structure (the knob runs have their own tests)")
     N, primes = C3
     k, L, n, nk = len(primes), len(primes) - 1, 600, 3
     o, e = O.Oracle(N, primes), Engine(N, primes)
