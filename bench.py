@@ -132,6 +132,56 @@ def cpu_baseline(name: str, budget_s: float):
     }
 
 
+class BoardSampler:
+    """Package power, engine clock and busy percentage of one GPU, read with rocm-smi about twice a second on a side
+    thread while the key-switch passes run (headline + variants): corroborates from outside that the timed region keeps
+    the device busy, and records the clock the power governor grants under this load (profiles/r03_clock_and_power_*).
+    Reads sysfs through a child process; touches neither the HIP context nor the streams.  Absent tool -> no samples."""
+
+    def __init__(self, gpu_index: int):
+        self.idx, self.samples, self._stop, self._th = gpu_index, [], threading.Event(), None
+
+    def _run(self):
+        import re
+        exe = "/opt/rocm/bin/rocm-smi"
+        if not os.path.exists(exe):
+            return
+        pat = {"sclk_mhz": re.compile(r"GPU\[%d\].*sclk clock level.*\((\d+)Mhz\)" % self.idx),
+               "package_power_w": re.compile(r"GPU\[%d\].*Power \(W\):\s*([0-9.]+)" % self.idx),
+               "gpu_use_pct": re.compile(r"GPU\[%d\].*GPU use \(%%\):\s*([0-9.]+)" % self.idx)}
+        while not self._stop.is_set():
+            try:
+                out = subprocess.run([exe, "--showclocks", "--showpower", "--showuse"], capture_output=True, text=True,
+                                     timeout=10).stdout
+            except Exception:
+                return
+            rec = {}
+            for k, rx in pat.items():
+                m = rx.search(out)
+                if m:
+                    rec[k] = float(m.group(1))
+            if len(rec) == 3:
+                self.samples.append(rec)
+            self._stop.wait(0.3)
+
+    def start(self):
+        self._th = threading.Thread(target=self._run, daemon=True)
+        self._th.start()
+
+    def stop(self):
+        self._stop.set()
+        if self._th:
+            self._th.join(timeout=15)
+        busy = [r for r in self.samples if r["gpu_use_pct"] >= 90.0]
+        if not busy:
+            return {"samples": len(self.samples), "note": "no sample fell inside the busy period (short run) or rocm-smi is absent"}
+        avg = lambda k: sum(r[k] for r in busy) / len(busy)
+        return {"samples": len(busy), "package_power_w": avg("package_power_w"), "sclk_mhz": avg("sclk_mhz"),
+                "gpu_use_pct": avg("gpu_use_pct"),
+                "source": "rocm-smi --showclocks --showpower --showuse on a side thread during the key-switch passes; "
+                          "samples with GPU use >= 90 %"}
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # launcher: --gpus N outside a distributed launcher starts the N ranks itself
 # ------------------------------------------------------------------------------------------------------------------
@@ -413,6 +463,9 @@ def main():
             dt = float(tt.item())
         return dt, gpu_ms
 
+    board = BoardSampler(local_rank) if rank == 0 else None
+    if board:
+        board.start()
     dt, gpu_ms = timed(step, args.steps, args.warmup)
 
     # what was timed is checked: one item of EVERY chunk of the launch sequence (the engine cuts the batch into chunks of
@@ -464,6 +517,7 @@ def main():
                     "group of items streams its key from HBM (items are processed grouped by key)"}
         del skey, skeyv, skeys
 
+    board_rec = board.stop() if board else None
     line = None
     if rank == 0:
         bytes_op = algorithmic_bytes_per_op(N, L)
@@ -555,6 +609,7 @@ def main():
                 },
             },
             "variants": variants,
+            "board_under_load": board_rec,
             "lt_sharded": None,
         }
         if args.cpu_seconds > 0 and world == 1:
