@@ -482,7 +482,11 @@ def main():
         except Exception as ex:  # the oracle is the checker only; its absence must not hide the GPU number
             verified = f"not checked: {ex!r}"
 
-    # per-launch-kind durations: a short profiled pass (serial, HIP events between the launches)
+    # per-launch-kind durations: a short profiled pass (serial, HIP events between the launches).  The host-side
+    # verification above left the device idle and its clock low: two untimed steps bring it back first.
+    step()
+    step()
+    e.sync()
     e.profile_begin()
     step()
     stage_ms, nchunks = e.profile_end()
