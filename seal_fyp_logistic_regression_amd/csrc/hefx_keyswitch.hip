@@ -547,8 +547,11 @@ __device__ __forceinline__ void mac_unit(const DevTables &T, const KsItem *__res
     });
 }
 
+#ifndef HEFX_MAC_WAVES  // experiment knob: minimum waves per SIMD the MAC is register-allocated for (8 -> 64 VGPRs)
+#define HEFX_MAC_WAVES 1
+#endif
 template <bool STREAM>
-__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+__global__ __launch_bounds__(256, HEFX_MAC_WAVES) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
                                                      int item0, int count, int int_only, KsScratch S)
 {
     // int_only: the FP64-policy target slots were accumulated by ks_ntt_macf_kernel; blockIdx.y counts the others
