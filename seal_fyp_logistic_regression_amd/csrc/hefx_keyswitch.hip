@@ -906,7 +906,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const auto pinv = md_pinv(A{}, T, sp, j);
     const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
     // u < P is reduced modulo q_j and (P/2 mod q_j) subtracted in the row's policy (exact for any 64-bit word)
-    const InMode mode = {true, true, true, half_j};
+    const InMode mode = {true, true, true, half_j, true, T.mods[sp].q < 2 * mc.q};
     auto ld = [&](int r, u64 &x, u64 &y) {
         const uint32_t e = eo_nat<SC>(t, r);
         x = ud[e];

@@ -42,6 +42,7 @@ struct InMode {
     bool has_sub;
     u64 sub;       // canonical residue to subtract
     bool below_2_61 = true;  // the words are residues of an admissible prime (< 2^61): the one-fma reduction applies
+    bool lt2q = false;       // the words are below 2 q of the row's prime: one conditional subtraction reduces them
 };
 
 template <int LOGN>
@@ -198,10 +199,14 @@ struct ArithU64T {
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     static constexpr bool IS_F64 = false;
     __device__ static __forceinline__ bool fast_wide(const Ctx &) { return false; }
+    // RED: 0 none, 1 Barrett (any 64-bit word), 3 one conditional subtraction (x < 2q)
     template <int RED>
     __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &mc)
     {
-        if (RED) x = barrett64(x, mc.q, mc.r1);
+        if (RED == 3)
+            x = csubn(x, c.nq);
+        else if (RED)
+            x = barrett64(x, mc.q, mc.r1);
         if (m.has_sub) x = submod(x, m.sub, c.q);
         return x;
     }
@@ -610,16 +615,19 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
                                               const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK())
 {
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
-    // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
-    // select per element (which would make every row pay for the reduction)
     constexpr int BS = 16 / NB;
     // the reduce / no-reduce decision is uniform per workgroup: one branch around the whole first stage, not one
     // select per element (which would make every row pay for the reduction)
     if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
+        // FAST40 kernels (mod-down epilogue): the cheap reduction the row's prime admits -- FP64: one fma (primes just
+        // below 2^40); integer: ONE conditional subtraction when the words are below 2 q (two 60-bit primes)
+        // (the integer form only from N = 16384 on: at N = 8192 the extra variant costs the kernel a wave per SIMD)
+        constexpr bool CHEAP_OK = FAST40 && (A::IS_F64 || LOGN >= 14);
         bool fast = false;
-        if constexpr (FAST40 && A::IS_F64) fast = mode.below_2_61 && A::fast_wide(cx);
+        if constexpr (CHEAP_OK) fast = A::IS_F64 ? (mode.below_2_61 && A::fast_wide(cx)) : mode.lt2q;
         if (fast) {
-            if constexpr (FAST40 && A::IS_F64) {
+            if constexpr (CHEAP_OK) {
+                constexpr int CHEAP = A::IS_F64 ? 2 : 3;
 #pragma unroll
                 for (int g = 0; g < NB; ++g) {
                     u64 x[BS], y[BS];
@@ -627,8 +635,8 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
                     for (int r = 0; r < BS; ++r) ld(BS * g + r, x[r], y[r]);
 #pragma unroll
                     for (int r = 0; r < BS; ++r)
-                        f[BS * g + r] = A::ct_half(A::template input<2>(x[r], mode, cx, mc),
-                                                   A::template input<2>(y[r], mode, cx, mc), w1, cx);
+                        f[BS * g + r] = A::ct_half(A::template input<CHEAP>(x[r], mode, cx, mc),
+                                                   A::template input<CHEAP>(y[r], mode, cx, mc), w1, cx);
                     HEFX_STAGE_FENCE();
                 }
             }
