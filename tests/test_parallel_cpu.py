@@ -42,12 +42,14 @@ def _worker(rank, world, port, d, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d", [8, 1])
-def test_sharded_linear_transform_world2(d):
+@pytest.mark.parametrize("d,world", [(8, 2), (1, 2), (3, 4)])
+def test_sharded_linear_transform_world2(d, world):
+    """world 4 with d = 3: one rank owns no diagonal and contributes the zero ciphertext (the 8-GPU node's case whenever a
+    transform has fewer units than ranks)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, d, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, d, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = [q.get(timeout=300) for _ in procs]
