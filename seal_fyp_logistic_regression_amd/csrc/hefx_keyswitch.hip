@@ -102,6 +102,21 @@ __device__ static __forceinline__ uint32_t eo_nat(int t, int r)
     static_assert(SC::C::T % 2 == 0, "split-2 loaders assume an even thread count");
     return (uint32_t)((t & 1) * SC::H + (t >> 1)) + (uint32_t)(SC::C::T / 2) * (uint32_t)r;
 }
+// The coefficient column a thread of a forward split workgroup loads (ntt_fwd_core's t0): the first half of the workgroup
+// takes the even columns, the second half the odd ones, so that eo_nat(eo_lane(t), r) is contiguous over the lanes of a
+// wave -- with t itself neighbouring lanes alternate between the two halves of the row and every 8-byte load is split by
+// the address coalescer (found on the small-batch path with tools/stamp_timeline.py, round 3).
+template <class SC>
+__device__ static __forceinline__ int eo_lane(int t)
+{
+    constexpr int T = SC::C::T;
+    return ((t & (T / 2 - 1)) << 1) | (t / (T / 2));
+}
+#ifdef HEFX_NO_EO_LANE  // A/B knob (tools/build_variant.sh): the round-2 mapping (column t)
+#define HEFX_EO_LANE(SC, t) (t)
+#else
+#define HEFX_EO_LANE(SC, t) eo_lane<SC>(t)
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // Galois-gathered reads.  The rotated inputs perm_g(c0), perm_g(c1) are never written out: their three readers --
@@ -212,13 +227,14 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     // [d_i]_m: the U64 policy needs it only when q_i > m; the FP64 policy takes any integer below 2^49 as input,
     // so a digit of a prime < 2^41 needs no reduction at all (the transform is linear and ends canonical)
     const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
+    const int tl = HEFX_EO_LANE(SC, t);
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const uint32_t e = eo_nat<SC>(t, r);
+        const uint32_t e = eo_nat<SC>(tl, r);
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
     // MAC-operand format: canonical words for the integer-policy moduli, unfinished doubles for the FP64 ones
-    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h);
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h, tl);
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
     // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
@@ -556,7 +572,15 @@ __global__ __launch_bounds__(256, HEFX_MAC_WAVES) void ks_mac_kernel(DevTables T
 {
     // int_only: the FP64-policy target slots were accumulated by ks_ntt_macf_kernel; blockIdx.y counts the others
     const int jj = int_only ? nth_int_slot(T, L, blockIdx.y) : (int)blockIdx.y;
+#ifdef HEFX_STAMP
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && wg < 512) hefx_stamp_buf[((size_t)2 * 512 + wg) * 16] = wall_clock64();
+#endif
     mac_unit<STREAM>(T, items, L, relin, item0, count, S, jj, 2 * blockIdx.z, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+#ifdef HEFX_STAMP
+    if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && wg < 512) hefx_stamp_buf[((size_t)2 * 512 + wg) * 16 + 15] = wall_clock64();
+#endif
 }
 
 // (2) as a launch
@@ -907,8 +931,9 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const u64 *__restrict__ ud = S.u + ((size_t)b * 2 + c) * SC::N;
     // u < P is reduced modulo q_j and (P/2 mod q_j) subtracted in the row's policy (exact for any 64-bit word)
     const InMode mode = {true, true, true, half_j, true, T.mods[sp].q < 2 * mc.q};
+    const int tl = HEFX_EO_LANE(SC, t);
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const uint32_t e = eo_nat<SC>(t, r);
+        const uint32_t e = eo_nat<SC>(tl, r);
         x = ud[e];
         y = ud[e + SC::H / 2];
     };
@@ -946,7 +971,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
         // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
         static_assert(GS % 2 == 0, "record layout");
-        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, NoHook, true>(f, ld, mode, mc, lds, tw, cx, t, h);
+        split_fwd_raw<LOGN, A, decltype(ld), KsWaves<LOGN>::NB_FWD, NoHook, true>(f, ld, mode, mc, lds, tw, cx, t, h, NoHook(), tl);
         // The epilogue is SPECIALISED on (add-in?, plaintext?) by one workgroup-uniform branch around it (round 3): with
         // the two conditions tested per record inside the loop the loads sat in conditional blocks, and the compiler's
         // wait-count insertion closed every such block with s_waitcnt vmcnt(0) -- a full drain, stores included, per
@@ -1052,6 +1077,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_intt_digits_q_kernel(D
     using QC = QuarterCfg<LOGN>;
     using C = typename QC::C;
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(0);
+    HEFX_STAMP_AT(0);
     if (blockIdx.x == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
     int p, part;
     quarter_decode(blockIdx.x, p, part);
@@ -1068,13 +1095,14 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_intt_digits_q_kernel(D
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * QC::N;
 #pragma unroll
     for (int r = 0; r < 8; ++r) dd[eo_pos<LOGN>(4 * C::idx_nat(t, r) + part)] = v[r];
+    HEFX_STAMP_AT(15);
 }
 
 // forward loader over a coefficient-form row stored EO
 template <int LOGN>
 struct EoQuadLoader {
     const u64 *__restrict__ row;
-    int t;
+    int t;  // the thread's coefficient column: quarter_fwd_lane(threadIdx.x)
     __device__ __forceinline__ void operator()(int r, u64 &x0, u64 &x1, u64 &x2, u64 &x3) const
     {
         using C = typename QuarterCfg<LOGN>::C;
@@ -1093,6 +1121,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     using QC = QuarterCfg<LOGN>;
     using C = typename QC::C;
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(1);
+    HEFX_STAMP_AT(0);
     // block -> (digit g = (b, i), target slot jj, quarter): the 4 L workgroups of a digit share an XCD
     const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;
@@ -1107,11 +1137,12 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     const u64 qi = T.mods[i].q;
     u64 v[8];
     const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
-    const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, t};
+    const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, quarter_fwd_lane<LOGN>(t)};
     quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, part);
     u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) xd[C::idx_out(t, r)] = v[r];
+    for (int r = 0; r < 8; r += 2) gst16(xd + C::idx_out(t, r), make_ulonglong2(v[r], v[r + 1]));
+    HEFX_STAMP_AT(15);
 }
 
 template <int LOGN>
@@ -1120,6 +1151,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_intt_q_kernel(
     using QC = QuarterCfg<LOGN>;
     using C = typename QC::C;
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(3);
+    HEFX_STAMP_AT(0);
     int p, part;
     quarter_decode(blockIdx.x, p, part);
     if (p >= rows) return;
@@ -1134,6 +1167,7 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_intt_q_kernel(
     u64 *__restrict__ ud = S.u + (size_t)p * QC::N;
 #pragma unroll
     for (int r = 0; r < 8; ++r) ud[eo_pos<LOGN>(4 * C::idx_nat(t, r) + part)] = csub(v[r] + half, mc.q);
+    HEFX_STAMP_AT(15);
 }
 
 template <int LOGN, class A>
@@ -1147,8 +1181,8 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
     const int sp = T.k - 1;
     const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
     const auto pinv = md_pinv(A{}, T, sp, j);
-    const InMode mode = {true, true, true, half_j};
-    const EoQuadLoader<LOGN> ld{S.u + ((size_t)b * 2 + c) * QC::N, t};
+    const InMode mode = {true, true, true, half_j, true, T.mods[sp].q < 2 * mc.q};
+    const EoQuadLoader<LOGN> ld{S.u + ((size_t)b * 2 + c) * QC::N, quarter_fwd_lane<LOGN>(t)};
     const size_t off = (size_t)part * QC::Q;
     const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * QC::N + off;
     const u64 *__restrict__ addrow = it.c_in + ((size_t)(relin ? c : 0) * L + j) * QC::N;
@@ -1183,6 +1217,7 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
         typename A::V f[8];
         quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
         if constexpr (!PRE) fetch();
+        HEFX_STAMP_AT(14);
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
             ulonglong2 o;
@@ -1209,6 +1244,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kerne
                                                                         int L, int relin, int rows, KsScratch S)
 {
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(4);
+    HEFX_STAMP_AT(0);
     const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
     const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;  // g = remainder polynomial (b, c)
     const int j = slot >> 2, part = slot & 3;
@@ -1221,8 +1258,14 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kerne
     const KsItem it = items[b];
     if (mf.q != 0.0)
         moddown_finish_q_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, part);
-    else
+    else if constexpr (QuarterCfg<LOGN>::T >= 1024)  // 128-VGPR cap: one integer variant
         moddown_finish_q_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, part);
+    else
+        fwd_int_dispatch(mc, [&](auto pol) {
+            using A = decltype(pol);
+            moddown_finish_q_body<LOGN, A>(T, it, L, relin, S, lds, nt.tw, A::make(mc), mc, b, c, j, t, part);
+        });
+    HEFX_STAMP_AT(15);
 }
 
 template <typename K>
@@ -1544,12 +1587,13 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     u64 v[16];
     // rounded: subtract (q_l/2 mod q_j) from the reduced remainder, in the row's arithmetic policy
     const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, rounded != 0, T.halfmod[(size_t)(L - 1) * T.k + j]};
+    const int tl = HEFX_EO_LANE(SC, t);
     auto ld = [&](int r, u64 &x, u64 &y) {
-        const uint32_t e = eo_nat<SC>(t, r);
+        const uint32_t e = eo_nat<SC>(tl, r);
         x = dd[e];
         y = dd[e + SC::H / 2];
     };
-    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h);
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD>(v, ld, mode, lds, ntt_tables(T, j), mc, T.modsf[j], t, h, tl);
     const size_t off = (size_t)h * SC::H;
     const int ci = poly / size, pi = poly % size;
     const u64 *__restrict__ src = (tab ? tab[ci] + (size_t)pi * L * SC::N : in + (size_t)poly * L * SC::N) + (size_t)j * SC::N + off;
@@ -1656,6 +1700,21 @@ hipError_t launch_ntt_split15(const DevTables &T, bool inverse, const u64 *src, 
                            T, src, dst, rows, nrows, mod_first);
     return hipGetLastError();
 }
+
+#ifdef HEFX_STAMP
+}  // namespace hefx
+extern "C" __attribute__((visibility("default"))) int hefx_debug_stamps(unsigned long long *out, int clear)
+{
+    if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(hefx::hefx_stamp_buf), sizeof(hefx::hefx_stamp_buf)) != hipSuccess) return -1;
+    if (clear) {
+        void *p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(hefx::hefx_stamp_buf)) != hipSuccess) return -2;
+        if (hipMemset(p, 0, sizeof(hefx::hefx_stamp_buf)) != hipSuccess) return -3;
+    }
+    return (int)(sizeof(hefx::hefx_stamp_buf) / 8);
+}
+namespace hefx {
+#endif
 
 // HIP loads a translation unit's code object at its first kernel launch (milliseconds); hefx_context_create pays
 // that once, up front, instead of the first encode / rotation / encryption of a program.

@@ -26,6 +26,30 @@
 
 #include "hefx_modarith.cuh"
 
+// -DHEFX_STAMP=1|2: development builds (tools/stamp_timeline.py) in which thread 0 of every workgroup of the small-batch
+// kernels records the 100 MHz wall clock at its phase boundaries (2: after draining its outstanding memory operations, so
+// that a stamp means "everything before this has arrived").  Never defined in the product build.
+#ifdef HEFX_STAMP
+namespace hefx {
+static __device__ u64 hefx_stamp_buf[8 * 512 * 16];
+__device__ __forceinline__ int &hefx_stamp_kid()
+{
+    __shared__ int kid;
+    return kid;
+}
+}  // namespace hefx
+#define HEFX_STAMP_KERNEL(k) do { if (threadIdx.x == 0) hefx_stamp_kid() = (k); } while (0)
+#define HEFX_STAMP_AT(id)                                                                                            \
+    do {                                                                                                             \
+        if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
+        if (threadIdx.x == 0 && blockIdx.x < 512)                                                                    \
+            hefx_stamp_buf[((size_t)hefx_stamp_kid() * 512 + blockIdx.x) * 16 + (id)] = wall_clock64();             \
+    } while (0)
+#else
+#define HEFX_STAMP_KERNEL(k) do { } while (0)
+#define HEFX_STAMP_AT(id) do { } while (0)
+#endif
+
 // Scheduling fence between radix-2 stages: keeps hipcc from hoisting every twiddle load of a pass (60 VGPRs)
 // above the first butterfly, which pushed the kernels past 128 VGPRs and into scratch spills.
 #ifndef HEFX_STAGE_FENCE
@@ -422,21 +446,27 @@ struct NoHook {
     __device__ __forceinline__ void operator()() const {}
 };
 // `tail_hook` runs once, right after the last LDS exchange (before the final stages' arithmetic): a caller's chance to
-// put loads in flight that only its epilogue needs (ks_moddown_finish)
+// put loads in flight that only its epilogue needs (ks_moddown_finish).
+// t0 (default: t): the thread's LOGICAL index in pass 0 -- on entry v[r] = coefficient idx_nat(t0, r).  Pass 0 combines the
+// sixteen registers of a thread with workgroup-uniform twiddles and hands its results to LDS, so which column of the
+// T x 16 array a thread owns there is free; loaders over [evens | odds] rows pick the one that makes lane-adjacent reads
+// adjacent in memory (eo_lane, hefx_keyswitch.hip).  Every later pass works by t.
 template <int LOGN, class A, class HOOK = NoHook>
 __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A::V *lds,
                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                             int pre, const HOOK &tail_hook = HOOK())
+                                             int pre, const HOOK &tail_hook = HOOK(), int t0 = -1)
 {
     using C = NttCfg<LOGN>;
+    static_assert(LOGN - 4 == 31 - __builtin_clz(C::T), "pass 0: one block, twiddles uniform over the workgroup");
     typename A::TW w[15];
     load_pass_tw<LOGN, A>(w, tw, 0, t, pre);
 #pragma unroll
     for (int p = 0; p < C::FP; ++p) {
         const int LOGS = LOGN - 4 * (p + 1);
         const int S = 1 << LOGS;
-        const int b = t >> LOGS;
-        const int base = b * (16 * S) + (t & (S - 1));
+        const int tp = (p == 0 && t0 >= 0) ? t0 : t;
+        const int b = tp >> LOGS;
+        const int base = b * (16 * S) + (tp & (S - 1));
         const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p > 0) {
 #pragma unroll
@@ -612,7 +642,8 @@ __device__ __forceinline__ void ntt_inv_row(u64 (&v)[16], u64 *lds, const NttTab
 template <int LOGN, class A, class LD, int NB = 2, class HOOK = NoHook, bool FAST40 = false>
 __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &ld, const InMode &mode,
                                               const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
-                                              const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK())
+                                              const typename A::Ctx &cx, int t, int h, const HOOK &tail_hook = HOOK(),
+                                              int t0 = -1)
 {
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h);
     constexpr int BS = 16 / NB;
@@ -666,7 +697,7 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
             HEFX_STAGE_FENCE();
         }
     }
-    ntt_fwd_core<LOGN - 1, A, HOOK>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h, tail_hook);
+    ntt_fwd_core<LOGN - 1, A, HOOK>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 2 + h, tail_hook, t0);
     using C = NttCfg<LOGN - 1>;
     if constexpr (C::R == 0) {  // idx_out -> idx_io through LDS (the last pass read exactly the words written here)
         typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
@@ -684,27 +715,28 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
 template <int LOGN, class A, class LD, int NB = 2, bool MACOP = false>
 __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const InMode &mode, const ModConst &mc,
                                             u64 *lds, const typename A::TW *__restrict__ tw,
-                                            const typename A::Ctx &cx, int t, int h)
+                                            const typename A::Ctx &cx, int t, int h, int t0 = -1)
 {
     typename A::V f[16];
-    split_fwd_raw<LOGN, A, LD, NB>(f, ld, mode, mc, lds, tw, cx, t, h);
+    split_fwd_raw<LOGN, A, LD, NB>(f, ld, mode, mc, lds, tw, cx, t, h, NoHook(), t0);
 #pragma unroll
     for (int r = 0; r < 16; ++r) v[r] = MACOP ? A::mac_operand(f[r], cx) : A::fwd_finish(f[r], cx);
 }
 
 template <int LOGN, int NB = 2, bool MACOP = false, class LD>
 __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMode &mode, u64 *lds,
-                                          const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h)
+                                          const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h,
+                                          int t0 = -1)
 {
     if (mf.q != 0.0)
-        split_fwd_a<LOGN, ArithF64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h);
+        split_fwd_a<LOGN, ArithF64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h, t0);
     else if constexpr (MACOP)  // the digit transforms of the key switch: the lighter L16 butterfly where the prime admits it
         fwd_int_dispatch(mc, [&](auto pol) {
             using A = decltype(pol);
-            split_fwd_a<LOGN, A, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, A::make(mc), t, h);
+            split_fwd_a<LOGN, A, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, A::make(mc), t, h, t0);
         });
     else
-        split_fwd_a<LOGN, ArithU64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h);
+        split_fwd_a<LOGN, ArithU64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h, t0);
 }
 
 // Inverse split: a0[r], a1[r] = canonical NTT values at positions 2j, 2j+1 with j = idx_out(t,r) of the

@@ -64,20 +64,26 @@ __device__ __forceinline__ void load_rem_tw8(typename A::TW (&w)[7], const typen
 }
 
 // v[r] = coefficient idx_nat(t,r) on entry, NTT value idx_out(t,r) on exit (not yet canonical: A::fwd_finish).
+// `w` holds the twiddles of pass 0 on entry (load_pass_tw8(w, tw, 0, t, pre), issued by the caller as early as it likes:
+// the quarter-row kernels fetch them together with their data).
+// t0: the thread's LOGICAL index in pass 0 -- on entry v[r] = coefficient idx_nat(t0, r).  Pass 0 combines the eight
+// registers of a thread with workgroup-uniform twiddles and hands its results to LDS, so WHICH column t0 of the
+// T x 8 array a thread owns there is free: the loaders pick the permutation that makes their global reads lane-contiguous
+// (quarter_fwd_lane); every later pass works by t.
 template <int LOGN, class A>
-__device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A::V *lds,
-                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
-                                              int pre)
+__device__ __forceinline__ void ntt8_fwd_core_w(typename A::V (&v)[8], typename A::TW (&w)[7], typename A::V *lds,
+                                                const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                                int pre, int t0)
 {
     using C = Ntt8Cfg<LOGN>;
-    typename A::TW w[7];
-    load_pass_tw8<LOGN, A>(w, tw, 0, t, pre);
+    static_assert(LOGN - 3 == 31 - __builtin_clz(C::T), "pass 0: one block, twiddles uniform over the workgroup");
 #pragma unroll
     for (int p = 0; p < C::FP; ++p) {
         const int LOGS = LOGN - 3 * (p + 1);
         const int S = 1 << LOGS;
-        const int b = t >> LOGS;
-        const int base = b * (8 * S) + (t & (S - 1));
+        const int tp = p == 0 ? t0 : t;
+        const int b = tp >> LOGS;
+        const int base = b * (8 * S) + (tp & (S - 1));
         const int pb = C::phys(base), ps = C::pass_stride(LOGS);
         if (p > 0) {
 #pragma unroll
@@ -93,6 +99,7 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
             }
         }
         HEFX_STAGE_FENCE();
+        HEFX_STAMP_AT(8 + p);
         if (p + 1 < C::FP)
             load_pass_tw8<LOGN, A>(w, tw, p + 1, t, pre);
         else if (C::R > 0)
@@ -101,6 +108,7 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
 #pragma unroll
             for (int e = 0; e < 8; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
+            HEFX_STAMP_AT(3 + p);
         }
     }
     if (C::R > 0) {
@@ -124,6 +132,16 @@ __device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A:
             }
         }
     }
+}
+
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt8_fwd_core(typename A::V (&v)[8], typename A::V *lds,
+                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
+                                              int pre)
+{
+    typename A::TW w[7];
+    load_pass_tw8<LOGN, A>(w, tw, 0, t, pre);
+    ntt8_fwd_core_w<LOGN, A>(v, w, lds, tw, cx, t, pre, t);
 }
 
 // Half h of a forward transform of size 2^LOGN: ld(r, x, y) delivers the raw words of coefficients idx_nat(t,r) and
@@ -155,14 +173,24 @@ __device__ __forceinline__ void split8_fwd_raw(typename A::V (&f)[8], const LD &
 // Inverse core with eight coefficients per thread: v[r] = NTT value idx_out(t,r) on entry (U64: [0,4q); F64: |v| < 2^45),
 // coefficient idx_nat(t,r) on exit, not yet canonical (A::inv_finish).  Mirror of ntt8_fwd_core; N^-1 folded into the
 // last stage exactly as in ntt_inv_core.
+// the twiddles the inverse core starts with: the remainder pass's, or (R == 0) those of the last full pass
 template <int LOGN, class A>
-__device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A::V *lds,
-                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
+__device__ __forceinline__ void load_inv_first_tw8(typename A::TW (&w)[7], const typename A::TW *__restrict__ itw, int t)
 {
     using C = Ntt8Cfg<LOGN>;
-    typename A::TW w[7];
-    if (C::R > 0) {
+    if (C::R > 0)
         load_rem_tw8<LOGN, A>(w, itw, t, 1);
+    else
+        load_pass_tw8<LOGN, A>(w, itw, C::FP - 1, t, 1);
+}
+
+// `w` = load_inv_first_tw8 on entry
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt8_inv_core_w(typename A::V (&v)[8], typename A::TW (&w)[7], typename A::V *lds,
+                                                const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
+{
+    using C = Ntt8Cfg<LOGN>;
+    if (C::R > 0) {
         A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = C::R - 1; u >= 0; --u) {
@@ -185,8 +213,7 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
             for (int e = 0; e < C::G; ++e) lds[pg + C::REM_STRIDE * c + e] = v[c * C::G + e];
         }
         __syncthreads();
-    } else {
-        load_pass_tw8<LOGN, A>(w, itw, C::FP - 1, t, 1);
+        HEFX_STAMP_AT(3);
     }
 #pragma unroll
     for (int p = C::FP - 1; p >= 0; --p) {
@@ -219,8 +246,18 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
 #pragma unroll
             for (int e = 0; e < 8; ++e) lds[pb + ps * e] = v[e];
             __syncthreads();
+            HEFX_STAMP_AT(4 + (C::FP - 1 - p));
         }
     }
+}
+
+template <int LOGN, class A>
+__device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A::V *lds,
+                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
+{
+    typename A::TW w[7];
+    load_inv_first_tw8<LOGN, A>(w, itw, t);
+    ntt8_inv_core_w<LOGN, A>(v, w, lds, itw, cx, t);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -233,7 +270,19 @@ __device__ __forceinline__ void ntt8_inv_core(typename A::V (&v)[8], typename A:
 // inverse stages (gaps 1, 2) combine the four values of positions 4g..4g+3.  Used when a chunk cannot fill the chip:
 // a lone rotation of a NAF chain, the lockstep chains of a few dot products.
 // ------------------------------------------------------------------------------------------------
-// ld(r, x0, x1, x2, x3): raw words of the coefficients idx_nat(t,r) + m*N/4, m = 0..3; on return
+// The coefficient column a thread loads (ntt8_fwd_core_w's t0): rows in coefficient form are stored [evens | odds], so
+// the first half of the workgroup takes the even columns and the second half the odd ones -- lane-adjacent reads are then
+// adjacent in memory.  (With t0 = t neighbouring lanes alternated between the two halves of the row: the 32 loads of a
+// thread took ~28 cycles each in the address coalescer, the last wave of a workgroup had its data ~1.6 us after the
+// first, and every wave waited at the first barrier: tools/stamp_timeline.py.)
+template <int LOGN>
+__device__ __forceinline__ int quarter_fwd_lane(int t)
+{
+    constexpr int T = Ntt8Cfg<LOGN - 2>::T;
+    return ((t & (T / 2 - 1)) << 1) | (t / (T / 2));
+}
+
+// ld(r, x0, x1, x2, x3): raw words of the coefficients idx_nat(t0,r) + m*N/4, m = 0..3, t0 = quarter_fwd_lane(t); on return
 // f[r] = unfinished NTT value at qd*N/4 + idx_out(t,r), qd = 2*h0 + h1
 template <int LOGN, class A, class LD>
 __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD &ld, const InMode &mode,
@@ -242,6 +291,12 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
 {
     const int h0 = qd >> 1, h1 = qd & 1;
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h0), w2 = A::half_twiddle(tw[2 + h0], cx, h1);
+    HEFX_STAMP_AT(1);
+    // the first radix-8 pass's twiddles travel with the data (one kernel at a time is latency, not registers -- except in
+    // the 1024-thread workgroups of N = 32768, capped at 128 VGPRs: there they are fetched after the first two stages)
+    constexpr bool PREW = Ntt8Cfg<LOGN - 2>::T < 1024;
+    typename A::TW wp[7];
+    if constexpr (PREW) load_pass_tw8<LOGN - 2, A>(wp, tw, 0, t, 4 + qd);
     auto stage = [&](auto red) {
         constexpr int RED = decltype(red)::value;
         u64 x[8][4];
@@ -257,16 +312,21 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
             f[r] = A::ct_sel(a, b, w2, cx);
         }
         HEFX_STAGE_FENCE();
+        HEFX_STAMP_AT(2);
     };
     if (A::IS_F64 ? mode.red_f64 : mode.red_int) {
         if (A::IS_F64 && mode.below_2_61 && A::fast_wide(cx))
             stage(std::integral_constant<int, 2>{});
+        else if (PREW && !A::IS_F64 && mode.lt2q)  // 32 Barrett reductions per thread were ~2 us of the 60-bit row's mod-down finish
+            stage(std::integral_constant<int, 3>{});
         else
             stage(std::integral_constant<int, 1>{});
     } else {
         stage(std::integral_constant<int, 0>{});
     }
-    ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 4 + qd);
+    if constexpr (!PREW) load_pass_tw8<LOGN - 2, A>(wp, tw, 0, t, 4 + qd);
+    ntt8_fwd_core_w<LOGN - 2, A>(f, wp, reinterpret_cast<typename A::V *>(lds), tw, cx, t, 4 + qd,
+                                 quarter_fwd_lane<LOGN>(t));
 }
 
 template <int LOGN, bool MACOP = false, class LD>
@@ -280,15 +340,24 @@ __device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InM
 #pragma unroll
         for (int r = 0; r < 8; ++r) v[r] = MACOP ? ArithF64::mac_operand(f[r], cx) : ArithF64::fwd_finish(f[r], cx);
     } else {
-        const ArithU64::Ctx cx = ArithU64::make(mc);
-        quarter_fwd_raw<LOGN, ArithU64, LD>(v, ld, mode, mc, lds, nt.tw, cx, t, qd);
+        fwd_int_dispatch(mc, [&](auto pol) {  // the 16q butterfly where the prime admits it
+            using A = decltype(pol);
+            const typename A::Ctx cx = A::make(mc);
+            quarter_fwd_raw<LOGN, A, LD>(v, ld, mode, mc, lds, nt.tw, cx, t, qd);
 #pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = MACOP ? ArithU64::mac_operand(v[r], cx) : ArithU64::fwd_finish(v[r], cx);
+            for (int r = 0; r < 8; ++r) v[r] = MACOP ? A::mac_operand(v[r], cx) : A::fwd_finish(v[r], cx);
+        });
     }
 }
 
 // ldp(j) = (value[2j], value[2j+1]) of the row (canonical NTT values); part = position mod 4 of the kept value; on return
-// v[r] = coefficient 4*idx_nat(t,r) + part, canonical
+// v[r] = coefficient 4*idx_nat(t,r) + part, canonical.
+// Stages A and B are element-wise on the groups of four positions 4j..4j+3, so when the core starts on eight CONSECUTIVE
+// groups per thread (R == 0: N = 4096, 16384) they run on lane-adjacent groups instead (idx_nat) and their results reach the
+// core's layout through LDS, as in split_inv_a: with idx_out every lane of a 16-byte load sat in its own cache line, sixteen
+// loads (forty with the twiddles of part 3) walked 256 contiguous bytes per lane, and the first phase of the inverse
+// kernels took 8.3-8.9 us of their 14-15 (tools/stamp_timeline.py).  All operands of a batch of groups -- records, stage
+// twiddles, the core's first twiddles -- are requested before the first is used.
 template <int LOGN, class A, class LDP>
 __device__ __forceinline__ void quarter_inv_a(u64 (&v)[8], const LDP &ldp, u64 *lds,
                                               const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t,
@@ -296,31 +365,61 @@ __device__ __forceinline__ void quarter_inv_a(u64 (&v)[8], const LDP &ldp, u64 *
 {
     using C = Ntt8Cfg<LOGN - 2>;
     constexpr int N = 1 << LOGN;
+    constexpr int NB = C::T >= 1024 ? 2 : 1, BS = 8 / NB;  // 1024-thread workgroups: 128 VGPRs, two batches
     const int b0 = part & 1, b1 = part >> 1;
     typename A::V f[8];
-    ulonglong2 p0[8], p1[8];
+    typename A::TW w[7];
+    auto rec = [&](int r) { return C::R == 0 ? C::idx_nat(t, r) : C::idx_out(t, r); };
+    HEFX_STAMP_AT(1);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int j = C::idx_out(t, r);  // the four positions 4j .. 4j+3
-        p0[r] = ldp(2 * j);
-        p1[r] = ldp(2 * j + 1);
-    }
+    for (int g = 0; g < NB; ++g) {
+        ulonglong2 p0[BS], p1[BS];
+        typename A::TW wa0[BS], wa1[BS], wb[BS];
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-        const int j = C::idx_out(t, r);
-        typename A::V e0, e1;  // stage A (gap 1): positions 4j + b0 and 4j + 2 + b0
-        if (b0 == 0) {
-            e0 = A::gs_half_sum(A::from_u64(p0[r].x), A::from_u64(p0[r].y), cx);
-            e1 = A::gs_half_sum(A::from_u64(p1[r].x), A::from_u64(p1[r].y), cx);
-        } else {
-            e0 = A::gs_half_diff(A::from_u64(p0[r].x), A::from_u64(p0[r].y), itw[N / 2 + 2 * j], cx);
-            e1 = A::gs_half_diff(A::from_u64(p1[r].x), A::from_u64(p1[r].y), itw[N / 2 + 2 * j + 1], cx);
+        for (int r = 0; r < BS; ++r) {
+            const int j = rec(BS * g + r);  // the four positions 4j .. 4j+3
+            p0[r] = ldp(2 * j);
+            p1[r] = ldp(2 * j + 1);
         }
-        // stage B (gap 2): sum (b1 = 0) or twiddled difference (b1 = 1)
-        f[r] = b1 == 0 ? A::inv_add(e0, e1, cx) : A::inv_sub_mul(e0, e1, itw[N / 4 + j], cx);
+        if (b0) {
+#pragma unroll
+            for (int r = 0; r < BS; ++r) {
+                const int j = rec(BS * g + r);
+                wa0[r] = itw[N / 2 + 2 * j];
+                wa1[r] = itw[N / 2 + 2 * j + 1];
+            }
+        }
+        if (b1) {
+#pragma unroll
+            for (int r = 0; r < BS; ++r) wb[r] = itw[N / 4 + rec(BS * g + r)];
+        }
+        if (g == NB - 1) load_inv_first_tw8<LOGN - 2, A>(w, itw, t);
+#pragma unroll
+        for (int r = 0; r < BS; ++r) {
+            typename A::V e0, e1;  // stage A (gap 1): positions 4j + b0 and 4j + 2 + b0
+            if (b0 == 0) {
+                e0 = A::gs_half_sum(A::from_u64(p0[r].x), A::from_u64(p0[r].y), cx);
+                e1 = A::gs_half_sum(A::from_u64(p1[r].x), A::from_u64(p1[r].y), cx);
+            } else {
+                e0 = A::gs_half_diff(A::from_u64(p0[r].x), A::from_u64(p0[r].y), wa0[r], cx);
+                e1 = A::gs_half_diff(A::from_u64(p1[r].x), A::from_u64(p1[r].y), wa1[r], cx);
+            }
+            // stage B (gap 2): sum (b1 = 0) or twiddled difference (b1 = 1)
+            f[BS * g + r] = b1 == 0 ? A::inv_add(e0, e1, cx) : A::inv_sub_mul(e0, e1, wb[r], cx);
+        }
+        HEFX_STAGE_FENCE();
     }
-    HEFX_STAGE_FENCE();
-    ntt8_inv_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
+    HEFX_STAMP_AT(2);
+    if constexpr (C::R == 0) {
+        typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+        const int pw = t + (t >> 3), pr = 9 * t;  // R == 0: phys(i) = i + (i >> 3)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lf[pw + (C::T + C::T / 8) * r] = f[r];  // phys(idx_nat(t, r))
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[r] = lf[pr + r];  // phys(8t + r): the words the core's first pass owns (and rewrites)
+    }
+    ntt8_inv_core_w<LOGN - 2, A>(f, w, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = A::inv_finish(f[r], cx);
 }
