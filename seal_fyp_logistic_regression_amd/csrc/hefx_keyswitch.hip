@@ -1062,7 +1062,7 @@ struct QuarterCfg {
 __host__ __device__ static inline int quarter_grid(int rows) { return ((rows + 7) / 8) * 32; }
 __device__ static __forceinline__ void quarter_decode(int bid, int &p, int &part)
 {
-    part = (bid >> 3) & 3;
+    part = 3 - ((bid >> 3) & 3);  // the inverse kernels' heaviest quarter (two twiddled stages) is dispatched first
     p = ((bid >> 5) << 3) | (bid & 7);
 }
 // EO position of coefficient j (rows in coefficient form are stored [evens | odds], as the split-2 kernels do)
@@ -1123,9 +1123,9 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     extern __shared__ __align__(16) u64 lds[];
     HEFX_STAMP_KERNEL(1);
     HEFX_STAMP_AT(0);
-    // block -> (digit g = (b, i), target slot jj, quarter): the 4 L workgroups of a digit share an XCD
-    const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;
+    // grid (8, 4 L, groups) -> (digit g = (b, i), target slot jj, quarter): dispatched x-fastest, the 4 L workgroups of a
+    // digit share an XCD (and no division sits between the kernel's entry and its first table loads)
+    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
     int jj = slot >> 2;
     const int part = slot & 3;
     if (g >= rows) return;
@@ -1134,11 +1134,13 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     if (jj >= i) ++jj;
     const int m = jj < L ? jj : T.k - 1;
     const ModConst mc = T.mods[m];
+    const ModConstF mf = T.modsf[m];
     const u64 qi = T.mods[i].q;
+    const bool wide_digit = T.modsf[i].q == 0.0;
     u64 v[8];
-    const InMode mode = {qi > mc.q, T.modsf[i].q == 0.0, false, 0};
+    const InMode mode = {qi > mc.q, wide_digit, false, 0};
     const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, quarter_fwd_lane<LOGN>(t)};
-    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, part);
+    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, part);
     u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
 #pragma unroll
     for (int r = 0; r < 8; r += 2) gst16(xd + C::idx_out(t, r), make_ulonglong2(v[r], v[r + 1]));
@@ -1174,14 +1176,13 @@ template <int LOGN, class A>
 __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const KsItem &it, int L, int relin,
                                                       const KsScratch &S, u64 *lds,
                                                       const typename A::TW *__restrict__ tw, const typename A::Ctx &cx,
-                                                      const ModConst &mc, int b, int c, int j, int t, int part)
+                                                      const ModConst &mc, u64 half_j, u64 q_special,
+                                                      const decltype(md_pinv(A{}, T, 0, 0)) &pinv, int b, int c, int j,
+                                                      int t, int part)
 {
     using QC = QuarterCfg<LOGN>;
     using C = typename QC::C;
-    const int sp = T.k - 1;
-    const u64 half_j = T.halfmod[(size_t)sp * T.k + j];
-    const auto pinv = md_pinv(A{}, T, sp, j);
-    const InMode mode = {true, true, true, half_j, true, T.mods[sp].q < 2 * mc.q};
+    const InMode mode = {true, true, true, half_j, true, q_special < 2 * mc.q};
     const EoQuadLoader<LOGN> ld{S.u + ((size_t)b * 2 + c) * QC::N, quarter_fwd_lane<LOGN>(t)};
     const size_t off = (size_t)part * QC::Q;
     const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * QC::N + off;
@@ -1211,12 +1212,16 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
                 pp[r] = pv.x, pp[r + 1] = pv.y;
             }
         };
-        // 1024-thread workgroups (N = 32768) are capped at 128 VGPRs: there the operands are fetched after the transform
+        // 1024-thread workgroups (N = 32768) are capped at 128 VGPRs: there the operands are fetched after the transform;
+        // elsewhere right BEHIND the transform's own loads (ahead of them they delayed the data every wave waits for first)
         constexpr bool PRE = QC::T < 1024;
-        if constexpr (PRE) fetch();
         typename A::V f[8];
-        quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
-        if constexpr (!PRE) fetch();
+        if constexpr (PRE) {
+            quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part, fetch);
+        } else {
+            quarter_fwd_raw<LOGN, A>(f, ld, mode, mc, lds, tw, cx, t, part);
+            fetch();
+        }
         HEFX_STAMP_AT(14);
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
@@ -1246,24 +1251,32 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kerne
     extern __shared__ __align__(16) u64 lds[];
     HEFX_STAMP_KERNEL(4);
     HEFX_STAMP_AT(0);
-    const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
-    const int slot = rest % (4 * L), g = (rest / (4 * L)) * 8 + x;  // g = remainder polynomial (b, c)
+    // grid (8, 4 L, groups), dispatched x-fastest: g = remainder polynomial (b, c)
+    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
     const int j = slot >> 2, part = slot & 3;
     if (g >= rows) return;
     const int t = threadIdx.x;
     const int b = g >> 1, c = g & 1;
+    const int sp = T.k - 1;
+    const size_t spj = (size_t)sp * T.k + j;
     const ModConst mc = T.mods[j];
     const ModConstF mf = T.modsf[j];
-    const NttTables nt = ntt_tables(T, j);
     const KsItem it = items[b];
+    const u64 half_j = T.halfmod[spj], q_special = T.mods[sp].q;
+    const PinvU pinv_u{T.invmod[spj]};
+    const PinvF pinv_f{T.invmodf[spj]};
+    const NttTables nt = ntt_tables(T, j);
     if (mf.q != 0.0)
-        moddown_finish_q_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, part);
+        moddown_finish_q_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, half_j, q_special,
+                                              pinv_f, b, c, j, t, part);
     else if constexpr (QuarterCfg<LOGN>::T >= 1024)  // 128-VGPR cap: one integer variant
-        moddown_finish_q_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, part);
+        moddown_finish_q_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, half_j, q_special,
+                                              pinv_u, b, c, j, t, part);
     else
         fwd_int_dispatch(mc, [&](auto pol) {
             using A = decltype(pol);
-            moddown_finish_q_body<LOGN, A>(T, it, L, relin, S, lds, nt.tw, A::make(mc), mc, b, c, j, t, part);
+            moddown_finish_q_body<LOGN, A>(T, it, L, relin, S, lds, nt.tw, A::make(mc), mc, half_j, q_special, pinv_u, b,
+                                           c, j, t, part);
         });
     HEFX_STAMP_AT(15);
 }
@@ -1344,7 +1357,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_intt_digits_q_kernel<LOGN>), dim3(quarter_grid(n * L)), dim3(TQ), ldsq, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
         mark(2);
-        hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(((n * L + 7) / 8) * 8 * 4 * L), dim3(TQ), ldsq, s, T, L,
+        hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, L,
                            n * L, scr);
         mark(3);
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, rl, 0,
@@ -1352,7 +1365,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(4);
         hipLaunchKernelGGL((ks_moddown_intt_q_kernel<LOGN>), dim3(quarter_grid(n * 2)), dim3(TQ), ldsq, s, T, L, n * 2, scr);
         mark(5);
-        hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(((n * 2 + 7) / 8) * 8 * 4 * L), dim3(TQ), ldsq, s, T,
+        hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T,
                            batch, L, rl, n * 2, scr);
         mark(-1);
         return hipGetLastError();

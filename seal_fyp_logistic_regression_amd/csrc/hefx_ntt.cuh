@@ -42,8 +42,9 @@ __device__ __forceinline__ int &hefx_stamp_kid()
 #define HEFX_STAMP_AT(id)                                                                                            \
     do {                                                                                                             \
         if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
-        if (threadIdx.x == 0 && blockIdx.x < 512)                                                                    \
-            hefx_stamp_buf[((size_t)hefx_stamp_kid() * 512 + blockIdx.x) * 16 + (id)] = wall_clock64();             \
+        const unsigned hefx_wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                   \
+        if (threadIdx.x == 0 && hefx_wg_ < 512)                                                                      \
+            hefx_stamp_buf[((size_t)hefx_stamp_kid() * 512 + hefx_wg_) * 16 + (id)] = wall_clock64();               \
     } while (0)
 #else
 #define HEFX_STAMP_KERNEL(k) do { } while (0)

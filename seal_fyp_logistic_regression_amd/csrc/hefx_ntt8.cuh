@@ -284,10 +284,12 @@ __device__ __forceinline__ int quarter_fwd_lane(int t)
 
 // ld(r, x0, x1, x2, x3): raw words of the coefficients idx_nat(t0,r) + m*N/4, m = 0..3, t0 = quarter_fwd_lane(t); on return
 // f[r] = unfinished NTT value at qd*N/4 + idx_out(t,r), qd = 2*h0 + h1
-template <int LOGN, class A, class LD>
+// after_loads(): called once, right after the data loads are requested (the mod-down finish puts its epilogue operands
+// in flight there)
+template <int LOGN, class A, class LD, class HOOK = NoHook>
 __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD &ld, const InMode &mode,
                                                 const ModConst &mc, u64 *lds, const typename A::TW *__restrict__ tw,
-                                                const typename A::Ctx &cx, int t, int qd)
+                                                const typename A::Ctx &cx, int t, int qd, const HOOK &after_loads = HOOK())
 {
     const int h0 = qd >> 1, h1 = qd & 1;
     const typename A::TW w1 = A::half_twiddle(tw[1], cx, h0), w2 = A::half_twiddle(tw[2 + h0], cx, h1);
@@ -302,6 +304,7 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
         u64 x[8][4];
 #pragma unroll
         for (int r = 0; r < 8; ++r) ld(r, x[r][0], x[r][1], x[r][2], x[r][3]);
+        after_loads();
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             // stage 0 (gap N/2): half h0 of (x0, x2) and of (x1, x3); stage 1 (gap N/4): quarter h1 of that half
