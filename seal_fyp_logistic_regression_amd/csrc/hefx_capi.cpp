@@ -1081,9 +1081,23 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         const bool small = small_ok && cnt <= ks_small_max() && !hoist && !chunk_alias;
         // ... and run on quarter-row workgroups when split-2 workgroups (2 L (L+1) per item in the widest launch) would
         // leave CUs idle: HEFX_QUARTER=0/1 overrides the size test
+        // per launch: quarter rows where the quarter grid (4 workgroups per row) still gets a CU per workgroup -- measured
+        // with clock stamps over n = 1..8, L = 2..8 (profiles/r03/quarter_mask_sweep.txt): the inverse launches always
+        // (few rows), the digit transforms up to 256 quarter workgroups (beyond that 2 split workgroups per row win: 14 us
+        // for 256 of them against 19 us for 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none /
+        // all, HEFX_QMASK=<bits> any combination (KS_Q_*)
         static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
-        const bool quarter = small && !fused && nchunks == 1 &&
-                             (quarter_force >= 0 ? quarter_force != 0 : cnt * 2 * L * (L + 1) <= 256);
+        static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
+        int quarter = 0;
+        if (small && !fused && nchunks == 1) {
+            if (qmask_force >= 0)
+                quarter = qmask_force & KS_Q_ALL;
+            else if (quarter_force >= 0)
+                quarter = quarter_force ? KS_Q_ALL : 0;
+            else
+                quarter = (cnt * L * 4 <= 256 ? KS_Q_INTT : 0) | (cnt * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
+                          (cnt * 2 * 4 <= 256 ? KS_Q_MDI : 0) | (cnt * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
+        }
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, hoist, chunk_alias, small ? hb : nullptr,
                                       quarter, cs, prof));

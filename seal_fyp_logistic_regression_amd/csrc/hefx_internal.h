@@ -130,7 +130,9 @@ struct KsProf {
 // quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  bool quarter, hipStream_t s, KsProf *prof);
+                                  int quarter, hipStream_t s, KsProf *prof);
+// `quarter`: which of the four transform launches run on quarter-row workgroups
+constexpr int KS_Q_INTT = 1, KS_Q_NTT = 2, KS_Q_MDI = 4, KS_Q_FIN = 8, KS_Q_ALL = 15;
 int ks_small_max();
 // double-hoisted linear transform (hefx_keyswitch.hip): see lt2_mac_kernel
 hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,

@@ -112,10 +112,13 @@ __device__ static __forceinline__ int eo_lane(int t)
     constexpr int T = SC::C::T;
     return ((t & (T / 2 - 1)) << 1) | (t / (T / 2));
 }
-#ifdef HEFX_NO_EO_LANE  // A/B knob (tools/build_variant.sh): the round-2 mapping (column t)
+// From N = 16384 on (C3 +2.7 %, C5 +3.3 %: profiles/r03/ab_eo_lane.txt).  At N = 8192 the second index costs the
+// 256-thread workgroups two registers past 128 and with them the fourth workgroup per CU; measured neutral to slightly
+// negative there, so the smaller rings keep column t.
+#ifdef HEFX_NO_EO_LANE  // A/B knob (tools/build_variant.sh): column t everywhere
 #define HEFX_EO_LANE(SC, t) (t)
 #else
-#define HEFX_EO_LANE(SC, t) eo_lane<SC>(t)
+#define HEFX_EO_LANE(SC, t) (SC::N >= 16384 ? eo_lane<SC>(t) : (t))
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -196,11 +199,14 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
                                                                                     int L, int relin, int rows, KsScratch S)
 {
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(0);
+    HEFX_STAMP_AT(0);
     if (blockIdx.x == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
     int p, h;
     split_decode(blockIdx.x, p, h);
     if (p >= rows) return;
     intt_digits_body<LOGN>(T, small.it[p / L], L, relin, 0, p / L, p % L, h, S, lds);
+    HEFX_STAMP_AT(15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -574,12 +580,12 @@ __global__ __launch_bounds__(256, HEFX_MAC_WAVES) void ks_mac_kernel(DevTables T
     const int jj = int_only ? nth_int_slot(T, L, blockIdx.y) : (int)blockIdx.y;
 #ifdef HEFX_STAMP
     const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (threadIdx.x == 0 && wg < 512) hefx_stamp_buf[((size_t)2 * 512 + wg) * 16] = wall_clock64();
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)2 * 1024 + wg) * 16] = wall_clock64();
 #endif
     mac_unit<STREAM>(T, items, L, relin, item0, count, S, jj, 2 * blockIdx.z, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
 #ifdef HEFX_STAMP
     if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    if (threadIdx.x == 0 && wg < 512) hefx_stamp_buf[((size_t)2 * 512 + wg) * 16 + 15] = wall_clock64();
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)2 * 1024 + wg) * 16 + 15] = wall_clock64();
 #endif
 }
 
@@ -589,7 +595,10 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
                                                                              int item0, int stream_x, KsScratch S)
 {
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(1);
+    HEFX_STAMP_AT(0);
     ntt_digit_row<LOGN>(T, L, rows, item0, stream_x, S, lds);
+    HEFX_STAMP_AT(15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -865,6 +874,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(3);
+    HEFX_STAMP_AT(0);
     int p, h;
     split_decode(blockIdx.x, p, h);
     if (p >= rows) return;
@@ -879,6 +890,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
     u64 *__restrict__ ud = S.u + (size_t)p * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) ud[C::idx_nat(t, r)] = csub(v[r] + half, mc.q);
+    HEFX_STAMP_AT(15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1028,6 +1040,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
                                                                                  int relin, int rows, KsScratch S)
 {
     extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(4);
+    HEFX_STAMP_AT(0);
     int g, j, h;
     group_decode(blockIdx.x, L, g, j, h);  // g = remainder polynomial (b, c); j = one of the L data primes
     if (g >= rows) return;
@@ -1041,6 +1055,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
         moddown_finish_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, h);
     else
         moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
+    HEFX_STAMP_AT(15);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1291,7 +1306,7 @@ static void set_lds(K kernel, size_t bytes)
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, int sub, bool hoist, bool alias,
-                                           const KsSmallItems *small, bool quarter, hipStream_t s, KsProf *prof)
+                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -1342,7 +1357,10 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(-1);
         return hipGetLastError();
     }
-    // quarter rows: a small chunk that cannot fill the chip with split-2 workgroups (unfused, no aliasing / hoisting)
+    // quarter rows: a small chunk that cannot fill the chip with split-2 workgroups (unfused, no aliasing / hoisting).
+    // `quarter` is a mask over the four transform launches (KS_Q_*): the scratch arrays have one layout, so each launch
+    // picks its own workgroup shape -- ks_run gives quarter rows to the launches whose quarter grid still fits the chip in
+    // one round (at n = 8, L = 5: the two inverse launches and not the 200 digit transforms).
     if (small && quarter && sub >= n) {
         static PerDeviceOnce attrq;
         const size_t ldsq = QuarterCfg<LOGN>::LDS_BYTES;
@@ -1354,19 +1372,36 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         }
         constexpr int TQ = QuarterCfg<LOGN>::T;
         mark(1);
-        hipLaunchKernelGGL((ks_intt_digits_q_kernel<LOGN>), dim3(quarter_grid(n * L)), dim3(TQ), ldsq, s, T, *small,
-                           const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
+        if (quarter & KS_Q_INTT)
+            hipLaunchKernelGGL((ks_intt_digits_q_kernel<LOGN>), dim3(quarter_grid(n * L)), dim3(TQ), ldsq, s, T, *small,
+                               const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
+        else
+            hipLaunchKernelGGL((ks_intt_digits_small_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, *small,
+                               const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
         mark(2);
-        hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, L,
-                           n * L, scr);
+        if (quarter & KS_Q_NTT)
+            hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, L,
+                               n * L, scr);
+        else
+            hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds_ntt, s, T, L,
+                               n * L, 0, 0, scr);
         mark(3);
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, rl, 0,
                            n, 0, scr);
         mark(4);
-        hipLaunchKernelGGL((ks_moddown_intt_q_kernel<LOGN>), dim3(quarter_grid(n * 2)), dim3(TQ), ldsq, s, T, L, n * 2, scr);
+        if (quarter & KS_Q_MDI)
+            hipLaunchKernelGGL((ks_moddown_intt_q_kernel<LOGN>), dim3(quarter_grid(n * 2)), dim3(TQ), ldsq, s, T, L, n * 2,
+                               scr);
+        else
+            hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2,
+                               scr);
         mark(5);
-        hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T,
-                           batch, L, rl, n * 2, scr);
+        if (quarter & KS_Q_FIN)
+            hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T,
+                               batch, L, rl, n * 2, scr);
+        else
+            hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T,
+                               batch, L, rl, n * 2, scr);
         mark(-1);
         return hipGetLastError();
     }
@@ -1535,7 +1570,7 @@ int lt2_chunk() { return LT2_CHUNK; }
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  bool quarter, hipStream_t s, KsProf *prof)
+                                  int quarter, hipStream_t s, KsProf *prof)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
@@ -1544,7 +1579,7 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
         for (int i = n; i < KS_SMALL_MAX; ++i) sm.it[i] = KsItem{};
         small = &sm;
     }
-    quarter = quarter && T.logn >= 12;  // quarter rows of N = 2048 would be half-wave workgroups
+    if (T.logn < 12) quarter = 0;  // quarter rows of N = 2048 would be half-wave workgroups
 #define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL

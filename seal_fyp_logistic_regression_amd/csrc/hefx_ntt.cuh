@@ -31,7 +31,7 @@
 // that a stamp means "everything before this has arrived").  Never defined in the product build.
 #ifdef HEFX_STAMP
 namespace hefx {
-static __device__ u64 hefx_stamp_buf[8 * 512 * 16];
+static __device__ u64 hefx_stamp_buf[8 * 1024 * 16];
 __device__ __forceinline__ int &hefx_stamp_kid()
 {
     __shared__ int kid;
@@ -43,8 +43,8 @@ __device__ __forceinline__ int &hefx_stamp_kid()
     do {                                                                                                             \
         if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                              \
         const unsigned hefx_wg_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);                   \
-        if (threadIdx.x == 0 && hefx_wg_ < 512)                                                                      \
-            hefx_stamp_buf[((size_t)hefx_stamp_kid() * 512 + hefx_wg_) * 16 + (id)] = wall_clock64();               \
+        if (threadIdx.x == 0 && hefx_wg_ < 1024)                                                                     \
+            hefx_stamp_buf[((size_t)hefx_stamp_kid() * 1024 + hefx_wg_) * 16 + (id)] = wall_clock64();               \
     } while (0)
 #else
 #define HEFX_STAMP_KERNEL(k) do { } while (0)

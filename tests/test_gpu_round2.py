@@ -508,12 +508,14 @@ def test_primes_at_the_top_of_the_admissible_range_bit_exact(N):
             assert (e.rescale_to_next(L, 2, e.to_device(r), rounded=rounded).download() == o.rescale(r, rounded=rounded)).all()
 
 
-@pytest.mark.parametrize("quarter", ["0", "1"])
-def test_small_batch_quarter_row_path_bit_exact(quarter):
+@pytest.mark.parametrize("knob", ["HEFX_QUARTER=0", "HEFX_QUARTER=1", "auto", "HEFX_QMASK=5", "HEFX_QMASK=10"])
+def test_small_batch_quarter_row_path_bit_exact(knob):
     """The small-batch key switch (quarter-row workgroups with eight coefficients per thread, descriptors in the kernel
-    arguments; HEFX_QUARTER forces it on or off for chunks of <= 8 items) gives the oracle's bits for rotations, fused
-    rotate+multiply_plain and relinearisation at every ring size it is built for (N = 4096 .. 32768: every radix-8 pass
-    / remainder combination of the 8-coefficient cores), top and lower levels, 1..8 items, distinct keys / elements."""
+    arguments) gives the oracle's bits for rotations, fused rotate+multiply_plain and relinearisation at every ring size it
+    is built for (N = 4096 .. 32768: every radix-8 pass / remainder combination of the 8-coefficient cores), top and lower
+    levels, 1..8 items, distinct keys / elements.  Each of the four transform launches picks quarter rows or split-2
+    workgroups on its own (the scratch layouts are shared): forced off, forced on, the engine's own per-launch rule, and the
+    two complementary mixes (inverse launches on quarter rows with forward ones on split-2 workgroups, and the reverse)."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r"""
@@ -556,8 +558,10 @@ for name in ("C2", "C3", "C4", "C5", "toy4096", "toy2048"):
         ok &= bool((dd.download() == o.apply_galois(ct, 3, keys[0])).all())
 print("PARITY", ok)
 """ % (root, root)
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_QUARTER": quarter}, capture_output=True,
-                       text=True, timeout=900)
+    env = {k: v for k, v in os.environ.items() if k not in ("HEFX_QUARTER", "HEFX_QMASK")}
+    if knob != "auto":
+        env[knob.split("=")[0]] = knob.split("=")[1]
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
     assert "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-2000:])
 
 
