@@ -1082,10 +1082,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         // ... and run on quarter-row workgroups when split-2 workgroups (2 L (L+1) per item in the widest launch) would
         // leave CUs idle: HEFX_QUARTER=0/1 overrides the size test
         // per launch: quarter rows where the quarter grid (4 workgroups per row) still gets a CU per workgroup -- measured
-        // with clock stamps over n = 1..8, L = 2..8 (profiles/r03/quarter_mask_sweep.txt): the inverse launches always
-        // (few rows), the digit transforms up to 256 quarter workgroups (beyond that 2 split workgroups per row win: 14 us
-        // for 256 of them against 19 us for 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none /
-        // all, HEFX_QMASK=<bits> any combination (KS_Q_*)
+        // with clock stamps over n = 1..8, L = 2..8 (profiles/r03/quarter_mask_sweep.txt) and end to end up to n = 32: the
+        // inverse launches up to 256 / 192 quarter workgroups (256 of the mod-down inverse at n = 32 measured +27 us), the
+        // digit transforms up to 256 (beyond that 2 split workgroups per row win: 14 us for 256 of them against 19 us for
+        // 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none / all, HEFX_QMASK=<bits> any
+        // combination (KS_Q_*)
         static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
         static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
         int quarter = 0;
@@ -1096,7 +1097,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
                 quarter = quarter_force ? KS_Q_ALL : 0;
             else
                 quarter = (cnt * L * 4 <= 256 ? KS_Q_INTT : 0) | (cnt * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
-                          (cnt * 2 * 4 <= 256 ? KS_Q_MDI : 0) | (cnt * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
+                          (cnt * 2 * 4 <= 192 ? KS_Q_MDI : 0) | (cnt * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
         }
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, hoist, chunk_alias, small ? hb : nullptr,

@@ -189,7 +189,12 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 // Small batches (a lone rotation of a NAF chain, the lockstep chains of a few dot products): the descriptors travel in
 // the KERNEL ARGUMENTS of this first launch -- no host-to-device descriptor copy ahead of the sequence (a ~4 us blit
 // plus its dependency gap on a ~90 us operation) -- and block 0 leaves them in device memory for the launches after it.
-constexpr int KS_SMALL_MAX = 8;
+// 32 descriptors = 1.5 KB of kernel arguments.  (8 until round 3: a batch of 9..32 items then paid the descriptor copy
+// and lost the quarter-row inverse launches -- 57 us at n = 8 against 80 us at n = 12 at L = 2; now 59 us.)
+#ifndef HEFX_SMALL_MAX
+#define HEFX_SMALL_MAX 32
+#endif
+constexpr int KS_SMALL_MAX = HEFX_SMALL_MAX;
 struct KsSmallItems {
     KsItem it[KS_SMALL_MAX];
 };

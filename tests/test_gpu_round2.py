@@ -513,7 +513,7 @@ def test_small_batch_quarter_row_path_bit_exact(knob):
     """The small-batch key switch (quarter-row workgroups with eight coefficients per thread, descriptors in the kernel
     arguments) gives the oracle's bits for rotations, fused rotate+multiply_plain and relinearisation at every ring size it
     is built for (N = 4096 .. 32768: every radix-8 pass / remainder combination of the 8-coefficient cores), top and lower
-    levels, 1..8 items, distinct keys / elements.  Each of the four transform launches picks quarter rows or split-2
+    levels, 1..19 items, distinct keys / elements.  Each of the four transform launches picks quarter rows or split-2
     workgroups on its own (the scratch layouts are shared): forced off, forced on, the engine's own per-launch rule, and the
     two complementary mixes (inverse launches on quarter rows with forward ones on split-2 workgroups, and the reverse)."""
     import subprocess, sys
@@ -538,7 +538,7 @@ for name in ("C2", "C3", "C4", "C5", "toy4096", "toy2048"):
     keys = [o.uniform(k, 2 * (k - 1), 70 + i).reshape(k - 1, 2, k, N) for i in range(3)]
     dkeys = [e.to_device(x) for x in keys]
     for L in sorted({k - 1, max(1, k - 2), 1}):
-        for n in (1, 3, 8):
+        for n in (1, 3, 8) + ((19,) if name in ("C3", "toy4096") else ()):  # 19: descriptors in the kernel arguments up to 32 items
             cts = [o.uniform(L, 2, 100 * L + i) for i in range(n)]
             pts = [o.uniform(L, 1, 200 * L + i)[0] for i in range(n)]
             steps = [(1, -1, 5, 2)[i %% 4] for i in range(n)]

@@ -11,9 +11,10 @@ e = Engine(N, primes)
 o = O.Oracle(N, primes)
 k = len(primes)
 key = e.to_device(o.uniform(k, 2 * (k - 1), 2).reshape(k - 1, 2, k, N))
+NS = tuple(int(x) for x in sys.argv[1].split(",")) if len(sys.argv) > 1 else (1, 2, 4, 8)
 for L in (2, 3, 4, 5, 8):
     row = []
-    for n in (1, 2, 4, 8):
+    for n in NS:
         cts = [e.to_device(o.uniform(L, 2, i)) for i in range(n)]
         outs = e.empty_many(n, (2, L, N))
         for _ in range(5):
