@@ -224,14 +224,18 @@ struct ArithU64T {
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
     static constexpr bool IS_F64 = false;
     __device__ static __forceinline__ bool fast_wide(const Ctx &) { return false; }
-    // RED: 0 none, 1 Barrett (any 64-bit word), 3 one conditional subtraction (x < 2q)
+    // RED: 0 none, 1 Barrett (any 64-bit word), 3 the word is below 2q: one conditional subtraction -- or, when a constant
+    // is subtracted anyway (mod-down: - (P/2 mod q)), no reduction at all: x + (q - sub) < 3q is a valid first-stage
+    // operand (ct_half: < 3q + 4q = 7q < 8q; quarter rows: ct_sel of two such values < 11q < 12q, the 16q core's entry
+    // bound), one addition instead of a conditional and a modular subtraction per word
     template <int RED>
     __device__ static __forceinline__ V input(u64 x, const InMode &m, const Ctx &c, const ModConst &mc)
     {
-        if (RED == 3)
-            x = csubn(x, c.nq);
-        else if (RED)
-            x = barrett64(x, mc.q, mc.r1);
+        if (RED == 3) {
+            if (m.has_sub) return x + (c.q - m.sub);
+            return csubn(x, c.nq);
+        }
+        if (RED) x = barrett64(x, mc.q, mc.r1);
         if (m.has_sub) x = submod(x, m.sub, c.q);
         return x;
     }

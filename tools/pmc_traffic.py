@@ -21,9 +21,15 @@ def fold(d, counter):
 
 
 def main():
-    fdir, wdir, ops, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    fdir, wdir, out = sys.argv[1], sys.argv[2], sys.argv[4]
     cmd = sys.argv[5] if len(sys.argv) > 5 else ""
     fe, wr = fold(fdir, "FETCH_SIZE"), fold(wdir, "WRITE_SIZE")
+    # <ops in the run>: a number, or "per-chunk:<items>" = every ks_ntt_digits dispatch stands for one chunk of that many
+    # items (robust against the number of passes the command makes: timed steps, warm steps, the profiled pass)
+    if sys.argv[3].startswith("per-chunk:"):
+        ops = int(sys.argv[3].split(":")[1]) * max(v[0] for k, v in fe.items() if k.startswith("ks_ntt_digits"))
+    else:
+        ops = int(sys.argv[3])
     rows, tf, tw = [], 0.0, 0.0
     for k in sorted(set(fe) | set(wr)):
         if not k.startswith(("ks_", "rs_")):

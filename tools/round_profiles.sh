@@ -14,7 +14,7 @@ HEFX_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kts 
 P="--steps 2 --warmup 0 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --lt="
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf -o pf -- python3 bench.py $P > /dev/null 2> $out/pf.err
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/pw -o pw -- python3 bench.py $P > /dev/null 2> $out/pw.err
-python tools/pmc_traffic.py $out/pf $out/pw $((3 * 4608)) $out/pmc_traffic.json "python3 bench.py $P (2 timed steps + 1 profiled pass of 4608 ops)" > /dev/null
+python tools/pmc_traffic.py $out/pf $out/pw per-chunk:256 $out/pmc_traffic.json "python3 bench.py $P (2 timed steps, 2 warm steps and 1 profiled pass of 4608 ops = 18 chunks of 256 each)" > /dev/null
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS SQ_ACTIVE_INST_ANY --output-format csv -d $out/sq -o sq -- python3 bench.py $P > /dev/null 2> $out/sq.err
 # keep the merge small: the per-dispatch counter tables are large
 python - $out <<'PY'
