@@ -760,7 +760,15 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
     typename A::V f[16];
     // the first stage is element-wise on records, so for R == 0 it runs on lane-adjacent records (idx_nat; see idx_io)
     // and its results reach the layout the core starts in (idx_out) through LDS
-    auto rec = [&](int r) { return C::R == 0 ? C::idx_nat(t, r) : C::idx_out(t, r); };
+    // ... and for R >= 2 as well, where a lane would walk four or eight consecutive records (64 / 128 bytes) through its
+    // loads: N = 32768 +1.3 % end to end, the two inverse kernels -10 % and -4 % (profiles/r03/ab_inverse_record_order.txt).
+    // R == 1 (N = 16384: two records, 32 bytes per lane) keeps idx_out: the transposition costs what it saves there.
+#ifdef HEFX_INV_NAT  // A/B knob: 1 = for every remainder size, 0 = only where the core's layout demands it
+    constexpr bool NATREC = HEFX_INV_NAT != 0 || C::R == 0;
+#else
+    constexpr bool NATREC = C::R != 1;
+#endif
+    auto rec = [&](int r) { return NATREC ? C::idx_nat(t, r) : C::idx_out(t, r); };
 #pragma unroll
     for (int g = 0; g < NB; ++g) {
         ulonglong2 pr[BS];
@@ -788,6 +796,13 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
         __syncthreads();
 #pragma unroll
         for (int r = 0; r < 16; ++r) f[r] = lf[pr + r];  // phys(16t + r): the words the core's first pass owns
+    } else if constexpr (NATREC) {
+        typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) lf[C::phys(C::idx_nat(t, r))] = f[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) f[r] = lf[C::phys(C::idx_out(t, r))];  // the words the remainder pass rewrites
     }
     ntt_inv_core<LOGN - 1, A>(f, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
 #pragma unroll
