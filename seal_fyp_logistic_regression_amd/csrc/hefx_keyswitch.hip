@@ -1059,6 +1059,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
     if (mf.q != 0.0)
         moddown_finish_body<LOGN, ArithF64>(T, it, L, relin, S, lds, nt.twf, ArithF64::make(mf), mc, b, c, j, t, h);
     else
+        // (the 16q butterfly here: no spill from N = 16384 on, and no gain -- 266 -> 269 us per chunk at C3,
+        // profiles/r03/ab_finish_l16.txt; one of five rows per polynomial is integer-policy)
         moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
     HEFX_STAMP_AT(15);
 }
