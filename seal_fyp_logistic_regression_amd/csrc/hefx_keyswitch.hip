@@ -1066,11 +1066,13 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
 }
 
 // ------------------------------------------------------------------------------------------------
-// SMALL-BATCH path: quarter rows (hefx_ntt8.cuh) -- the same five launches with every row handled by four workgroups
-// of N/32 threads, eight coefficients per thread.  Selected when a chunk cannot fill the chip with split-2 workgroups
-// (a lone rotation of a NAF chain, the eight lockstep chains of the LR gradient, logistic_regression_ckks.cpp:295-300 ->
-// helper.h:472-476): there the caller waits for the latency of one 60-bit transform, which is instruction issue on the
-// one CU that runs it.  Same integers, same bits.
+// SMALL-BATCH path: quarter rows (hefx_ntt8.cuh) -- the same five launches with a row handled by four workgroups of
+// N/32 threads, eight coefficients per thread.  For chunks that cannot fill the chip with split-2 workgroups (a lone
+// rotation of a NAF chain, the eight lockstep chains of the LR gradient, logistic_regression_ckks.cpp:295-300 ->
+// helper.h:472-476): there the caller waits for one launch after the other -- per launch ~1 us of table fetches, ~2 us
+// until the row has arrived, four radix-8 passes of ~1.1 us on a 60-bit row (tools/stamp_timeline.py).  The scratch
+// arrays have one layout, so ks_run decides PER LAUNCH between these kernels and the split-2 ones (KS_Q_* mask): quarter
+// rows only while their grid still gets a CU per workgroup.  Same integers, same bits.
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
 struct QuarterCfg {
