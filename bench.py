@@ -544,6 +544,25 @@ def main():
                     break
                 except Exception:
                     pass
+        # VALU issue: the committed SQ counter pass of this same command gives the VALU wave-instructions per op; with the
+        # engine clock sampled during this run that is cycles of wall time per instruction and SIMD -- against ~5 cycles
+        # of issue cost for this mix (4 for 32-bit ops, 4.75 v_fma_f64, 5.7 v_mad_u64_u32: profiles/r01_valu_issue_rates.txt)
+        issue = None
+        sqf = os.path.join(ROOT, "profiles", "r03_bench_sq_counters.json")
+        if args.set == "C3" and os.path.exists(sqf):
+            try:
+                sq = json.load(open(sqf))
+                per_op = sum(v["SQ_INSTS_VALU"] / (v["launches"] * 256) for v in sq.values())  # 256 items per chunk launch
+                mhz = (board_rec or {}).get("sclk_mhz")
+                issue = {"valu_wave_instr_per_op": per_op,
+                         "source": "profiles/r03_bench_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU of this command)",
+                         "sclk_mhz": mhz}
+                if mhz:
+                    cyc = (dt / total_ops * world) * mhz * 1e6 * SIMDS / per_op
+                    issue["wall_cycles_per_instr_per_simd"] = cyc
+                    issue["frac_of_issue_bound_at_5_cycles"] = 5.0 / cyc
+            except Exception:
+                issue = None
         dom = max(stage_ms, key=stage_ms.get)
         tot = sum(stage_ms.values())
         valu = valu_bound_ops_per_s(N, primes, L)
@@ -610,6 +629,7 @@ def main():
                              f"x (N/2) log2 N butterflies, {VALU_CYC_INT:.0f} / {VALU_CYC_F64:.0f} SIMD cycles per "
                              f"wave-butterfly (profiles/r01_valu_issue_rates.txt), {SIMDS} SIMDs at {CLOCK_HZ / 1e9:.1f} "
                              "GHz; butterflies only (no loads, exchanges, MAC, epilogues)",
+                    "issue": issue,
                 },
             },
             "variants": variants,
