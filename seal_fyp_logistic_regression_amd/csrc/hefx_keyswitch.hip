@@ -41,7 +41,14 @@ struct KsWaves {
 #endif
     // load batches of the first (split) stage: all sixteen coefficient pairs are fetched at once in the 256-VGPR
     // builds of N <= 8192 (a few percent there; at N = 16384 the inverse kernels lose 5-15 % with one batch)
-    static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = FWD <= 2 ? 1 : 2;
+    // (N = 8192 forward: two batches since round 3 -- with the lane-contiguous loader (eo_lane) one batch took the
+    // 256-thread workgroups two registers past 128 and with them the fourth workgroup per CU; two batches + eo_lane:
+    // digit NTTs 94 -> 87 us, mod-down finish 102 -> 98 us per chunk, profiles/r03/ab_c2_eo_lane.txt)
+#ifdef HEFX_NB_FWD
+    static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = HEFX_NB_FWD;
+#else
+    static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = (FWD <= 2 && LOGN < 13) ? 1 : 2;
+#endif
 };
 
 namespace hefx {
@@ -112,13 +119,15 @@ __device__ static __forceinline__ int eo_lane(int t)
     constexpr int T = SC::C::T;
     return ((t & (T / 2 - 1)) << 1) | (t / (T / 2));
 }
-// From N = 16384 on (C3 +2.7 %, C5 +3.3 %: profiles/r03/ab_eo_lane.txt).  At N = 8192 the second index costs the
-// 256-thread workgroups two registers past 128 and with them the fourth workgroup per CU; measured neutral to slightly
-// negative there, so the smaller rings keep column t.
+// From N = 8192 on (C3 +2.7 %, C5 +3.3 %: profiles/r03/ab_eo_lane.txt; C2 +2.5 % together with two load batches, see
+// KsWaves: ab_c2_eo_lane.txt).  The smaller rings keep column t.
 #ifdef HEFX_NO_EO_LANE  // A/B knob (tools/build_variant.sh): column t everywhere
 #define HEFX_EO_LANE(SC, t) (t)
 #else
-#define HEFX_EO_LANE(SC, t) (SC::N >= 16384 ? eo_lane<SC>(t) : (t))
+#ifndef HEFX_EO_LANE_MIN
+#define HEFX_EO_LANE_MIN 8192
+#endif
+#define HEFX_EO_LANE(SC, t) (SC::N >= HEFX_EO_LANE_MIN ? eo_lane<SC>(t) : (t))
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -1644,7 +1653,8 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void rs_fini
     u64 v[16];
     // rounded: subtract (q_l/2 mod q_j) from the reduced remainder, in the row's arithmetic policy
     const InMode mode = {ql > q, T.modsf[L - 1].q == 0.0, rounded != 0, T.halfmod[(size_t)(L - 1) * T.k + j]};
-    const int tl = HEFX_EO_LANE(SC, t);
+    // (the rescale keeps column t at N = 8192: two registers past 128 there, and no second load batch to trade them for)
+    const int tl = SC::N >= 16384 ? HEFX_EO_LANE(SC, t) : t;
     auto ld = [&](int r, u64 &x, u64 &y) {
         const uint32_t e = eo_nat<SC>(tl, r);
         x = dd[e];
