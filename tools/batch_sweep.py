@@ -15,7 +15,8 @@ key32 = lambda tag: hashlib.sha256(f"batch-sweep:{tag}".encode()).digest()
 key = e.sample("uniform", key32("key"), 3, 2 * L, k, 0).view(0, (L, 2, k, N))
 out = {"set": name, "N": N, "L": L, "unit": "rotate_vector(step 1, direct key) + multiply_plain",
        "algorithmic_bytes_per_op": bench.algorithmic_bytes_per_op(N, L), "runs": []}
-for B in (1, 16, 256, 1024, 4608):
+BATCHES = tuple(int(x) for x in sys.argv[2].split(",")) if len(sys.argv) > 2 else (1, 16, 256, 1024, 4608)
+for B in BATCHES:
     ct = e.sample("uniform", key32(f"ct{B}"), 1, 2 * B, L, 0)
     pt = e.sample("uniform", key32(f"pt{B}"), 2, B, L, 0)
     o = e.empty(B, 2, L, N)
