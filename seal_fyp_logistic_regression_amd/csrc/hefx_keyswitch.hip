@@ -109,6 +109,19 @@ __device__ static __forceinline__ uint32_t eo_nat(int t, int r)
     static_assert(SC::C::T % 2 == 0, "split-2 loaders assume an even thread count");
     return (uint32_t)((t & 1) * SC::H + (t >> 1)) + (uint32_t)(SC::C::T / 2) * (uint32_t)r;
 }
+// May the digit transforms hand the key MAC words below 2q instead of canonical ones for target modulus (mc, mf) at level
+// L?  Only the limb policy (MacL: integer-policy prime below 2^60, L <= 8 -- mac_dispatch) has the headroom, and only for
+// L <= 5: its middle column takes xl*kh + xh*kl per digit with xh < 2^31 then, (2^60 + 2^61) * 5 < 2^64; the top column
+// 2^61 * 5; and the folded sum stays below 2 L q^2 < q 2^64, barrett128's domain (10 q < 2^64).
+__device__ __forceinline__ bool mac_takes_lt2q(const ModConst &mc, const ModConstF &mf, int L)
+{
+#ifdef HEFX_NO_LT2Q  // A/B knob (tools/build_variant.sh): canonical operands always
+    return false;
+#else
+    return mf.q == 0.0 && L <= 5 && (mc.q >> 60) == 0;
+#endif
+}
+
 // The coefficient column a thread of a forward split workgroup loads (ntt_fwd_core's t0): the first half of the workgroup
 // takes the even columns, the second half the odd ones, so that eo_nat(eo_lane(t), r) is contiguous over the lanes of a
 // wave -- with t itself neighbouring lanes alternate between the two halves of the row and every 8-byte load is split by
@@ -254,7 +267,9 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
         y = dd[e + SC::H / 2];
     };
     // MAC-operand format: canonical words for the integer-policy moduli, unfinished doubles for the FP64 ones
-    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, T.modsf[m], t, h, tl);
+    const ModConstF mf = T.modsf[m];
+    split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, h, tl,
+                                                 mac_takes_lt2q(mc, mf, L));
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
     // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
@@ -455,7 +470,7 @@ __device__ __forceinline__ void mac_dispatch(const DevTables &T, int m, int L, c
     if (T.modsf[m].q != 0.0)
         f(MacF());
     else if (L <= 8 && (T.mods[m].q >> 60) == 0)
-        f(MacL());
+        f(MacL());  // (for L <= 5 its x operands may be below 2q instead of canonical: mac_takes_lt2q)
     else
         f(MacW());
 }
@@ -1173,7 +1188,7 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     u64 v[8];
     const InMode mode = {qi > mc.q, wide_digit, false, 0};
     const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, quarter_fwd_lane<LOGN>(t)};
-    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, part);
+    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, part, mac_takes_lt2q(mc, mf, L));
     u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
 #pragma unroll
     for (int r = 0; r < 8; r += 2) gst16(xd + C::idx_out(t, r), make_ulonglong2(v[r], v[r + 1]));
