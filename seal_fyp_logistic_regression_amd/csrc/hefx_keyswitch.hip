@@ -109,16 +109,20 @@ __device__ static __forceinline__ uint32_t eo_nat(int t, int r)
     static_assert(SC::C::T % 2 == 0, "split-2 loaders assume an even thread count");
     return (uint32_t)((t & 1) * SC::H + (t >> 1)) + (uint32_t)(SC::C::T / 2) * (uint32_t)r;
 }
-// May the digit transforms hand the key MAC words below 2q instead of canonical ones for target modulus (mc, mf) at level
-// L?  Only the limb policy (MacL: integer-policy prime below 2^60, L <= 8 -- mac_dispatch) has the headroom, and only for
-// L <= 5: its middle column takes xl*kh + xh*kl per digit with xh < 2^31 then, (2^60 + 2^61) * 5 < 2^64; the top column
-// 2^61 * 5; and the folded sum stays below 2 L q^2 < q 2^64, barrett128's domain (10 q < 2^64).
-__device__ __forceinline__ bool mac_takes_lt2q(const ModConst &mc, const ModConstF &mf, int L)
+// How lazy may the words be that the digit transforms hand the key MAC for target modulus (mc, mf) at level L: 0 canonical,
+// 1 below 2q, 2 below 4q?  Only the limb policy (MacL: integer-policy prime below 2^60, L <= 8 -- mac_dispatch) has
+// headroom.  Its middle column takes xl*kh + xh*kl per digit (xl, kl, kh < 2^30):
+//   x < 2q < 2^61: xh < 2^31, (2^60 + 2^61) * L < 2^64 for L <= 5; top column 2^61 * 5; folded sum < 2 L q^2 < q 2^64
+//                  (barrett128's domain: 10 q < 2^64)
+//   x < 4q < 2^62: xh < 2^32 (still one 32-bit limb), (2^60 + 2^62) * L < 2^64 for L <= 3; top column 2^62 * 3;
+//                  folded sum < 4 L q^2 = 12 q^2 < q 2^64
+__device__ __forceinline__ int mac_x_slack(const ModConst &mc, const ModConstF &mf, int L)
 {
 #ifdef HEFX_NO_LT2Q  // A/B knob (tools/build_variant.sh): canonical operands always
-    return false;
+    return 0;
 #else
-    return mf.q == 0.0 && L <= 5 && (mc.q >> 60) == 0;
+    if (mf.q != 0.0 || (mc.q >> 60) != 0) return 0;
+    return L <= 3 ? 2 : (L <= 5 ? 1 : 0);
 #endif
 }
 
@@ -269,7 +273,7 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     // MAC-operand format: canonical words for the integer-policy moduli, unfinished doubles for the FP64 ones
     const ModConstF mf = T.modsf[m];
     split_fwd<LOGN, KsWaves<LOGN>::NB_FWD, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, h, tl,
-                                                 mac_takes_lt2q(mc, mf, L));
+                                                 mac_x_slack(mc, mf, L));
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
     // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
@@ -470,7 +474,7 @@ __device__ __forceinline__ void mac_dispatch(const DevTables &T, int m, int L, c
     if (T.modsf[m].q != 0.0)
         f(MacF());
     else if (L <= 8 && (T.mods[m].q >> 60) == 0)
-        f(MacL());  // (for L <= 5 its x operands may be below 2q instead of canonical: mac_takes_lt2q)
+        f(MacL());  // (for L <= 5 / L <= 3 its x operands may be below 2q / 4q instead of canonical: mac_x_slack)
     else
         f(MacW());
 }
@@ -1188,7 +1192,7 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     u64 v[8];
     const InMode mode = {qi > mc.q, wide_digit, false, 0};
     const EoQuadLoader<LOGN> ld{S.d + ((size_t)b * L + i) * QC::N, quarter_fwd_lane<LOGN>(t)};
-    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, part, mac_takes_lt2q(mc, mf, L));
+    quarter_fwd<LOGN, true>(v, ld, mode, lds, ntt_tables(T, m), mc, mf, t, part, mac_x_slack(mc, mf, L));
     u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
 #pragma unroll
     for (int r = 0; r < 8; r += 2) gst16(xd + C::idx_out(t, r), make_ulonglong2(v[r], v[r + 1]));

@@ -246,12 +246,14 @@ struct ArithU64T {
     }
     // what the key MAC reads from scratch for a row of this policy (hefx_keyswitch.hip, MacL / MacW): canonical words
     __device__ static __forceinline__ u64 mac_operand(V x, const Ctx &c) { return fwd_finish(x, c); }
-    // ... or words below 2q where the MAC's policy has the headroom (mac_takes_lt2q, hefx_keyswitch.hip): one conditional
-    // subtraction less per word
-    __device__ static __forceinline__ u64 mac_operand_lt2q(V x, const Ctx &c)
+    // ... or words below 2q / below 4q where the MAC's policy has the headroom (mac_x_slack, hefx_keyswitch.hip): one or two
+    // conditional subtractions less per word
+    template <int SLACK>  // 1: < 2q, 2: < 4q
+    __device__ static __forceinline__ u64 mac_operand_lazy(V x, const Ctx &c)
     {
         if (L16) x = csubn(x, c.n8q);
-        return csubn(csubn(x, c.n4q), c.n2q);
+        x = csubn(x, c.n4q);
+        return SLACK >= 2 ? x : csubn(x, c.n2q);
     }
     // key-switch mod-down epilogue (App. A.8) from the UNFINISHED transform value f (< 8q):
     // ((acc - f) * P^-1 + sadd) [* pt] mod q, canonical
@@ -403,7 +405,11 @@ struct ArithF64 {
     // what the key MAC reads from scratch for a row of this policy (MacF): the UNFINISHED value itself, as a double --
     // an integer with |x| < 2^41 + (LOGN+1) * 0.52q < 2^45, a valid left operand of mm(); no canonicalisation here
     __device__ static __forceinline__ u64 mac_operand(V x, const Ctx &) { return (u64)__double_as_longlong(x); }
-    __device__ static __forceinline__ u64 mac_operand_lt2q(V x, const Ctx &c) { return mac_operand(x, c); }
+    template <int SLACK>
+    __device__ static __forceinline__ u64 mac_operand_lazy(V x, const Ctx &c)
+    {
+        return mac_operand(x, c);
+    }
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const double2 &pinv)
     {
@@ -728,13 +734,16 @@ __device__ __forceinline__ void split_fwd_raw(typename A::V (&f)[16], const LD &
 template <int LOGN, class A, class LD, int NB = 2, bool MACOP = false>
 __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const InMode &mode, const ModConst &mc,
                                             u64 *lds, const typename A::TW *__restrict__ tw,
-                                            const typename A::Ctx &cx, int t, int h, int t0 = -1, bool mac_lt2q = false)
+                                            const typename A::Ctx &cx, int t, int h, int t0 = -1, int mac_slack = 0)
 {
     typename A::V f[16];
     split_fwd_raw<LOGN, A, LD, NB>(f, ld, mode, mc, lds, tw, cx, t, h, NoHook(), t0);
-    if (MACOP && !A::IS_F64 && mac_lt2q) {  // workgroup-uniform: one branch around the sixteen words
+    if (MACOP && !A::IS_F64 && mac_slack == 1) {  // workgroup-uniform: one branch around the sixteen words
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = A::mac_operand_lt2q(f[r], cx);
+        for (int r = 0; r < 16; ++r) v[r] = A::template mac_operand_lazy<1>(f[r], cx);
+    } else if (MACOP && !A::IS_F64 && mac_slack >= 2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = A::template mac_operand_lazy<2>(f[r], cx);
     } else {
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = MACOP ? A::mac_operand(f[r], cx) : A::fwd_finish(f[r], cx);
@@ -744,14 +753,14 @@ __device__ __forceinline__ void split_fwd_a(u64 (&v)[16], const LD &ld, const In
 template <int LOGN, int NB = 2, bool MACOP = false, class LD>
 __device__ __forceinline__ void split_fwd(u64 (&v)[16], const LD &ld, const InMode &mode, u64 *lds,
                                           const NttTables &nt, const ModConst &mc, const ModConstF &mf, int t, int h,
-                                          int t0 = -1, bool mac_lt2q = false)
+                                          int t0 = -1, int mac_slack = 0)
 {
     if (mf.q != 0.0)
         split_fwd_a<LOGN, ArithF64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.twf, ArithF64::make(mf), t, h, t0);
     else if constexpr (MACOP)  // the digit transforms of the key switch: the lighter L16 butterfly where the prime admits it
         fwd_int_dispatch(mc, [&](auto pol) {
             using A = decltype(pol);
-            split_fwd_a<LOGN, A, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, A::make(mc), t, h, t0, mac_lt2q);
+            split_fwd_a<LOGN, A, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, A::make(mc), t, h, t0, mac_slack);
         });
     else
         split_fwd_a<LOGN, ArithU64, LD, NB, MACOP>(v, ld, mode, mc, lds, nt.tw, ArithU64::make(mc), t, h, t0);

@@ -334,7 +334,7 @@ __device__ __forceinline__ void quarter_fwd_raw(typename A::V (&f)[8], const LD 
 
 template <int LOGN, bool MACOP = false, class LD>
 __device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InMode &mode, u64 *lds, const NttTables &nt,
-                                            const ModConst &mc, const ModConstF &mf, int t, int qd, bool mac_lt2q = false)
+                                            const ModConst &mc, const ModConstF &mf, int t, int qd, int mac_slack = 0)
 {
     if (mf.q != 0.0) {
         const ArithF64::Ctx cx = ArithF64::make(mf);
@@ -347,9 +347,12 @@ __device__ __forceinline__ void quarter_fwd(u64 (&v)[8], const LD &ld, const InM
             using A = decltype(pol);
             const typename A::Ctx cx = A::make(mc);
             quarter_fwd_raw<LOGN, A, LD>(v, ld, mode, mc, lds, nt.tw, cx, t, qd);
-            if (MACOP && mac_lt2q) {
+            if (MACOP && mac_slack == 1) {
 #pragma unroll
-                for (int r = 0; r < 8; ++r) v[r] = A::mac_operand_lt2q(v[r], cx);
+                for (int r = 0; r < 8; ++r) v[r] = A::template mac_operand_lazy<1>(v[r], cx);
+            } else if (MACOP && mac_slack >= 2) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) v[r] = A::template mac_operand_lazy<2>(v[r], cx);
             } else {
 #pragma unroll
                 for (int r = 0; r < 8; ++r) v[r] = MACOP ? A::mac_operand(v[r], cx) : A::fwd_finish(v[r], cx);
