@@ -336,12 +336,16 @@ struct MacW {
         mac128(a1xl, a1xh, r1.x, dg.x);
         mac128(a1yl, a1yh, r1.y, dg.y);
     }
+    // LT2Q: words below 2q instead of canonical ones -- what the regular MAC leaves in the accumulator scratch: both of
+    // its readers take them as they are (the inverse transform of the special-prime rows: first stage on words below 2q;
+    // the mod-down epilogue: acc + 4q - f < 6q into a Shoup product), one conditional subtraction less per word
+    template <bool LT2Q = false>
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
     {
-        r0.x = barrett128(a0xl, a0xh, c.mc);
-        r0.y = barrett128(a0yl, a0yh, c.mc);
-        r1.x = barrett128(a1xl, a1xh, c.mc);
-        r1.y = barrett128(a1yl, a1yh, c.mc);
+        r0.x = LT2Q ? barrett128_lt2q(a0xl, a0xh, c.mc) : barrett128(a0xl, a0xh, c.mc);
+        r0.y = LT2Q ? barrett128_lt2q(a0yl, a0yh, c.mc) : barrett128(a0yl, a0yh, c.mc);
+        r1.x = LT2Q ? barrett128_lt2q(a1xl, a1xh, c.mc) : barrett128(a1xl, a1xh, c.mc);
+        r1.y = LT2Q ? barrett128_lt2q(a1yl, a1yh, c.mc) : barrett128(a1yl, a1yh, c.mc);
     }
 };
 
@@ -389,6 +393,7 @@ struct MacL {
         mad(c[2], lo30(r1.x), hi30(r1.x), dxl, dxh);
         mad(c[3], lo30(r1.y), hi30(r1.y), dyl, dyh);
     }
+    template <bool LT2Q>
     __device__ static __forceinline__ u64 fold(const u64 (&col)[3], const ModConst &mc)
     {
         u64 lo = col[0], hi = 0, t = col[1] << 30;
@@ -397,14 +402,15 @@ struct MacL {
         t = col[2] << 60;
         lo += t;
         hi += (col[2] >> 4) + (lo < t);
-        return barrett128(lo, hi, mc);
+        return LT2Q ? barrett128_lt2q(lo, hi, mc) : barrett128(lo, hi, mc);
     }
+    template <bool LT2Q = false>
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &cx) const
     {
-        r0.x = fold(c[0], cx.mc);
-        r0.y = fold(c[1], cx.mc);
-        r1.x = fold(c[2], cx.mc);
-        r1.y = fold(c[3], cx.mc);
+        r0.x = fold<LT2Q>(c[0], cx.mc);
+        r0.y = fold<LT2Q>(c[1], cx.mc);
+        r1.x = fold<LT2Q>(c[2], cx.mc);
+        r1.y = fold<LT2Q>(c[3], cx.mc);
     }
 };
 
@@ -442,6 +448,7 @@ struct MacF {
         a1x += ArithF64::mm(in.a1x, dx, c);
         a1y += ArithF64::mm(in.a1y, dy, c);
     }
+    template <bool LT2Q = false>  // FP64 rows are stored canonical either way
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
     {
         r0.x = ArithF64::canon(a0x, c);
@@ -565,7 +572,11 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         ulonglong2 r0, r1;
+#ifdef HEFX_NO_LT2Q
         A[e].result(r0, r1, cx);
+#else
+        A[e].template result<true>(r0, r1, cx);
+#endif
         mac_store<STREAM>(acc0[e], acc1[e], w, r0, r1);
     }
 }

@@ -140,8 +140,8 @@ __device__ __forceinline__ u64 negmod(u64 a, u64 q) { return a ? q - a : 0; }
 // any 64-bit x -> [0,q); r1 = floor(2^64/q)
 __device__ __forceinline__ u64 barrett64(u64 x, u64 q, u64 r1) { return csub(x - mulhi64(x, r1) * q, q); }
 
-// (hi:lo) < q*2^64 -> [0,q)
-__device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, const ModConst &m)
+// (hi:lo) < q*2^64 -> [0,2q): the quotient estimate is short by at most one
+__device__ __forceinline__ u64 barrett128_lt2q(u64 lo, u64 hi, const ModConst &m)
 {
     u64 carry = mulhi64(lo, m.r0);
     u64 t_lo = lo * m.r1, t_hi = mulhi64(lo, m.r1);
@@ -151,8 +151,10 @@ __device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, const ModConst &m)
     u64 s = tmp1 + u_lo;
     u64 carry2 = u_hi + (s < u_lo);
     u64 qhat = hi * m.r1 + tmp3 + carry2;
-    return csub(lo - qhat * m.q, m.q);
+    return lo - qhat * m.q;
 }
+// (hi:lo) < q*2^64 -> [0,q)
+__device__ __forceinline__ u64 barrett128(u64 lo, u64 hi, const ModConst &m) { return csub(barrett128_lt2q(lo, hi, m), m.q); }
 
 __device__ __forceinline__ u64 mulmod(u64 a, u64 b, const ModConst &m)
 {

@@ -201,11 +201,12 @@ struct ArithU64T {
         x = shoup_lazy(s, c.ninv, c.ninv_s, c.nq);
         y = shoup_lazy(d, c.ilw, c.ilw_s, c.nq);
     }
-    // first stage of a split inverse transform on a canonical pair (a0,a1): sum (h=0) or twiddled difference
+    // first stage of a split inverse transform on a pair (a0,a1) of words below 2q: sum (h=0, < 4q) or twiddled difference
     __device__ static __forceinline__ V gs_half_sum(V a0, V a1, const Ctx &) { return a0 + a1; }
+    // (a0, a1 below 2q: the key MAC's integer-policy results are not canonical, hefx_keyswitch.hip MacW / MacL result<true>)
     __device__ static __forceinline__ V gs_half_diff(V a0, V a1, const TW &w, const Ctx &c)
     {
-        return shoup_lazy4(a0 + c.q - a1, w.x, w.y, c.nq);
+        return shoup_lazy4(a0 + c.two_q - a1, w.x, w.y, c.nq);
     }
     template <int NV>
     __device__ static __forceinline__ void inv_pass_begin(V (&)[NV], const Ctx &) {}
@@ -261,7 +262,7 @@ struct ArithU64T {
                                                   const ulonglong2 &pinv, const ModConst &mc)
     {
         if (L16) f = csubn(f, c.n8q);                    // < 16q -> < 8q
-        u64 z = acc + c.four_q - csubn(f, c.n4q);      // < 5q (no 9q intermediate: primes may reach 2^61)
+        u64 z = acc + c.four_q - csubn(f, c.n4q);      // acc < 2q (MAC result<true>): < 6q (no 9q intermediate: primes may reach 2^61)
         z = shoup_lazy(z, pinv.x, pinv.y, c.nq) + sadd;   // < 3q
         if (has_pt) return mulmod(z, pt, mc);            // product < 3q*q < q*2^64: Barrett128 gives [0,q)
         return csubn(csubn(z, c.n2q), c.nq);
