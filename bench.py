@@ -411,6 +411,10 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+    # test hook (tests/test_gpu_round4.py): this rank dies right after the rendezvous, before the first barrier -- the
+    # launcher must then end its blocked peers and report a non-zero exit code instead of hanging
+    if os.environ.get("HEFX_BENCH_FAIL_RANK") == str(rank):
+        os._exit(7)
 
     from seal_fyp_logistic_regression_amd import Engine
 

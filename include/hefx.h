@@ -79,6 +79,13 @@ int hefx_copy(hefx_context *ctx, void *d_dst, const void *d_src, size_t bytes, v
  * and bring the results together (include/seal/seal.h, SEAL_SHIM_DEVICES). */
 int hefx_copy_peer(hefx_context *dst_ctx, void *d_dst, hefx_context *src_ctx, const void *d_src, size_t bytes,
                    void *stream);
+/* the same copy submitted on `stream` of the DESTINATION context's device (null: its default stream): ordered after the
+ * destination context's earlier work -- in particular after whatever still uses a recycled destination block
+ * (hefx_malloc's contract above) -- and NOT after the source's: the caller makes the source bytes complete first
+ * (hefx_stream_sync on the source context, or an event) and keeps the source block alive until the copy has run.
+ * This is the direction results travel home in (include/seal/seal.h flush_multi). */
+int hefx_copy_peer_to(hefx_context *dst_ctx, void *d_dst, hefx_context *src_ctx, const void *d_src, size_t bytes,
+                      void *dst_stream);
 /* the HIP device a context lives on */
 int hefx_context_device(const hefx_context *ctx);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
@@ -150,9 +157,11 @@ int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_
                       const uint64_t *d_key, uint64_t *d_ct_out, void *stream);
 /* n independent (ciphertext, element, key) triples in one launch sequence.  "Independent" is meant: no item may read
  * another item's output (an item's own input and output may be the same buffer); the engine processes the items in an
- * order of its choosing (grouped by key, so that neighbours share their key loads).  A batch that breaks the rule --
- * d_ct_in[j] == d_ct_out[i] for i != j, or two items with the same output -- is refused with HEFX_ERR_INVALID before
- * anything is submitted. */
+ * order of its choosing (grouped by key, so that neighbours share their key loads).  A batch that breaks the rule is
+ * refused with HEFX_ERR_INVALID before anything is submitted; the check is on byte ranges, so views into one allocation
+ * are covered: two outputs that overlap, an input (or, in hefx_rotate_multiply_plain_batch, a plaintext) that overlaps
+ * another item's output, an input that overlaps its own output other than exactly (d_ct_in[i] == d_ct_out[i], the
+ * in-place rotation).  The *_hoisted entry points are stricter: their one shared source may be no item's output. */
 int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                             const uint32_t *galois_elts, const uint64_t *const *d_keys,
                             uint64_t *const *d_ct_out, void *stream);

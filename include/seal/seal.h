@@ -162,8 +162,26 @@ struct Engine {
         std::weak_ptr<Buf> owner;  // the home buffer; a recycled address with another owner is a miss
         std::uint64_t *p;
         std::size_t words;
+        std::uint64_t used;        // submission counter of the last use (least recently used replicas go first)
     };
     std::vector<std::map<const std::uint64_t *, Replica>> replicas;  // per device > 0: home pointer -> copy
+    std::vector<std::size_t> replica_bytes;                          // per device: bytes held by its replicas
+    std::size_t replica_budget = (std::size_t)16384 << 20;           // per device (SEAL_SHIM_REPLICA_MB)
+    std::uint64_t submission = 0;
+    // frees replicas of device d, least recently used first, until `need` more bytes fit the budget (or, with
+    // everything = true, all that this submission does not use); returns the bytes released
+    inline std::size_t evict_replicas(int d, std::size_t need, bool everything);
+    ~Engine()
+    {
+        for (std::size_t d = 1; d < dev_ctx.size(); ++d) {
+            if (!dev_ctx[d]) continue;
+            (void)hefx_stream_sync(dev_ctx[d], nullptr);
+            if (d < replicas.size())
+                for (auto &r : replicas[d]) (void)hefx_free(dev_ctx[d], r.second.p);
+            hefx_context_destroy(dev_ctx[d]);
+        }
+        // the home context outlives the payload buffers that still point at it (process-lifetime registry): not destroyed here
+    }
     inline hefx_context *device_context(int d);
     inline void flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
                             int max_depth);
@@ -259,6 +277,7 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
         check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "round" ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR));
     if (const char *m = std::getenv("SEAL_SHIM_PENDING_MB")) e->pend_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
+    if (const char *m = std::getenv("SEAL_SHIM_REPLICA_MB")) e->replica_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *st = std::getenv("SEAL_SHIM_STATS")) {
         if (std::atoi(st)) {
             static std::vector<std::shared_ptr<Engine>> *watched = new std::vector<std::shared_ptr<Engine>>();
@@ -469,10 +488,12 @@ inline hefx_context *Engine::device_context(int d)
         dev_ctx.assign((std::size_t)ndev, nullptr);
         dev_ctx[0] = ctx_raw;
         replicas.resize((std::size_t)ndev);
+        replica_bytes.assign((std::size_t)ndev, 0);
     }
     if ((int)dev_ctx.size() < ndev) {  // ndev was raised after the first submission (tests)
         dev_ctx.resize((std::size_t)ndev, nullptr);
         replicas.resize((std::size_t)ndev);
+        replica_bytes.resize((std::size_t)ndev, 0);
     }
     if (!dev_ctx[d]) {
         const int have = std::max(1, hefx_device_count());
@@ -483,6 +504,23 @@ inline hefx_context *Engine::device_context(int d)
         dev_ctx[d] = cx;
     }
     return dev_ctx[d];
+}
+
+inline std::size_t Engine::evict_replicas(int d, std::size_t need, bool everything)
+{
+    auto &rep = replicas[d];
+    std::size_t freed = 0;
+    while (!rep.empty() && (everything || replica_bytes[d] + need > replica_budget)) {
+        auto victim = rep.end();
+        for (auto it = rep.begin(); it != rep.end(); ++it)
+            if (it->second.used != submission && (victim == rep.end() || it->second.used < victim->second.used)) victim = it;
+        if (victim == rep.end()) break;  // everything left is in use by the submission being prepared
+        (void)hefx_free(dev_ctx[d], victim->second.p);
+        freed += victim->second.words * 8;
+        replica_bytes[d] -= victim->second.words * 8;
+        rep.erase(victim);
+    }
+    return freed;
 }
 
 inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
@@ -545,7 +583,19 @@ inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &f
         }
     } cleanup{this, tmp, dev_of};
     (void)device_context(0);
+    ++submission;
     bool copied_in = false;
+    // a device that cannot hold a sub-graph's buffers (its results, the replicas of its external inputs) hands its whole
+    // share back to the home device, where every input already lives: the submission runs, only less spread out
+    auto give_back = [&](int d) {
+        for (int i : share[d]) {
+            if (tmp[i]) (void)hefx_free(dev_ctx[d], tmp[i]);
+            tmp[i] = nullptr;
+            dev_of[i] = 0;
+            share[0].push_back(i);
+        }
+        share[d].clear();
+    };
     for (int d = 1; d < ndev; ++d) {
         if (share[d].empty()) continue;
         hefx_context *cx = device_context(d);
@@ -553,31 +603,50 @@ inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &f
         for (auto it = rep.begin(); it != rep.end();) {  // replicas whose home buffer is gone
             if (it->second.owner.expired()) {
                 (void)hefx_free(cx, it->second.p);
+                replica_bytes[d] -= it->second.words * 8;
                 it = rep.erase(it);
             } else
                 ++it;
         }
-        for (int i : share[d]) {
+        auto dev_alloc = [&](std::size_t bytes, bool is_replica) -> std::uint64_t * {
+            if (is_replica) (void)evict_replicas(d, bytes, false);  // stay inside SEAL_SHIM_REPLICA_MB per device
             void *p_ = nullptr;
-            const int rc = hefx_malloc(cx, K[i].dst->words * 8, &p_);
-            if (rc != HEFX_OK) raise(rc);
-            tmp[i] = static_cast<std::uint64_t *>(p_);
+            if (hefx_malloc(cx, bytes, &p_) == HEFX_OK) return static_cast<std::uint64_t *>(p_);
+            (void)hefx_stream_sync(cx, nullptr);
+            if (evict_replicas(d, 0, true) && hefx_malloc(cx, bytes, &p_) == HEFX_OK) return static_cast<std::uint64_t *>(p_);
+            return nullptr;
+        };
+        bool fits = true;
+        for (int i : share[d]) {
+            if (!(tmp[i] = dev_alloc(K[i].dst->words * 8, false))) {
+                fits = false;
+                break;
+            }
             for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
                 if (!*inp || producer.count((*inp)->p)) continue;
                 auto hit = rep.find((*inp)->p);
-                if (hit != rep.end() && hit->second.owner.lock().get() == inp->get()) continue;
+                if (hit != rep.end() && hit->second.owner.lock().get() == inp->get()) {
+                    hit->second.used = submission;
+                    continue;
+                }
                 if (hit != rep.end()) {
                     (void)hefx_free(cx, hit->second.p);
+                    replica_bytes[d] -= hit->second.words * 8;
                     rep.erase(hit);
                 }
-                void *r_ = nullptr;
-                const int rc2 = hefx_malloc(cx, (*inp)->words * 8, &r_);
-                if (rc2 != HEFX_OK) raise(rc2);
+                std::uint64_t *r_ = dev_alloc((*inp)->words * 8, true);
+                if (!r_) {
+                    fits = false;
+                    break;
+                }
                 check(hefx_copy_peer(cx, r_, ctx_raw, (*inp)->p, (*inp)->words * 8, nullptr));  // on the home stream
-                rep[(*inp)->p] = Replica{*inp, static_cast<std::uint64_t *>(r_), (*inp)->words};
+                rep[(*inp)->p] = Replica{*inp, r_, (*inp)->words, submission};
+                replica_bytes[d] += (*inp)->words * 8;
                 copied_in = true;
             }
+            if (!fits) break;
         }
+        if (!fits) give_back(d);
     }
     // the replicas were copied on the home device's stream, behind whatever produced them
     if (copied_in) check(hefx_stream_sync(ctx_raw, nullptr));
@@ -601,17 +670,23 @@ inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &f
                              },
                              [&](int i) { return tmp[i]; });
         }
-    // results that are visible outside the graph go home (on the producing device's stream), then the host waits for
-    // the other devices: the home device's later work must find them complete
+    // Results that are visible outside the graph go home.  The copy is submitted on the HOME device's stream, after the
+    // host has seen the producing device finish: a home buffer comes from the pooled allocator, which hands out blocks
+    // whose previous owner's work may still be queued on the home stream (hefx_malloc's contract: same-stream order
+    // only) -- a copy issued on the producer's stream would race with it on a real second GPU.  The home
+    // stream is then waited for once, because the producers' scratch results are recycled when this function returns.
+    bool copied_back = false;
     for (int d = 1; d < ndev; ++d) {
         if (share[d].empty()) continue;
+        check(hefx_stream_sync(dev_ctx[d], nullptr));
         for (int i : share[d]) {
             if (fused_rot[i]) continue;  // the rotation inside a fused product was never written
             if (K[i].dst.use_count() - 1 - inner[i] <= 0) continue;
-            check(hefx_copy_peer(ctx_raw, K[i].dst->p, dev_ctx[d], tmp[i], K[i].dst->words * 8, nullptr));
+            check(hefx_copy_peer_to(ctx_raw, K[i].dst->p, dev_ctx[d], tmp[i], K[i].dst->words * 8, nullptr));
+            copied_back = true;
         }
-        check(hefx_stream_sync(dev_ctx[d], nullptr));
     }
+    if (copied_back) check(hefx_stream_sync(ctx_raw, nullptr));
 }
 
 inline BufPtr upload(const std::shared_ptr<Engine> &e, const std::vector<std::uint64_t> &h)

@@ -7,8 +7,9 @@ import subprocess
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 SO = os.path.join(HERE, "libhefx.so")
-SOURCES = ["hefx_kernels.hip", "hefx_keyswitch.hip", "hefx_encode.hip", "hefx_sample.hip", "hefx_capi.cpp"]
-DEPS = SOURCES + ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cuh", "../../include/hefx.h"]  # a change in any of them rebuilds
+SOURCES = ["hefx_keyswitch.hip", "hefx_kernels.hip", "hefx_encode.hip", "hefx_sample.hip", "hefx_capi.cpp"]  # slowest first
+HEADERS = ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cuh", "../../include/hefx.h"]
+DEPS = SOURCES + HEADERS  # a change in any of them rebuilds the library (a header: every object; a source: its object)
 
 
 def hipcc() -> str:
@@ -28,9 +29,13 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not needs_build():
         return SO
-    objs = []
+    objs, jobs = [], []
+    hdr_t = max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
     for src in SOURCES:
         obj = os.path.join(CSRC, os.path.splitext(src)[0] + ".o")
+        objs.append(obj)
+        if not force and os.path.exists(obj) and os.path.getmtime(obj) > max(hdr_t, os.path.getmtime(os.path.join(CSRC, src))):
+            continue  # this object is newer than its source and every header
         # -pragma-unroll-threshold: the transforms are written as fully unrolled loops over register arrays; the inline
         # asm statements of hefx_modarith.cuh count as large in the unroller's size estimate and push the inverse
         # transforms past the default threshold (loops left rolled -> the register arrays go to scratch memory)
@@ -38,8 +43,10 @@ def build(force: bool = False, verbose: bool = False) -> str:
                "-mllvm", "-pragma-unroll-threshold=1048576", "-x", "hip", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
-        subprocess.check_call(cmd)
-        objs.append(obj)
+        jobs.append((src, subprocess.Popen(cmd)))  # the five translation units compile side by side
+    for src, p in jobs:
+        if p.wait() != 0:
+            raise subprocess.CalledProcessError(p.returncode, f"hipcc {src}")
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd))

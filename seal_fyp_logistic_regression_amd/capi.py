@@ -46,6 +46,7 @@ _SIGS = {
     "hefx_download": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "hefx_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "hefx_copy_peer": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "hefx_copy_peer_to": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "hefx_context_device": (_i, [_vp]),
     "hefx_memset_zero": (_i, [_vp, _vp, _sz, _vp]),
     "hefx_stream_sync": (_i, [_vp, _vp]),

@@ -589,6 +589,18 @@ extern "C" int hefx_copy_peer(hefx_context *dst, void *d_dst, hefx_context *src,
         HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, (hipStream_t)stream));
     return HEFX_OK;
 }
+extern "C" int hefx_copy_peer_to(hefx_context *dst, void *d_dst, hefx_context *src, const void *d_src, size_t bytes,
+                                 void *dst_stream)
+{
+    if (!src) return fail(HEFX_ERR_INVALID, "null source context");
+    CTXCHK(dst);  // the copy is submitted on the destination device
+    if (!d_dst || !d_src) return fail(HEFX_ERR_INVALID, "null pointer");
+    if (dst->device == src->device)
+        HIPCHK(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)dst_stream));
+    else
+        HIPCHK(hipMemcpyPeerAsync(d_dst, dst->device, d_src, src->device, bytes, (hipStream_t)dst_stream));
+    return HEFX_OK;
+}
 extern "C" int hefx_context_device(const hefx_context *c) { return c ? c->device : -1; }
 extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
 {
@@ -976,20 +988,38 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
     }
     // Items run in key-grouped order on several internal streams, so no item may read another item's output: a
-    // dependent chain handed over as ONE batch (ct_out[i] == ct_in[j], i != j) would silently give wrong bits.  Refused
-    // here, before anything is submitted (O(n) on the host).  An item's own in-place rotation (i == j) is fine, and so
-    // are items that share a source.
-    if (n > 1) {
-        std::unordered_map<const void *, int> outs;
-        outs.reserve((size_t)n * 2);
-        for (int i = 0; i < n; ++i) {
-            auto ins = outs.emplace((const void *)ct_out[i], i);
-            if (!ins.second) return fail(HEFX_ERR_INVALID, "two items of a key-switch batch write the same output");
-        }
+    // dependent chain handed over as ONE batch would silently give wrong bits.  Refused here, before anything is
+    // submitted, on BYTE RANGES (callers hand out views of one allocation: big.view(...) slices): no two outputs may
+    // overlap, and no input or plaintext may overlap another item's output -- nor its own, except the exact in-place
+    // rotation c_in == c_out, which the kernels serve from a scratch copy.  O(n log n) on the host.
+    if (n > 1 || (pts && n == 1)) {
+        const size_t row = (size_t)c->n * sizeof(u64);
+        const size_t out_b = 2 * (size_t)L * row, in_b = (relin ? 3 : 2) * (size_t)L * row, pt_b = (size_t)L * row;
+        std::vector<std::pair<uintptr_t, int>> outs((size_t)n);
+        for (int i = 0; i < n; ++i) outs[(size_t)i] = {(uintptr_t)ct_out[i], i};
+        std::sort(outs.begin(), outs.end());
+        for (int i = 1; i < n; ++i)
+            if (outs[(size_t)i - 1].first + out_b > outs[(size_t)i].first)
+                return fail(HEFX_ERR_INVALID, "two items of a key-switch batch write overlapping outputs");
+        // the output (if any) whose range meets [p, p + bytes): outputs are disjoint, so at most two candidates
+        auto hits = [&](const void *p, size_t bytes, int self, bool inplace_ok) -> bool {
+            const uintptr_t a = (uintptr_t)p;
+            auto it = std::upper_bound(outs.begin(), outs.end(), std::make_pair(a, n));
+            for (int step = 0; step < 2; ++step) {
+                if (step == 0) {
+                    if (it == outs.begin()) continue;
+                    const auto &o = *(it - 1);  // starts at or before a
+                    if (o.first + out_b > a && !(inplace_ok && o.second == self && o.first == a)) return true;
+                } else if (it != outs.end() && it->first < a + bytes)  // starts inside the range
+                    return true;
+            }
+            return false;
+        };
         for (int j = 0; j < n; ++j) {
-            auto it = outs.find((const void *)ct_in[j]);
-            if (it != outs.end() && it->second != j)
-                return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: one item's input is another item's output");
+            if (hits(ct_in[j], in_b, j, !relin))
+                return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: one item's input overlaps an item's output");
+            if (pts && pts[j] && hits(pts[j], pt_b, j, false))
+                return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: a plaintext overlaps an item's output");
         }
     }
     // The items of a batch are independent, so they are PROCESSED grouped by key (stable order inside a group): items

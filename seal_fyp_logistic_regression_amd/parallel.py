@@ -57,22 +57,59 @@ class _DeviceWords:
                                          "strides": None}
 
 
-def _engine_comm_ready(ev: Evaluator, group, world: int) -> bool:
-    eng = ev.be.engine
-    if eng.comm_world == world:
-        return True
-    if ENGINE_COMM == "off" or eng.comm_world:
-        return False
+_comm_decisions = {}  # (id(group), world) -> bool: the collective outcome of the handshake below, equal on every rank
+
+
+def _all_true(flag: bool, group, backend: str) -> bool:
+    """logical AND of `flag` over the ranks of `group` (one small all-reduce)"""
+    import torch
     import torch.distributed as dist
-    if ENGINE_COMM == "on" or dist.get_backend(group) == "nccl":
+    t = torch.tensor([1 if flag else 0], dtype=torch.int32, device="cuda" if backend == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()) == 1)
+
+
+def _engine_comm_ready(ev: Evaluator, group, world: int) -> bool:
+    """Whether the exchange runs behind the C-ABI (hefx_allreduce_sum) -- decided COLLECTIVELY, once per group: the ranks
+    take the engine path only if every one of them holds (or could attach) the communicator; a rank that cannot (its
+    engine already serves another group, RCCL failed to initialise there) makes ALL ranks take the torch path instead of
+    leaving its peers alone in a collective.  Whether to try at all depends only on the mode and the backend, which are
+    the same everywhere, so the handshake itself is entered by every rank or by none."""
+    eng = ev.be.engine
+    import torch.distributed as dist
+    backend = dist.get_backend(group)
+    if ENGINE_COMM == "off" or not (ENGINE_COMM == "on" or backend == "nccl"):
+        return False
+    key = (id(group), world)
+    if key in _comm_decisions:
+        if _comm_decisions[key] and eng.comm_world != world:  # destroyed behind our back (bench.py's opt-in leg does)
+            del _comm_decisions[key]
+        else:
+            return _comm_decisions[key]
+    have = eng.comm_world == world
+    if _all_true(have, group, backend):
+        _comm_decisions[key] = True
+        return True
+    ok = _all_true(have or eng.comm_world == 0, group, backend)
+    err = None
+    if ok:
         try:
+            if have:
+                eng.comm_destroy()  # some peer lacks it: everybody attaches anew (comm_init is collective)
             init_engine_comm(ev, group)
-        except Exception:
-            if ENGINE_COMM == "on":
-                raise
-            return False
-        return eng.comm_world == world
-    return False
+        except Exception as ex:  # reported below, after the ranks have agreed on the outcome
+            err = ex
+        ok = _all_true(err is None and eng.comm_world == world, group, backend)
+        if not ok and eng.comm_world:
+            try:
+                eng.comm_destroy()
+            except Exception:
+                pass
+    if not ok and ENGINE_COMM == "on":
+        raise RuntimeError("HEFX_ENGINE_COMM=on, but the engine communicator could not be attached on every rank"
+                           + (f": {err!r}" if err else ""))
+    _comm_decisions[key] = ok
+    return ok
 
 
 def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertext:
@@ -107,7 +144,10 @@ def allreduce_ciphertext(ev: Evaluator, ct: Ciphertext, group=None) -> Ciphertex
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         if staged:
             eng.copy_raw(out.ptr, t.data_ptr(), t.numel() * 8)
-        if cur.cuda_stream != 0:
+        # nccl: a synchronous collective makes torch's current stream wait for it (work.wait()), and that stream is the
+        # null stream the engine submits to unless the caller moved torch elsewhere.  Any other backend (gloo with device
+        # tensors stages through the host) only PROMISES completion to the host, so the host waits before the engine reads.
+        if cur.cuda_stream != 0 or dist.get_backend(group) != "nccl":
             cur.synchronize()
         eng.reduce_canonical(L, size, out, addends=world)
         data = out

@@ -53,6 +53,31 @@ __device__ __forceinline__ u64 mul_sub_lo64(u64 x, u64 w, u64 h, u64 nq)
     return (u64)(uint32_t)a | ((u64)ahi << 32);
 }
 
+// Pseudo-Mersenne product for q = 2^60 - delta (SEAL's 60-bit primes: delta = 2^60 - q < 2^23 for every set of
+// tests/golden/appendix_b.json): y < 2^63, w < q  ->  y*w mod q in [0, 2q), from the twiddle alone (no Shoup companion).
+//   P = y*w < 2^123 by four multiply-adds (c = y1*w0 + b cannot wrap: y1 < 2^31, b < 2^60 + 2^32);
+//   h = P >> 60, fold: h*delta + (P mod 2^60) = t1*2^32 + lo32(t0), h2 = that >> 60, r = (that mod 2^60) + h2*delta < 2^60 + 2^49.
+__device__ __forceinline__ u64 pm_mul(u64 y, u64 w, uint32_t delta)
+{
+    const uint32_t y0 = (uint32_t)y, y1 = (uint32_t)(y >> 32), w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    u64 a = (u64)y0 * w0;
+    asm("" : "+v"(a));  // keep the full product: otherwise v_mul_lo + v_mul_hi (quarter rate) instead of one multiply-add
+    u64 b = (u64)y0 * w1 + (a >> 32);
+    u64 c = (u64)y1 * w0 + b;
+    asm("" : "+v"(c));
+    const u64 hi = (u64)y1 * w1 + (c >> 32);
+    const uint32_t plo_hi = (uint32_t)c;
+    const uint32_t h_lo = __builtin_amdgcn_alignbit((uint32_t)hi, plo_hi, 28);
+    const uint32_t h_hi = __builtin_amdgcn_alignbit((uint32_t)(hi >> 32), (uint32_t)hi, 28);
+    const u64 plo60 = ((u64)(plo_hi & 0x0FFFFFFFu) << 32) | (uint32_t)a;
+    u64 t0 = (u64)h_lo * delta + plo60;
+    asm("" : "+v"(t0));
+    const u64 t1 = (u64)h_hi * delta + (t0 >> 32);
+    const uint32_t h2 = __builtin_amdgcn_alignbit((uint32_t)(t1 >> 32), (uint32_t)t1, 28);
+    const u64 low60 = ((u64)((uint32_t)t1 & 0x0FFFFFFFu) << 32) | (uint32_t)t0;
+    return (u64)h2 * delta + low60;
+}
+
 template <int FORM>
 __global__ __launch_bounds__(256) void k(u64 *p, const ulonglong2 *tw, u64 q, u64 nq, int rounds)
 {
@@ -71,6 +96,15 @@ __global__ __launch_bounds__(256) void k(u64 *p, const ulonglong2 *tw, u64 q, u6
             for (int i = 0; i < 16; ++i)
                 if (!(i & s)) {
                     u64 a, t;
+                    if (FORM == 5) {
+                        // values in [0,8q) = below 2^63: a = csub(x, 4q) in every other stage (in < 8q -> < 4q, out < 6q;
+                        // next stage in < 6q, out < 8q); the product is below 2q, so y' = a + 2q - t
+                        a = (s == 8 || s == 2) ? v[i] : csubn(v[i], nq4);
+                        t = pm_mul(v[i + s], w.x, (uint32_t)nq);
+                        v[i] = a + t;
+                        v[i + s] = a + 2 * q - t;
+                        continue;
+                    }
                     if (FORM == 0) {
                         a = csub(v[i], q4);
                         t = v[i + s] * w.x - under2(v[i + s], w.y) * q;
@@ -142,7 +176,9 @@ int main()
     const auto r2 = residues([&] { hipLaunchKernelGGL(k<2>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
     const auto r3 = residues([&] { hipLaunchKernelGGL(k<3>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
     const auto r4 = residues([&] { hipLaunchKernelGGL(k<4>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
-    printf("residues equal to form 1: form 2 %d, form 3 %d, form 4 %d\n", r1 == r2, r1 == r3, r1 == r4);
+    const auto r5 = residues([&] { hipLaunchKernelGGL(k<5>, dim3(blocks), dim3(256), 0, 0, d, tw, q, 0 - q, 7); });
+    printf("residues equal to form 1: form 2 %d, form 3 %d, form 4 %d, form 5 (pseudo-Mersenne) %d\n", r1 == r2, r1 == r3, r1 == r4,
+           r1 == r5);
     hipMemcpy(d, h.data(), h.size() * 8, hipMemcpyHostToDevice);
     const double m0 = run<0>(d, tw, q, rounds, blocks), m1 = run<1>(d, tw, q, rounds, blocks);
     for (int f = 2; f <= 4; ++f) {
@@ -150,6 +186,11 @@ int main()
         printf("form %d (%s%s): %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", f,
                f == 2 || f == 3 ? "quotient by multiply-adds" : "v_mul_hi quotient", f >= 3 ? ", 16q lazy range" : "", m,
                m * 1e6 / wave_bf, m * 1e-3 * 2.4e9 / wave_bf);
+    }
+    {
+        const double m = run<5>(d, tw, q, rounds, blocks);
+        printf("form 5 (pseudo-Mersenne fold, 8-byte twiddle, 8q lazy range): %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n",
+               m, m * 1e6 / wave_bf, m * 1e-3 * 2.4e9 / wave_bf);
     }
     printf("compiler's form : %.3f ms -> %.1f ns, %.1f SIMD cycles @2.4 GHz per wave-butterfly\n", m0, m0 * 1e6 / wave_bf,
            m0 * 1e-3 * 2.4e9 / wave_bf);
