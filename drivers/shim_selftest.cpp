@@ -236,7 +236,7 @@ int main()
     // ALL rows and run in lockstep must give the bits of call-by-call execution; also with a tiny pending budget
     // (SEAL_SHIM_PENDING_MB-style forced flushes in the middle of the chains)
     {
-        const int rows = 5, size = 4;
+        int rows = 5, size = 4;
         auto run = [&](bool lazy, std::size_t budget) {
             auto e = context->engine();
             e->live();
@@ -285,6 +285,23 @@ int main()
               "LR loop with forced mid-chain flushes (3 MB pending budget) == call-by-call execution");
         CHECK(std::get<2>(lazy) >= (std::size_t)rows * (3 + 2 * size) && std::get<2>(eager) == 0,
               "the whole loop stays recorded until add_many (encode / plaintext mod_switch do not flush)");
+        // round 4: the rotate-by-1 + add_inplace pairs run as hefx_apply_galois_add_batch, runs of them as
+        // hefx_rotate_add_chain (3 levels above; 11 here: long enough for the captured two-level HIP graph), the mask
+        // encodes as one hefx_ckks_encode_batch -- and with each fusion switched off the bits stay those of call-by-call
+        {
+            rows = 3, size = 12;
+            const auto chain = run(true, (std::size_t)8192 << 20), plain = run(false, (std::size_t)8192 << 20);
+            CHECK(std::get<0>(chain) == std::get<0>(plain) && std::get<1>(chain) == std::get<1>(plain),
+                  "LR loop with 11-level rotate+add chains (hefx_rotate_add_chain, graph replay) == call-by-call execution");
+            auto e = context->engine();
+            const std::size_t calls0 = e->stats.calls;
+            (void)run(true, (std::size_t)8192 << 20);
+            const std::size_t fused_calls = e->stats.calls - calls0;
+            // (row 0's feature is an external ciphertext, rows 1 and 2 are rotations: two depth classes, each with its own
+            // calls; call by call the loop is 3 x (5 + 2 x 11 + 2) = 87 engine calls)
+            CHECK(fused_calls <= 24, "the 3 x 11-level loop submits in <= 24 batched engine calls (87 call by call)");
+            rows = 5, size = 4;
+        }
         // several devices behind the same program (SEAL_SHIM_DEVICES): the rows are independent sub-graphs, dealt over
         // two / three engine contexts (sharing the GPUs that exist), inputs replicated, results copied home -- the
         // bits of the one-device run; a second pass reuses the cached replicas of the keys
@@ -308,6 +325,38 @@ int main()
     // SEAL's error behaviour at the boundary
     Ciphertext low = ca;
     evaluator.mod_switch_to_next_inplace(low);
+    // recorded encode + encrypt (round 4): a loop of encode / encrypt calls stays recorded and reaches the device as one
+    // hefx_ckks_encode_batch + one hefx_encrypt_batch; decrypt observes it
+    {
+        auto e = context->engine();
+        e->live();
+        const std::size_t before = e->pend.size();
+        vector<Ciphertext> cts(6);
+        for (int i = 0; i < 6; i++) {
+            vector<double> v{1.0 + i, -2.0 * i, 0.5};
+            Plaintext pt;
+            encoder.encode(v, scale, pt);
+            encryptor.encrypt(pt, cts[i]);
+        }
+        CHECK(e->pend.size() - before == 12, "6 encodes + 6 encryptions stay recorded");
+        const std::size_t calls0 = e->stats.calls;
+        bool ok = true;
+        for (int i = 0; i < 6; i++) {
+            const auto r = dec(cts[i]);
+            ok = ok && fabs(r[0] - (1.0 + i)) < 1e-6 && fabs(r[1] + 2.0 * i) < 1e-6 && fabs(r[2] - 0.5) < 1e-6 && fabs(r[3]) < 1e-6;
+        }
+        CHECK(ok, "recorded encode + encrypt: every ciphertext decrypts to its vector");
+        CHECK(e->stats.calls - calls0 == 2, "... from two batched engine calls");
+        // a recorded plaintext, mod-switched without a copy, multiplies like an eager one
+        Plaintext m;
+        encoder.encode(vector<double>{2.0, 2.0, 2.0, 2.0}, scale, m);
+        evaluator.mod_switch_to_next_inplace(m);
+        Ciphertext low2 = ca, prod2;
+        evaluator.mod_switch_to_next_inplace(low2);
+        evaluator.multiply_plain(low2, m, prod2);
+        CHECK(fabs(dec(prod2)[0] - 2.0 * dec(ca)[0]) < 1e-4 && m.coeff_count() == 2 * 8192,
+              "recorded encode -> zero-copy mod_switch_to_next -> multiply_plain");
+    }
     CHECK(throws_invalid([&] { Ciphertext t; evaluator.add(ca, low, t); }, "parameter mismatch"), "add: parms_id mismatch throws");
     Ciphertext big = ca;
     big.scale() = scale * 2;

@@ -88,6 +88,9 @@ int hefx_copy_peer_to(hefx_context *dst_ctx, void *d_dst, hefx_context *src_ctx,
                       void *dst_stream);
 /* the HIP device a context lives on */
 int hefx_context_device(const hefx_context *ctx);
+/* free and total memory of that device in bytes (hipMemGetInfo; blocks parked in the context's pool count as used):
+ * what a host side sizes its budgets with (the shim's pending-results budget is a quarter of the device) */
+int hefx_device_memory(hefx_context *ctx, size_t *free_bytes, size_t *total_bytes);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
 int hefx_stream_sync(hefx_context *ctx, void *stream);
 
@@ -171,6 +174,27 @@ int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *con
 int hefx_rotate_multiply_plain_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                                      const uint32_t *galois_elts, const uint64_t *const *d_keys,
                                      const uint64_t *const *d_pts, uint64_t *const *d_ct_out, void *stream);
+
+/* ---- rotate_vector_inplace + add_inplace as ONE key switch (helper.h:474-475, the body of cipher_dot_product's loop;
+ *      logistic_regression_ckks.cpp:217-229 and :295-300 reach it 2000 x 7 and 8 x 1999 times per training step):
+ *      ct_out[i] = apply_galois(ct_in[i], elt_i, key_i) and acc_out[i] = acc_in[i] + ct_out[i] (mod q, canonical -- the
+ *      words Evaluator::add_inplace would leave), the sum taken in the mod-down epilogue that produces the rotation's
+ *      words instead of a sixth launch and a second pass over the row.  acc_in[i] == acc_out[i] is the in-place sum,
+ *      ct_in[i] == ct_out[i] the in-place rotation; otherwise the independence rule of hefx_apply_galois_batch holds
+ *      for the rotations AND the sums (no sum may overlap another item's sum, rotation or input). */
+int hefx_apply_galois_add_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
+                                const uint32_t *galois_elts, const uint64_t *const *d_keys,
+                                const uint64_t *const *d_acc_in, uint64_t *const *d_acc_out,
+                                uint64_t *const *d_ct_out, void *stream);
+/* the whole loop of helper.h:472-476 for n ciphertext pairs in lockstep (the eight weight chains of the LR gradient):
+ *      t_0 = ct_in, t_s = apply_galois(t_(s-1), elt, key), a_s = a_(s-1) + t_s for s = 1..steps (a_0 = acc_in);
+ *      ct_out = t_steps, acc_out = a_steps; the inputs are not written.  Level by level the same key switches as `steps`
+ *      calls of hefx_apply_galois_add_batch (same bits); the intermediate rotations live in two engine-owned buffer sets,
+ *      so the levels are two alternating launch sequences, captured once as a HIP graph and replayed
+ *      (HEFX_CHAIN_GRAPH=0: plain launches) -- no per-level validation, allocation or host bookkeeping. */
+int hefx_rotate_add_chain(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in, const uint32_t *galois_elts,
+                          const uint64_t *const *d_keys, const uint64_t *const *d_acc_in, uint64_t *const *d_acc_out,
+                          uint64_t *const *d_ct_out, int steps, void *stream);
 
 /* ---- Evaluator::relinearize_inplace (helper.h:440,541; polynomial.cpp:92,187): size 3 -> 2. */
 int hefx_relinearize(hefx_context *ctx, int L, const uint64_t *d_ct3, const uint64_t *d_relin_key,
@@ -289,6 +313,11 @@ int hefx_linear_transform_plain_bsgs(hefx_context *ctx, int L, const uint64_t *d
  *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit. */
 int hefx_ckks_encode(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
                      double scale, uint64_t *d_out, void *stream);
+/* the same for `count` vectors whose plaintexts are separately allocated: d_outs[i] receives vector i (host arrays as
+ * above, vector i at h_re + i * nvalues).  One encode pass and one scatter launch per 256 vectors; the words
+ * hefx_ckks_encode writes. */
+int hefx_ckks_encode_batch(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
+                           double scale, uint64_t *const *d_outs, void *stream);
 
 /* ---- randomness, Encryptor::encrypt, Decryptor::decrypt on the GPU (call sites
  *      linear_transformation2.cpp:344-350, logistic_regression_ckks.cpp:362-381, matrix_multiplication.cpp:419).
@@ -318,6 +347,11 @@ int hefx_galois_permute(hefx_context *ctx, uint32_t galois_elt, const uint64_t *
  * NULL (encryption of zero); u ternary from sub-stream 4*stream_id, e0 / e1 noise from 4*stream_id+1 / +2. */
 int hefx_encrypt(hefx_context *ctx, int L, const uint64_t *d_pk, const uint64_t *d_plain, const uint8_t *key32,
                  uint64_t stream_id, uint64_t *d_out, void *stream);
+/* n encryptions under one public key and one sampler key, item i with stream id first_stream_id + i: the words n
+ * hefx_encrypt calls with those ids produce, from five launches per 256 items instead of five per item.  d_plains may be
+ * NULL, and so may any d_plains[i] (encryption of zero). */
+int hefx_encrypt_batch(hefx_context *ctx, int L, int n, const uint64_t *d_pk, const uint64_t *const *d_plains,
+                       const uint8_t *key32, uint64_t first_stream_id, uint64_t *const *d_outs, void *stream);
 /* out[L][N] = c0 + c1*s + ... + c_(size-1)*s^(size-1), NTT form; d_sk = NTT-form secret key rows [>=L][N] */
 int hefx_decrypt(hefx_context *ctx, int L, int size, const uint64_t *d_ct, const uint64_t *d_sk, uint64_t *d_out,
                  void *stream);

@@ -183,8 +183,8 @@ struct Engine {
         // the home context outlives the payload buffers that still point at it (process-lifetime registry): not destroyed here
     }
     inline hefx_context *device_context(int d);
-    inline void flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
-                            int max_depth);
+    struct Fusion;
+    inline void flush_multi(std::vector<Node> &K, const Fusion &fz, int max_depth);
 
     // ---- deferred evaluation ------------------------------------------------------------------------------
     // The reference issues its ciphertext operations one call at a time -- helper.h:252-257 (rotate_vector,
@@ -202,14 +202,23 @@ struct Engine {
     // multiply_plain is fused into the key switch that feeds it when nobody else holds the rotated input.  Same bits
     // as immediate execution: every node is a deterministic function of its inputs.  SEAL_SHIM_LAZY=0 turns it off.
     struct Node {
-        enum Kind { ROT, MULPT, MULCT, RELIN, RESCALE, ADD, SUB };
+        // (ENCODE and ENCRYPT first: the groups of one depth are submitted in this order, producers of plaintexts ahead
+        // of the products that read them)
+        enum Kind { ENCODE, ENCRYPT, ROT, MULPT, MULCT, RELIN, RESCALE, ADD, SUB };
         Kind kind;
-        BufPtr a, b, dst;     // a: ciphertext; b: ciphertext (MULCT/ADD/SUB), plaintext (MULPT) or key (ROT/RELIN)
+        BufPtr a, b, dst;     // a: ciphertext (ENCRYPT: the plaintext; ENCODE: none); b: ciphertext (MULCT/ADD/SUB),
+                              // plaintext (MULPT), key (ROT/RELIN) or public key (ENCRYPT)
         std::uint32_t elt;    // ROT
-        int L, size;          // rows and size of the input ciphertext(s)
+        int L, size;          // rows and size of the input ciphertext(s); ENCODE: size = number of slot values
         int depth;
         int consumers;        // recorded nodes that read dst
         int mulpt_consumer;   // a MULPT node reading dst (fusion candidate), -1 if none
+        // ENCODE: the slot values (copied at the call: the caller's vector may change) and the scale;
+        // ENCRYPT: the encryptor's sampler key and the stream id this encryption drew
+        std::shared_ptr<std::vector<double>> host;
+        double scale = 0;
+        std::shared_ptr<std::array<std::uint8_t, 32>> skey;
+        std::uint64_t stream_id = 0;
     };
     std::vector<Node> pend;
     std::map<const std::uint64_t *, int> pend_dst;                                              // result buffer -> node
@@ -241,8 +250,26 @@ struct Engine {
         return ctx_raw;
     }
     BufPtr record(Node::Kind kind, const BufPtr &a, const BufPtr &b, std::uint32_t elt, int L, int size,
-                  std::size_t out_words, const std::shared_ptr<Engine> &self);
+                  std::size_t out_words, const std::shared_ptr<Engine> &self, const Node *extra = nullptr);
     inline void flush();
+
+    // What a submission fuses (all of it invisible in the bits: every fused call runs the same key switches and sums):
+    //   rot_mul   ROT + the MULPT that alone reads it            -> hefx_rotate_multiply_plain_batch
+    //   rot_add   ROT + an ADD of its result (helper.h:474-475)  -> hefx_apply_galois_add_batch (sum in the epilogue)
+    //   chains    runs of rot_add pairs, each feeding the next, whose intermediate rotations and sums nobody outside the
+    //             graph holds (helper.h:472-476: the loop reassigns `dup` and `mult`)  -> hefx_rotate_add_chain, all
+    //             chains of one start depth, level and length in lockstep (the LR gradient's eight, 2000 levels each)
+    struct Fusion {
+        std::vector<int> mul_of, add_of;    // per ROT node: the fused MULPT / ADD node, or -1
+        std::vector<char> skip;             // the node runs inside another node's call
+        std::vector<char> unwritten;        // ... and its result buffer is never written (nobody may read it)
+        struct Chain {
+            int first_rot, last_rot, last_add, steps;
+            const Buf *ct_in, *acc_in;
+        };
+        std::vector<Chain> chains;
+    };
+    inline Fusion plan_fusion(const std::vector<Node> &K) const;
 
     // payload buffers come from the engine's pooled allocator (hefx_malloc / hefx_free: slab-carved, no hipFree and so no
     // device synchronisation on the hot path; all work is ordered on the default stream)
@@ -276,6 +303,13 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     // rescale_to_next from the floor division (3.4.x as App. A.9 reads it; default) to round-to-nearest (3.5+)
     if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
         check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "round" ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR));
+    {   // recorded results may hold up to a quarter of the device's memory (at most 64 GiB) before a submission is
+        // forced: the 2000-row loops of the LR driver (80 GB of intermediates at N = 16384, L = 8) then run as two or
+        // three lockstep submissions on a 288 GB MI355X instead of nine; SEAL_SHIM_PENDING_MB overrides
+        std::size_t fr = 0, tot = 0;
+        if (hefx_device_memory(e->ctx_raw, &fr, &tot) == HEFX_OK && tot)
+            e->pend_budget = std::min<std::size_t>((std::size_t)64 << 30, std::max<std::size_t>((std::size_t)1 << 30, tot / 4));
+    }
     if (const char *m = std::getenv("SEAL_SHIM_PENDING_MB")) e->pend_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *m = std::getenv("SEAL_SHIM_REPLICA_MB")) e->replica_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *st = std::getenv("SEAL_SHIM_STATS")) {
@@ -314,25 +348,34 @@ inline BufPtr new_buf(const std::shared_ptr<Engine> &e, std::size_t words) { ret
 inline bool Engine::pending(const Buf *b) const { return pend_dst.count(b->p) != 0; }
 
 inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, std::uint32_t elt, int L, int size,
-                             std::size_t out_words, const std::shared_ptr<Engine> &self)
+                             std::size_t out_words, const std::shared_ptr<Engine> &self, const Node *extra)
 {
     if (kind == Node::ROT) {  // the same rotation of the same buffer with the same key: computed once
         auto hit = pend_cse.find(std::make_tuple((const std::uint64_t *)a->p, elt, (const std::uint64_t *)b->p));
         if (hit != pend_cse.end() && pend[hit->second].L == L) return pend[hit->second].dst;
     }
     Node nd{kind, a, b, new_buf(self, out_words), elt, L, size, 0, 0, -1};
+    if (extra) {
+        nd.host = extra->host;
+        nd.scale = extra->scale;
+        nd.skey = extra->skey;
+        nd.stream_id = extra->stream_id;
+    }
     const int idx = (int)pend.size();
-    auto link = [&](const BufPtr &in) {
+    auto link = [&](const BufPtr &in, bool ct_input) {
+        if (!in) return;
         auto p = pend_dst.find(in->p);
         if (p == pend_dst.end()) return;
         Node &src = pend[p->second];
         nd.depth = std::max(nd.depth, src.depth + 1);
         ++src.consumers;
-        if (kind == Node::MULPT) src.mulpt_consumer = idx;
+        if (kind == Node::MULPT && ct_input) src.mulpt_consumer = idx;
     };
-    link(a);
+    link(a, true);
     if (kind == Node::MULCT || kind == Node::ADD || kind == Node::SUB) {
-        if (b.get() != a.get()) link(b);
+        if (b.get() != a.get()) link(b, true);
+    } else if (kind == Node::MULPT) {
+        link(b, false);  // the plaintext may be a recorded encode
     }
     pend.push_back(nd);
     pend_dst[nd.dst->p] = idx;
@@ -355,8 +398,8 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
 // to this device, out(i) is where node i's result goes.
 template <class In, class Out>
 inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vector<Engine::Node> &K,
-                         const std::vector<std::vector<int>> &by_depth, const std::vector<char> &fused_rot,
-                         const std::vector<char> &fused_mul, int depth_first, int depth_last, const In &in, const Out &out);
+                         const std::vector<std::vector<int>> &by_depth, const Engine::Fusion &fz, int depth_first,
+                         int depth_last, const In &in, const Out &out);
 inline std::vector<std::vector<int>> nodes_by_depth(const std::vector<Engine::Node> &K, const std::vector<int> &ids, int max_depth)
 {
     std::vector<std::vector<int>> by_depth(max_depth + 1);
@@ -378,24 +421,14 @@ inline void Engine::flush()
     ++stats.flushes;
     stats.nodes += K.size();
     stats.levels += (std::size_t)max_depth + 1;
-    // a multiply_plain rides in its rotation's epilogue when the rotated ciphertext is visible to nobody else: the
-    // rotation node and the product node are its only holders
-    std::vector<char> fused_rot(K.size(), 0), fused_mul(K.size(), 0);
-    for (std::size_t i = 0; i < K.size(); ++i) {
-        const Node &k = K[i];
-        if (k.kind != Node::ROT || k.consumers != 1 || k.mulpt_consumer < 0 || k.dst.use_count() != 2) continue;
-        const Node &m = K[k.mulpt_consumer];
-        if (m.kind != Node::MULPT || m.a.get() != k.dst.get() || m.size != 2) continue;
-        fused_rot[i] = 1;
-        fused_mul[k.mulpt_consumer] = 1;
-    }
+    const Fusion fz = plan_fusion(K);
     try {
         if (ndev > 1)
-            flush_multi(K, fused_rot, fused_mul, max_depth);
+            flush_multi(K, fz, max_depth);
         else {
             std::vector<int> all(K.size());
             for (std::size_t i = 0; i < K.size(); ++i) all[i] = (int)i;
-            submit_nodes(ctx_raw, stats, K, nodes_by_depth(K, all, max_depth), fused_rot, fused_mul, 0, max_depth,
+            submit_nodes(ctx_raw, stats, K, nodes_by_depth(K, all, max_depth), fz, 0, max_depth,
                          [](const std::uint64_t *p_) { return p_; },
                    [&](int i) { return K[i].dst->p; });
         }
@@ -414,48 +447,122 @@ inline void Engine::flush()
 }
 template <class In, class Out>
 inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vector<Engine::Node> &K,
-                         const std::vector<std::vector<int>> &by_depth, const std::vector<char> &fused_rot,
-                         const std::vector<char> &fused_mul, int depth_first, int depth_last, const In &in, const Out &out)
+                         const std::vector<std::vector<int>> &by_depth, const Engine::Fusion &fz, int depth_first,
+                         int depth_last, const In &in, const Out &out)
 {
     using Node = Engine::Node;
     std::vector<const std::uint64_t *> va, vb, vc;
-    std::vector<std::uint64_t *> vo;
+    std::vector<std::uint64_t *> vo, vo2;
     std::vector<std::uint32_t> ve;
     for (int depth = depth_first; depth <= depth_last; ++depth) {
         if (by_depth[depth].empty()) continue;
-        // groups of this depth: (kind, fused?, L, size, shared key)
+        // groups of this depth: (kind, fusion, L, size, shared key); fusion of a ROT: 0 none, 1 + multiply_plain, 2 + add
         std::map<std::tuple<int, int, int, int, const std::uint64_t *>, std::vector<int>> groups;
+        // chains that start at this depth, in lockstep per (level, length): (L, steps) -> chain indices
+        std::map<std::pair<int, int>, std::vector<int>> chain_groups;
         for (int i : by_depth[depth]) {
             const Node &k = K[i];
-            if (fused_mul[i]) continue;  // runs inside its rotation
-            const std::uint64_t *shared = k.kind == Node::RELIN ? k.b->p : nullptr;
-            groups[std::make_tuple((int)k.kind, (int)fused_rot[i], k.L, k.size, shared)].push_back(i);
+            if (fz.skip[i]) continue;  // runs inside another node's call
+            const std::uint64_t *shared = (k.kind == Node::RELIN || k.kind == Node::ENCRYPT) ? k.b->p : nullptr;
+            int f = 0;
+            if (k.kind == Node::ROT) f = fz.mul_of[i] >= 0 ? 1 : (fz.add_of[i] >= 0 ? 2 : 0);
+            groups[std::make_tuple((int)k.kind, f, k.L, k.size, shared)].push_back(i);
+        }
+        for (std::size_t ci = 0; ci < fz.chains.size(); ++ci) {
+            const auto &ch = fz.chains[ci];
+            if (K[ch.first_rot].depth != depth) continue;
+            // flush_multi hands every device only its own nodes: a chain belongs to the device of its first rotation
+            if (std::find(by_depth[depth].begin(), by_depth[depth].end(), ch.first_rot) == by_depth[depth].end()) continue;
+            chain_groups[{K[ch.first_rot].L, ch.steps}].push_back((int)ci);
+        }
+        for (auto &g : chain_groups) {
+            const int L = g.first.first, steps = g.first.second, n = (int)g.second.size();
+            va.clear(), vb.clear(), vc.clear(), vo.clear(), vo2.clear(), ve.clear();
+            ++stats.calls;
+            for (int ci : g.second) {
+                const auto &ch = fz.chains[ci];
+                va.push_back(in(ch.ct_in->p));
+                vb.push_back(in(K[ch.first_rot].b->p));
+                ve.push_back(K[ch.first_rot].elt);
+                vc.push_back(in(ch.acc_in->p));
+                vo.push_back(out(ch.last_rot));
+                vo2.push_back(out(ch.last_add));
+            }
+            check(hefx_rotate_add_chain(cx, L, n, va.data(), ve.data(), vb.data(), vc.data(), vo2.data(), vo.data(), steps, nullptr));
         }
         for (auto &g : groups) {
-            const int kind = std::get<0>(g.first), fz = std::get<1>(g.first), L = std::get<2>(g.first),
+            const int kind = std::get<0>(g.first), f = std::get<1>(g.first), L = std::get<2>(g.first),
                       size = std::get<3>(g.first);
             const std::vector<int> &gi = g.second;
             const int n = (int)gi.size();
-            va.clear(), vb.clear(), vc.clear(), vo.clear(), ve.clear();
+            va.clear(), vb.clear(), vc.clear(), vo.clear(), vo2.clear(), ve.clear();
             ++stats.calls;
             for (int i : gi) {
                 const Node &k = K[i];
+                if (kind == Node::ENCODE || kind == Node::ENCRYPT) continue;  // gather their own operands below
                 va.push_back(in(k.a->p));
                 if (k.b) vb.push_back(in(k.b->p));
                 ve.push_back(k.elt);
-                if (fz) {
-                    const Node &m = K[k.mulpt_consumer];
+                if (kind == Node::ROT && f == 1) {
+                    const Node &m = K[fz.mul_of[i]];
                     vc.push_back(in(m.b->p));
-                    vo.push_back(out(k.mulpt_consumer));
+                    vo.push_back(out(fz.mul_of[i]));
+                } else if (kind == Node::ROT && f == 2) {
+                    const Node &ad = K[fz.add_of[i]];
+                    vc.push_back(in(ad.a.get() == k.dst.get() ? ad.b->p : ad.a->p));  // the sum's other operand
+                    vo.push_back(out(i));
+                    vo2.push_back(out(fz.add_of[i]));
                 } else {
                     vo.push_back(out(i));
                 }
             }
             switch (kind) {
+                case Node::ENCODE: {  // all vectors of one (level, length), scale by scale: one engine call each
+                    std::map<double, std::vector<int>> by_scale;
+                    for (int i : gi) by_scale[K[i].scale].push_back(i);
+                    for (auto &bs : by_scale) {
+                        const std::size_t nv = (std::size_t)size;
+                        std::vector<double> vals(nv * bs.second.size());
+                        std::vector<std::uint64_t *> outs;
+                        for (std::size_t t = 0; t < bs.second.size(); ++t) {
+                            std::memcpy(vals.data() + t * nv, K[bs.second[t]].host->data(), nv * sizeof(double));
+                            outs.push_back(out(bs.second[t]));
+                        }
+                        check(hefx_ckks_encode_batch(cx, L, vals.data(), nullptr, size, (int)bs.second.size(), bs.first,
+                                                     outs.data(), nullptr));
+                    }
+                    break;
+                }
+                case Node::ENCRYPT: {  // runs of consecutive stream ids of one encryptor: one engine call each
+                    std::vector<int> order(gi);
+                    std::sort(order.begin(), order.end(), [&](int x, int y) {
+                        if (*K[x].skey != *K[y].skey) return *K[x].skey < *K[y].skey;
+                        return K[x].stream_id < K[y].stream_id;
+                    });
+                    for (std::size_t t0 = 0; t0 < order.size();) {
+                        std::size_t t1 = t0 + 1;
+                        while (t1 < order.size() && *K[order[t1]].skey == *K[order[t0]].skey &&
+                               K[order[t1]].stream_id == K[order[t0]].stream_id + (t1 - t0))
+                            ++t1;
+                        std::vector<const std::uint64_t *> plains;
+                        std::vector<std::uint64_t *> outs;
+                        for (std::size_t t = t0; t < t1; ++t) {
+                            plains.push_back(K[order[t]].a ? in(K[order[t]].a->p) : nullptr);
+                            outs.push_back(out(order[t]));
+                        }
+                        check(hefx_encrypt_batch(cx, L, (int)(t1 - t0), in(std::get<4>(g.first)), plains.data(),
+                                                 K[order[t0]].skey->data(), K[order[t0]].stream_id, outs.data(), nullptr));
+                        t0 = t1;
+                    }
+                    break;
+                }
                 case Node::ROT:
-                    if (fz)
+                    if (f == 1)
                         check(hefx_rotate_multiply_plain_batch(cx, L, n, va.data(), ve.data(), vb.data(), vc.data(), vo.data(),
                                                                nullptr));
+                    else if (f == 2)
+                        check(hefx_apply_galois_add_batch(cx, L, n, va.data(), ve.data(), vb.data(), vc.data(), vo2.data(),
+                                                          vo.data(), nullptr));
                     else
                         check(hefx_apply_galois_batch(cx, L, n, va.data(), ve.data(), vb.data(), vo.data(), nullptr));
                     break;
@@ -480,6 +587,103 @@ inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vect
             }
         }
     }
+}
+
+// The fusion plan of a submission (see Engine::Fusion).  O(nodes log nodes) on the host.
+inline Engine::Fusion Engine::plan_fusion(const std::vector<Node> &K) const
+{
+    const int nk = (int)K.size();
+    Fusion fz;
+    fz.mul_of.assign(nk, -1);
+    fz.add_of.assign(nk, -1);
+    fz.skip.assign(nk, 0);
+    fz.unwritten.assign(nk, 0);
+    static const bool fuse_add = !(std::getenv("SEAL_SHIM_FUSE_ADD") && std::atoi(std::getenv("SEAL_SHIM_FUSE_ADD")) == 0);
+    static const bool fuse_chain = !(std::getenv("SEAL_SHIM_CHAINS") && std::atoi(std::getenv("SEAL_SHIM_CHAINS")) == 0);
+    // a multiply_plain rides in its rotation's epilogue when the rotated ciphertext is visible to nobody else: the
+    // rotation node and the product node are its only holders
+    for (int i = 0; i < nk; ++i) {
+        const Node &k = K[i];
+        if (k.kind != Node::ROT || k.consumers != 1 || k.mulpt_consumer < 0 || k.dst.use_count() != 2) continue;
+        const Node &m = K[k.mulpt_consumer];
+        if (m.kind != Node::MULPT || m.a.get() != k.dst.get() || m.size != 2) continue;
+        fz.mul_of[i] = k.mulpt_consumer;
+        fz.skip[k.mulpt_consumer] = 1;
+        fz.unwritten[i] = 1;  // the rotation inside a fused product is never stored
+    }
+    if (!fuse_add) return fz;
+    std::map<const std::uint64_t *, int> producer;
+    for (int i = 0; i < nk; ++i) producer[K[i].dst->p] = i;
+    // the depth at which a node's result EXISTS: its own, or -- for a sum fused into a rotation -- the rotation's
+    std::vector<int> eff_depth(nk);
+    for (int i = 0; i < nk; ++i) eff_depth[i] = K[i].depth;
+    auto depth_of = [&](const BufPtr &b) {  // -1: not produced by this submission
+        auto p = producer.find(b->p);
+        return p == producer.end() ? -1 : eff_depth[p->second];
+    };
+    // rot_add: the first ADD (size 2, same level) that reads a rotation's result; its other operand must exist when the
+    // rotation runs, i.e. come from outside or from a shallower (effective) depth.  Nodes are recorded after their
+    // inputs, so by the time ADD j is looked at every producer of its operands has been decided.
+    std::vector<int> rot_of_add(nk, -1);
+    for (int j = 0; j < nk; ++j) {
+        const Node &ad = K[j];
+        if (ad.kind != Node::ADD || ad.size != 2 || ad.a.get() == ad.b.get()) continue;
+        for (int side = 0; side < 2; ++side) {
+            const BufPtr &rin = side ? ad.b : ad.a, &other = side ? ad.a : ad.b;
+            auto p = producer.find(rin->p);
+            if (p == producer.end()) continue;
+            const int i = p->second;
+            const Node &r = K[i];
+            if (r.kind != Node::ROT || r.L != ad.L || fz.mul_of[i] >= 0 || fz.add_of[i] >= 0) continue;
+            if (depth_of(other) >= r.depth) continue;
+            fz.add_of[i] = j;
+            rot_of_add[j] = i;
+            fz.skip[j] = 1;
+            eff_depth[j] = r.depth;
+            break;
+        }
+    }
+    if (!fuse_chain) return fz;
+    // chains: pair (r', a') continues pair (r, a) when r' rotates r's result with the same element and key, a' adds r' to
+    // a's sum, and nobody but these nodes holds r's result (node + a + r' = 3 references) or a's sum (node + a' = 2)
+    std::vector<int> next_pair(nk, -1), has_prev(nk, 0);
+    std::map<const std::uint64_t *, int> rot_reading;  // buffer -> a paired ROT that rotates it (unique or -2)
+    for (int i = 0; i < nk; ++i)
+        if (K[i].kind == Node::ROT && fz.add_of[i] >= 0) {
+            auto ins = rot_reading.emplace(K[i].a->p, i);
+            if (!ins.second) ins.first->second = -2;
+        }
+    for (int i = 0; i < nk; ++i) {
+        if (K[i].kind != Node::ROT || fz.add_of[i] < 0) continue;
+        const Node &r = K[i], &a = K[fz.add_of[i]];
+        auto nx = rot_reading.find(r.dst->p);
+        if (nx == rot_reading.end() || nx->second < 0) continue;
+        const int i2 = nx->second;
+        const Node &r2 = K[i2], &a2 = K[fz.add_of[i2]];
+        if (r2.elt != r.elt || r2.b.get() != r.b.get() || r2.L != r.L) continue;
+        const BufPtr &other2 = a2.a.get() == r2.dst.get() ? a2.b : a2.a;
+        if (other2.get() != a.dst.get()) continue;
+        if (r.dst.use_count() != 3 || a.dst.use_count() != 2) continue;
+        next_pair[i] = i2;
+        has_prev[i2] = 1;
+    }
+    for (int i = 0; i < nk; ++i) {
+        if (K[i].kind != Node::ROT || fz.add_of[i] < 0 || has_prev[i] || next_pair[i] < 0) continue;
+        int steps = 1, last = i;
+        while (next_pair[last] >= 0) last = next_pair[last], ++steps;
+        if (steps < 3) continue;  // two levels are two fused calls either way
+        const Node &a1 = K[fz.add_of[i]];
+        Fusion::Chain ch{i, last, fz.add_of[last], steps, K[i].a.get(),
+                         (a1.a.get() == K[i].dst.get() ? a1.b : a1.a).get()};
+        fz.chains.push_back(ch);
+        for (int r = i;; r = next_pair[r]) {  // every node of the chain runs inside the one call of its first rotation
+            fz.skip[r] = 1;
+            fz.skip[fz.add_of[r]] = 1;
+            if (r != last) fz.unwritten[r] = fz.unwritten[fz.add_of[r]] = 1;
+            if (r == last) break;
+        }
+    }
+    return fz;
 }
 
 inline hefx_context *Engine::device_context(int d)
@@ -523,8 +727,7 @@ inline std::size_t Engine::evict_replicas(int d, std::size_t need, bool everythi
     return freed;
 }
 
-inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &fused_rot, const std::vector<char> &fused_mul,
-                                int max_depth)
+inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_depth)
 {
     const int nk = (int)K.size();
     // connected sub-graphs of the recorded dependencies (shared EXTERNAL inputs -- keys, the weight ciphertext -- do not
@@ -659,10 +862,10 @@ inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &f
             hefx_context *cx = dev_ctx[d];
             auto &rep = replicas[d];
             if (d == 0)
-                submit_nodes(cx, stats, K, by_depth[d], fused_rot, fused_mul, depth, depth,
+                submit_nodes(cx, stats, K, by_depth[d], fz, depth, depth,
                              [](const std::uint64_t *p_) { return p_; }, [&](int i) { return K[i].dst->p; });
             else
-                submit_nodes(cx, stats, K, by_depth[d], fused_rot, fused_mul, depth, depth,
+                submit_nodes(cx, stats, K, by_depth[d], fz, depth, depth,
                              [&](const std::uint64_t *p_) -> const std::uint64_t * {
                                  auto pr = producer.find(p_);
                                  if (pr != producer.end()) return tmp[pr->second];
@@ -680,7 +883,7 @@ inline void Engine::flush_multi(std::vector<Node> &K, const std::vector<char> &f
         if (share[d].empty()) continue;
         check(hefx_stream_sync(dev_ctx[d], nullptr));
         for (int i : share[d]) {
-            if (fused_rot[i]) continue;  // the rotation inside a fused product was never written
+            if (fz.unwritten[i]) continue;  // inside a fused product or a chain: never written
             if (K[i].dst.use_count() - 1 - inner[i] <= 0) continue;
             check(hefx_copy_peer_to(ctx_raw, K[i].dst->p, dev_ctx[d], tmp[i], K[i].dst->words * 8, nullptr));
             copied_back = true;
@@ -1112,14 +1315,14 @@ public:
     bool is_ntt_form() const { return bfv.empty(); }
     bool is_zero() const { return zero_; }
     // SEAL: number of uint64 words of the plaintext (CKKS: rows * N in NTT form; BFV: coefficients modulo t)
-    std::size_t coeff_count() const { return bfv.empty() && buf ? buf->words : bfv.size(); }
+    std::size_t coeff_count() const { return bfv.empty() && buf ? (view_words_ ? view_words_ : buf->words) : bfv.size(); }
     // read access to the words (SEAL's Plaintext::data()); CKKS payloads live on the device: a host mirror is fetched
     const std::uint64_t *data() const
     {
         if (!bfv.empty()) return bfv.data();
         if (!buf) return nullptr;
         if (!mirror_ || mirror_of_ != buf->p) {
-            mirror_ = std::make_shared<std::vector<std::uint64_t>>(shim::download(buf));
+            mirror_ = std::make_shared<std::vector<std::uint64_t>>(shim::download(buf, view_words_));
             mirror_of_ = buf->p;
         }
         return mirror_->data();
@@ -1143,6 +1346,7 @@ public:
     std::vector<std::uint64_t> bfv;   // BFV: N coefficients modulo the plain modulus, on the host
     int rows = 0;
     bool zero_ = false;
+    std::size_t view_words_ = 0;      // non-zero: the plaintext is the first view_words_ words of buf (after a mod switch)
     mutable std::shared_ptr<std::vector<std::uint64_t>> mirror_;
     mutable const std::uint64_t *mirror_of_ = nullptr;
 
@@ -1393,9 +1597,18 @@ public:
         if (!plain.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
         auto &e = ctx_->engine();
         const int L = plain.rows;
+        if (e->lazy && !shim::sync_mode()) {  // recorded: consecutive encryptions of one Encryptor run as hefx_encrypt_batch
+            shim::Engine::Node x{};
+            if (!key_) key_ = std::make_shared<std::array<std::uint8_t, 32>>(rnd_.key);
+            x.skey = key_;
+            x.stream_id = rnd_.stream();
+            dest.set(e->record(shim::Engine::Node::ENCRYPT, plain.buf, pk_.buf, 0, L, 2, (std::size_t)2 * L * ctx_->n(), e, &x), 2,
+                     L, plain.parms_id(), plain.scale());
+            return;
+        }
         auto c = shim::new_buf(e, (std::size_t)2 * L * ctx_->n());
         // sampling (u ternary, e0/e1 clipped normal), NTT and the dyadic arithmetic: one engine call
-        shim::check(hefx_encrypt(e->ready({}), L, pk_.buf->p, plain.buf->p, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
+        shim::check(hefx_encrypt(e->ready({plain.buf.get()}), L, pk_.buf->p, plain.buf->p, rnd_.key.data(), rnd_.stream(), c->p, nullptr));
         dest.set(c, 2, L, plain.parms_id(), plain.scale());
     }
 
@@ -1422,6 +1635,7 @@ private:
     std::shared_ptr<SEALContext> ctx_;
     PublicKey pk_;
     shim::SamplerState rnd_;
+    mutable std::shared_ptr<std::array<std::uint8_t, 32>> key_;  // rnd_.key, shared with the recorded encryptions
 };
 
 class Decryptor {
@@ -1444,6 +1658,7 @@ public:
         shim::check(hefx_decrypt(e->ready({ct.buf.get()}), L, (int)ct.size(), ct.buf->p, sk_.buf->p, acc->p, nullptr));
         dest.buf = acc;
         dest.rows = L;
+        dest.view_words_ = 0;
         dest.parms_id() = ct.parms_id();
         dest.scale() = ct.scale();
         dest.zero_ = false;
@@ -1581,11 +1796,11 @@ public:
         }();
         if (!host_only && L <= 16 && n >= 1024) {  // inverse NTT, CRT, centring and the slot-root FFT on the GPU
             dest.resize(n / 2);
-            shim::check(hefx_ckks_decode(e->ready({}), L, plain.buf->p, 1, plain.scale(), dest.data(), nullptr, nullptr));
+            shim::check(hefx_ckks_decode(e->ready({plain.buf.get()}), L, plain.buf->p, 1, plain.scale(), dest.data(), nullptr, nullptr));
             return;
         }
         auto tmp = shim::new_buf(e, (std::size_t)L * n);
-        shim::check(hefx_copy(e->ready({}), tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
+        shim::check(hefx_copy(e->ready({plain.buf.get()}), tmp->p, plain.buf->p, (std::size_t)L * n * 8, nullptr));
         shim::check(hefx_ntt_inverse(e->ready({}), tmp->p, 1, L, 0, nullptr));
         const std::vector<std::uint64_t> co = shim::download(tmp);
         // CRT compose (Garner mixed radix -> little-endian limbs), centre, scale
@@ -1657,7 +1872,19 @@ private:
         const bool zero = mx * scale < 0.499, nonzero = std::sqrt(2.0 * ss) / (double)n * scale > 0.501;
         if (!zero && !nonzero) return false;
         auto &e = ctx_->engine();
+        if (e->lazy && !shim::sync_mode()) {
+            // recorded: the encodes of a loop (2000 one-hot masks in logistic_regression_ckks.cpp:222-225, 4018 vectors in
+            // front of the training loop) go to the device as one hefx_ckks_encode_batch per (level, length, scale)
+            shim::Engine::Node x{};
+            x.host = std::make_shared<std::vector<double>>(values);
+            x.scale = scale;
+            dest.buf = e->record(shim::Engine::Node::ENCODE, nullptr, nullptr, 0, L, (int)values.size(), (std::size_t)L * n, e, &x);
+            dest.view_words_ = 0;
+            finish(dest, L, id, scale, zero);
+            return true;
+        }
         dest.buf = shim::new_buf(e, (std::size_t)L * n);
+        dest.view_words_ = 0;
         shim::check(hefx_ckks_encode(e->ready({}), L, values.data(), nullptr, (int)values.size(), 1, scale, dest.buf->p, nullptr));
         finish(dest, L, id, scale, zero);
         return true;
@@ -1665,6 +1892,7 @@ private:
     void finish(Plaintext &dest, int L, const parms_id_type &id, double scale, bool zero) const
     {
         dest.rows = L;
+        dest.view_words_ = 0;
         dest.parms_id() = id;
         dest.scale() = scale;
         dest.zero_ = zero;
@@ -1929,7 +2157,7 @@ public:
         check_pt(a, p);
         if (!close(a.scale(), p.scale())) throw std::invalid_argument("scale mismatch");
         auto out = shim::new_buf(eng(), a.buf->words);
-        shim::check(hefx_add_plain(eng()->ready({a.buf.get()}), a.rows, (int)a.size(), a.buf->p, p.buf->p, out->p, nullptr));
+        shim::check(hefx_add_plain(eng()->ready({a.buf.get(), p.buf.get()}), a.rows, (int)a.size(), a.buf->p, p.buf->p, out->p, nullptr));
         dest.set(out, a.size(), a.rows, a.parms_id(), a.scale());
     }
     void add_plain_inplace(Ciphertext &a, const Plaintext &p) const { add_plain(a, p, a); }
@@ -2081,10 +2309,11 @@ public:
         if (!p.buf) throw std::invalid_argument("plain is not valid for encryption parameters");
         const int L = target_rows(p.rows, id);
         if (L == p.rows) return;
-        auto out = shim::new_buf(eng(), words(1, L));
-        shim::check(hefx_mod_drop(eng()->ready({}), p.rows, L, 1, p.buf->p, out->p, nullptr));
-        p.buf = out;
+        // a CKKS plaintext is [rows][N]: dropping its last primes is the PREFIX of the same payload -- no copy, no engine
+        // call, and a recorded encode (logistic_regression_ckks.cpp:225-227: encode, mod_switch_to_next, multiply_plain per
+        // observation row) stays recorded
         p.rows = L;
+        p.view_words_ = words(1, L);
         p.parms_id() = id;
     }
     void mod_switch_to_next_inplace(Ciphertext &a) const

@@ -650,9 +650,18 @@ def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequenc
                 acc, k = ev.add_pairs(acc, rotate_all(dups, k)), k + 1
         mults = acc
     else:
-        for _ in range(1, size):                                     # :472-476
-            dups = rotate_all(dups, 1)
-            mults = ev.add_pairs(mults, dups)
+        plan1 = ev.rotation_plan(1, gal_keys)
+        chain = getattr(be, "rotate_add_chain", None)
+        if chain is not None and len(plan1) == 1 and size > 1:
+            # :472-476 as ONE engine call (hefx_rotate_add_chain): the same key switches and sums level by level -- the
+            # oracle-backed twin of the tests runs the loop below, and the bits agree
+            elt, key = plan1[0], gal_keys.key(plan1[0])
+            _, sums = chain(L, [c.data for c in dups], [elt] * n, [key] * n, [m.data for m in mults], size - 1)
+            mults = [Ciphertext()._set(d, 2, L, m.scale) for d, m in zip(sums, mults)]
+        else:
+            for _ in range(1, size):                                 # :472-476
+                dups = rotate_all(dups, 1)
+                mults = ev.add_pairs(mults, dups)
     for m in mults:
         m.scale = 2.0 ** int(np.log2(m.scale))                       # :489 "manual rescale"
     return mults

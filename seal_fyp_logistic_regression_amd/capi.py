@@ -47,6 +47,7 @@ _SIGS = {
     "hefx_copy": (_i, [_vp, _vp, _vp, _sz, _vp]),
     "hefx_copy_peer": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "hefx_copy_peer_to": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
+    "hefx_device_memory": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "hefx_context_device": (_i, [_vp]),
     "hefx_memset_zero": (_i, [_vp, _vp, _sz, _vp]),
     "hefx_stream_sync": (_i, [_vp, _vp]),
@@ -66,6 +67,8 @@ _SIGS = {
     "hefx_apply_galois": (_i, [_vp, _i, _vp, _u32, _vp, _vp, _vp]),
     "hefx_apply_galois_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _vp]),
     "hefx_rotate_multiply_plain_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
+    "hefx_apply_galois_add_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _pp, _vp]),
+    "hefx_rotate_add_chain": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _pp, _i, _vp]),
     "hefx_relinearize": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "hefx_relinearize_batch": (_i, [_vp, _i, _i, _pp, _vp, _pp, _vp]),
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -92,12 +95,14 @@ _SIGS = {
                                                        _pp, _vp, _vp]),
     "hefx_linear_transform_plain_bsgs": (_i, [_vp, _i, _vp, _i, _i, _pp, _i, C.POINTER(_u32), _pp, _i, _vp, _vp]),
     "hefx_ckks_encode": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _vp, _vp]),
+    "hefx_ckks_encode_batch": (_i, [_vp, _i, _vp, _vp, _i, _i, C.c_double, _pp, _vp]),
     "hefx_sample_uniform": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_sample_ternary": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_sample_noise": (_i, [_vp, C.c_char_p, _u64, _i, _i, _i, _vp, _vp]),
     "hefx_keygen_kswitch": (_i, [_vp, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
     "hefx_galois_permute": (_i, [_vp, _u32, _vp, _i, _vp, _vp]),
     "hefx_encrypt": (_i, [_vp, _i, _vp, _vp, C.c_char_p, _u64, _vp, _vp]),
+    "hefx_encrypt_batch": (_i, [_vp, _i, _i, _vp, _pp, C.c_char_p, _u64, _pp, _vp]),
     "hefx_decrypt": (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp]),
     "hefx_ckks_decode": (_i, [_vp, _i, _vp, _i, C.c_double, _vp, _vp, _vp]),
     "hefx_event_create": (_i, [_vp, _pp]),
@@ -146,7 +151,7 @@ def check(rc: int) -> None:
 
 
 def ptr_array(ptrs):
-    arr = (C.c_void_p * len(ptrs))(*[int(p) for p in ptrs])
+    arr = (C.c_void_p * len(ptrs))(*[None if p is None else int(p) for p in ptrs])
     return arr
 
 

@@ -193,6 +193,7 @@ struct hefx_context {
     size_t pool_cached = 0, pool_cap = (size_t)64 << 30;          // bytes parked / allowed to stay parked (HEFX_POOL_MB)
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
+    KsItem *chain_items = nullptr;  // device descriptors of hefx_rotate_add_chain's two replayed levels
     hipEvent_t ring_ev[KS_RING] = {};
     bool ring_busy[KS_RING] = {};
     unsigned ring_next = 0;
@@ -445,6 +446,7 @@ extern "C" void hefx_context_destroy(hefx_context *c)
         if (c->ring_ev[s]) (void)hipEventDestroy(c->ring_ev[s]);
     if (c->h_items) (void)hipHostFree(c->h_items);
     if (c->d_items) (void)hipFree(c->d_items);
+    if (c->chain_items) (void)hipFree(c->chain_items);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -602,6 +604,15 @@ extern "C" int hefx_copy_peer_to(hefx_context *dst, void *d_dst, hefx_context *s
     return HEFX_OK;
 }
 extern "C" int hefx_context_device(const hefx_context *c) { return c ? c->device : -1; }
+extern "C" int hefx_device_memory(hefx_context *c, size_t *free_bytes, size_t *total_bytes)
+{
+    CTXCHK(c);
+    size_t f = 0, t = 0;
+    HIPCHK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return HEFX_OK;
+}
 extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
 {
     CTXCHK(c);
@@ -932,15 +943,19 @@ static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t
 // Chunks of a batch alternate between two internal streams (each with its own scratch half) so that the
 // small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
 // the next; the caller's stream is forked before and joined after.
+// acc_in / acc_out (both or neither; rotations without a fused plaintext only): acc_out[i] = acc_in[i] + ct_out[i]
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
-                  uint64_t *const *ct_out, void *stream, bool hoist = false)
+                  uint64_t *const *ct_out, void *stream, bool hoist = false, const uint64_t *const *acc_in = nullptr,
+                  uint64_t *const *acc_out = nullptr)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
     if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
     if (!relin && (!elts || !keys)) return fail(HEFX_ERR_INVALID, "missing Galois elements / keys");
     if (relin && !single_key) return fail(HEFX_ERR_INVALID, "missing relinearization key");
+    if ((acc_in != nullptr) != (acc_out != nullptr) || (acc_out && (relin || pts || hoist)))
+        return fail(HEFX_ERR_INVALID, "accumulate: rotations only, input and output sums together, no fused plaintext");
     const size_t per = ks_words_per_item(c, L);
     int chunk = c->chunk;
     if (chunk <= 0) {  // auto: about 1 GiB of scratch per in-flight chunk, multiple of 8, at most KS_MAX_CHUNK
@@ -992,7 +1007,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // submitted, on BYTE RANGES (callers hand out views of one allocation: big.view(...) slices): no two outputs may
     // overlap, and no input or plaintext may overlap another item's output -- nor its own, except the exact in-place
     // rotation c_in == c_out, which the kernels serve from a scratch copy.  O(n log n) on the host.
-    if (n > 1 || (pts && n == 1)) {
+    if (n > 1 || pts || acc_out) {
         const size_t row = (size_t)c->n * sizeof(u64);
         const size_t out_b = 2 * (size_t)L * row, in_b = (relin ? 3 : 2) * (size_t)L * row, pt_b = (size_t)L * row;
         std::vector<std::pair<uintptr_t, int>> outs((size_t)n);
@@ -1020,7 +1035,33 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
                 return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: one item's input overlaps an item's output");
             if (pts && pts[j] && hits(pts[j], pt_b, j, false))
                 return fail(HEFX_ERR_INVALID, "key-switch batch items must be independent: a plaintext overlaps an item's output");
+            if (acc_out && (hits(acc_in[j], out_b, -1, false) || hits(acc_out[j], out_b, -1, false)))
+                return fail(HEFX_ERR_INVALID, "accumulate: a sum overlaps a rotation output of the batch");
         }
+    }
+    if (acc_out) {  // the sums: pairwise disjoint, none overlapping any input; acc_in[i] == acc_out[i] (in place) is fine
+        const size_t out_b = 2 * (size_t)L * (size_t)c->n * sizeof(u64);
+        std::vector<std::pair<uintptr_t, int>> sums((size_t)n);
+        for (int i = 0; i < n; ++i) {
+            if (!acc_in[i] || !acc_out[i]) return fail(HEFX_ERR_INVALID, "null accumulator pointer in batch");
+            sums[(size_t)i] = {(uintptr_t)acc_out[i], i};
+        }
+        std::sort(sums.begin(), sums.end());
+        for (int i = 1; i < n; ++i)
+            if (sums[(size_t)i - 1].first + out_b > sums[(size_t)i].first)
+                return fail(HEFX_ERR_INVALID, "accumulate: two items write overlapping sums");
+        auto meets = [&](const void *p, int self, bool same_ok) {
+            const uintptr_t a = (uintptr_t)p;
+            auto it = std::upper_bound(sums.begin(), sums.end(), std::make_pair(a, n));
+            if (it != sums.begin()) {
+                const auto &o = *(it - 1);
+                if (o.first + out_b > a && !(same_ok && o.second == self && o.first == a)) return true;
+            }
+            return it != sums.end() && it->first < a + out_b;
+        };
+        for (int j = 0; j < n; ++j)
+            if (meets(ct_in[j], j, false) || meets(acc_in[j], j, true))
+                return fail(HEFX_ERR_INVALID, "accumulate: an input overlaps another item's sum");
     }
     // The items of a batch are independent, so they are PROCESSED grouped by key (stable order inside a group): items
     // that share a Galois key become neighbours -- the MAC loads the key once for two neighbours, and a chunk touches
@@ -1083,6 +1124,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.perm = relin ? nullptr : perms[j];
             it.elt = relin ? 1u : elts[j];
             it.flags = 0;
+            it.acc_in = acc_out ? (const u64 *)acc_in[j] : nullptr;
+            it.acc_out = acc_out ? (u64 *)acc_out[j] : nullptr;
             if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
                 it.c_in = S.alias + (size_t)i * 2 * L * N;
                 it.flags = KS_ALIASED;
@@ -1166,6 +1209,154 @@ extern "C" int hefx_rotate_multiply_plain_batch(hefx_context *c, int L, int n, c
         if (!pts[i]) return fail(HEFX_ERR_INVALID, "null plaintext pointer in batch");
     return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, pts, ct_out, stream);
 }
+extern "C" int hefx_apply_galois_add_batch(hefx_context *c, int L, int n, const uint64_t *const *ct_in,
+                                           const uint32_t *elts, const uint64_t *const *keys,
+                                           const uint64_t *const *acc_in, uint64_t *const *acc_out,
+                                           uint64_t *const *ct_out, void *stream)
+{
+    if (!acc_in || !acc_out) return fail(HEFX_ERR_INVALID, "missing accumulators");
+    return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, nullptr, ct_out, stream, false, acc_in, acc_out);
+}
+// ---------------------------------------------------------------------------------------------
+// helper.h:472-476 as ONE call:  for (s = 1 .. steps) { rotate_vector_inplace(dup, step, gal_keys); add_inplace(mult, dup); }
+// for n ciphertext pairs in lockstep (the eight weight chains of the LR gradient, logistic_regression_ckks.cpp:295-300:
+// 2000 levels each).  t_0 = ct_in, t_s = apply_galois(t_(s-1)), a_s = a_(s-1) + t_s; ct_out = t_steps, acc_out = a_steps;
+// the inputs are never written.  Every level is the key switch the op-by-op sequence runs (same descriptors, same
+// kernels, hence the same bits); what the call removes is the host: the intermediate rotations ping-pong between two
+// buffer sets, so the levels are two alternating launch sequences -- captured once as a HIP graph of two levels and
+// replayed (HEFX_CHAIN_GRAPH=0: plain launches), no validation, allocation or bookkeeping per level.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct ChainLevel {
+    const uint64_t *const *in;
+    uint64_t *const *out;
+};
+// one level on `s`, descriptors in the first launch's kernel arguments (n <= ks_small_max()); nothing is validated here
+hipError_t chain_level(hefx_context *c, int L, int n, const uint64_t *const *in, uint64_t *const *out,
+                       const uint64_t *const *acc_in, uint64_t *const *acc_out, const uint32_t *elts,
+                       const uint64_t *const *keys, const std::vector<const uint32_t *> &perms, const KsScratch &S,
+                       KsItem *db, int quarter, hipStream_t s)
+{
+    KsItem hb[64];
+    for (int i = 0; i < n; ++i) {
+        KsItem &it = hb[i];
+        it.c_in = (const u64 *)in[i];
+        it.c_out = (u64 *)out[i];
+        it.pt = nullptr;
+        it.key = (const u64 *)keys[i];
+        it.perm = perms[(size_t)i];
+        it.elt = elts[i];
+        it.flags = 0;
+        it.acc_in = (const u64 *)acc_in[i];
+        it.acc_out = (u64 *)acc_out[i];
+    }
+    return launch_keyswitch_chunk(c->T, L, n, db, false, S, n, false, false, hb, quarter, s, nullptr);
+}
+}  // namespace
+
+extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64_t *const *ct_in, const uint32_t *elts,
+                                     const uint64_t *const *keys, const uint64_t *const *acc_in,
+                                     uint64_t *const *acc_out, uint64_t *const *ct_out, int steps, void *stream)
+{
+    CTXCHK(c);
+    if (steps < 1) return fail(HEFX_ERR_INVALID, "a rotate-and-add chain needs at least one step");
+    if (!acc_in || !acc_out) return fail(HEFX_ERR_INVALID, "missing accumulators");
+    if (steps == 1)
+        return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, nullptr, ct_out, stream, false, acc_in, acc_out);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (n < 1 || !ct_in || !ct_out || !elts || !keys) return fail(HEFX_ERR_INVALID, "bad chain arguments");
+    // the two intermediate buffer sets (pooled; parked again when the call returns -- later users are ordered behind
+    // this call's work on the caller's stream, hefx_malloc's contract)
+    const size_t ctw = 2 * (size_t)L * c->n;
+    void *ws = nullptr;
+    if (int rc = hefx_malloc(c, 2 * (size_t)n * ctw * sizeof(u64), &ws)) return rc;
+    struct Parked {
+        hefx_context *c;
+        void *p;
+        ~Parked() { (void)hefx_free(c, p); }
+    } parked{c, ws};
+    std::vector<uint64_t *> A((size_t)n), B((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        A[(size_t)i] = (uint64_t *)ws + (size_t)i * ctw;
+        B[(size_t)i] = (uint64_t *)ws + ((size_t)n + i) * ctw;
+    }
+    // level 1 through the validating front door: ct_in -> A, acc_in -> acc_out; from then on the sums are in place
+    if (int rc = ks_run(c, L, n, false, ct_in, elts, keys, nullptr, nullptr, A.data(), stream, false, acc_in, acc_out)) return rc;
+    const int mid = steps - 2;  // levels 2 .. steps-1 alternate A -> B, B -> A; the last level writes ct_out
+    const uint64_t *const *lastsrc = (mid & 1) ? B.data() : A.data();
+    hipStream_t user = (hipStream_t)stream;
+    static const bool graph_ok = !(getenv("HEFX_CHAIN_GRAPH") && atoi(getenv("HEFX_CHAIN_GRAPH")) == 0);
+    if (n > ks_small_max() || n > 64) {  // wide chains: the regular batched path per level (descriptor ring, chunks)
+        for (int sidx = 0; sidx < mid; ++sidx) {
+            const bool ab = (sidx & 1) == 0;
+            if (int rc = ks_run(c, L, n, false, ab ? A.data() : B.data(), elts, keys, nullptr, nullptr, ab ? B.data() : A.data(),
+                                stream, false, acc_out, acc_out))
+                return rc;
+        }
+        return ks_run(c, L, n, false, lastsrc, elts, keys, nullptr, nullptr, ct_out, stream, false, acc_out, acc_out);
+    }
+    std::vector<const uint32_t *> perms((size_t)n);
+    for (int i = 0; i < n; ++i)
+        if (int rc = get_perm(c, elts[i], &perms[(size_t)i])) return rc;
+    // scratch as ks_run lays it out for one chunk on the caller's stream (level 1 has already sized it)
+    const size_t per = ks_words_per_item(c, L);
+    if (int rc = ensure_scratch(c, per * (size_t)n + ks_x_words(c, L, n))) return rc;
+    const size_t N = c->n;
+    KsScratch S;
+    S.d = c->scratch;
+    S.acc = S.d + (size_t)n * L * N;
+    S.u = S.acc + (size_t)n * 2 * (L + 1) * N;
+    S.x = S.u + (size_t)n * 2 * N;
+    S.alias = S.x + ks_x_words(c, L, n);
+    static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
+    static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
+    const int quarter = qmask_force >= 0    ? (qmask_force & KS_Q_ALL)
+                        : quarter_force >= 0 ? (quarter_force ? KS_Q_ALL : 0)
+                                             : ((n * L * 4 <= 256 ? KS_Q_INTT : 0) | (n * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
+                                                (n * 2 * 4 <= 192 ? KS_Q_MDI : 0) | (n * 2 * L * 4 <= 320 ? KS_Q_FIN : 0));
+    // the kernels after the first read the descriptors from device memory: a slot of their own per direction, so a
+    // replayed level never finds another call's descriptors there
+    if (!c->chain_items) HIPCHK(hipMalloc((void **)&c->chain_items, sizeof(KsItem) * 2 * 64));
+    KsItem *dbA = c->chain_items, *dbB = c->chain_items + 64;
+    auto level = [&](bool ab, hipStream_t s) {
+        return chain_level(c, L, n, ab ? A.data() : B.data(), ab ? B.data() : A.data(), acc_out, acc_out, elts, keys, perms, S,
+                           ab ? dbA : dbB, quarter, s);
+    };
+    const int pairs = mid / 2;
+    hipError_t herr = hipSuccess;
+    if (graph_ok && pairs >= 4) {
+        // legacy default streams cannot be captured: the chain runs on an internal stream, forked from and joined to the caller's
+        hipStream_t cs = c->streams[0];
+        HIPCHK(hipEventRecord(c->ev_fork, user));
+        HIPCHK(hipStreamWaitEvent(cs, c->ev_fork, 0));
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        herr = hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal);
+        if (herr == hipSuccess) {
+            hipError_t e1 = level(true, cs);
+            hipError_t e2 = e1 == hipSuccess ? level(false, cs) : e1;
+            herr = hipStreamEndCapture(cs, &graph);
+            if (e2 != hipSuccess) herr = e2;
+        }
+        if (herr == hipSuccess) herr = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        for (int r = 0; r < pairs && herr == hipSuccess; ++r) herr = hipGraphLaunch(exec, cs);
+        if (herr == hipSuccess && (mid & 1)) herr = level(true, cs);
+        if (herr == hipSuccess)
+            herr = chain_level(c, L, n, lastsrc, ct_out, acc_out, acc_out, elts, keys, perms, S, dbA, quarter, cs);
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        hipError_t ej = hipEventRecord(c->ev_join[0], cs);
+        if (ej == hipSuccess) ej = hipStreamWaitEvent(user, c->ev_join[0], 0);
+        if (herr == hipSuccess) herr = ej;
+    } else {
+        for (int sidx = 0; sidx < mid && herr == hipSuccess; ++sidx) herr = level((sidx & 1) == 0, user);
+        if (herr == hipSuccess)
+            herr = chain_level(c, L, n, lastsrc, ct_out, acc_out, acc_out, elts, keys, perms, S, dbA, quarter, user);
+    }
+    if (herr != hipSuccess) return hipfail(herr, "rotate-and-add chain");
+    return HEFX_OK;
+}
+
 extern "C" int hefx_relinearize(hefx_context *c, int L, const uint64_t *ct3, const uint64_t *key, uint64_t *ct2,
                                 void *stream)
 {
@@ -1199,9 +1390,10 @@ static int rescale_common(hefx_context *c, int L, int size, int count, const uin
 // Pointer tables of the *_batch entries travel through a ring slot of the key-switch descriptors (pinned host mirror
 // -> device copy, one async copy per slice).  fill(hp, i0, cnt) writes the slice's table; run(dp, cnt) launches on it.
 template <class Fill, class Run>
-static int table_slices(hefx_context *c, int n, int ptrs_per_item, hipStream_t s, Fill fill, Run run)
+static int table_slices(hefx_context *c, int n, int ptrs_per_item, hipStream_t s, Fill fill, Run run, int max_slice = 0)
 {
-    const int SLICE = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *)) / ptrs_per_item;
+    int SLICE = (int)(sizeof(KsItem) * KS_MAX_CHUNK / sizeof(void *)) / ptrs_per_item;
+    if (max_slice > 0 && SLICE > max_slice) SLICE = max_slice;
     for (int i0 = 0; i0 < n; i0 += SLICE) {
         const int cnt = n - i0 < SLICE ? n - i0 : SLICE;
         const unsigned slot = c->ring_next++ % KS_RING;
@@ -1589,6 +1781,41 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
     return HEFX_OK;
 }
 
+// the same for `count` vectors whose plaintexts are separately allocated (pointer table): slices of vectors are encoded
+// into engine scratch in one pass each and handed to their owners by one scatter launch -- the words hefx_ckks_encode
+// writes for each vector.  What the shim's recorder calls for the encodes it has collected (2000 one-hot masks inside the
+// reference's prediction loop, logistic_regression_ckks.cpp:222-225; 4018 in front of it).
+extern "C" int hefx_ckks_encode_batch(hefx_context *c, int L, const double *h_re, const double *h_im, int nvalues,
+                                      int count, double scale, uint64_t *const *d_outs, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (!d_outs || count < 1) return fail(HEFX_ERR_INVALID, "values has invalid size");
+    if (c->logn == 15) {  // out-of-place transform: vector by vector
+        for (int i = 0; i < count; ++i)
+            if (int rc = hefx_ckks_encode(c, L, h_re + (size_t)i * nvalues, h_im ? h_im + (size_t)i * nvalues : nullptr, nvalues, 1,
+                                          scale, d_outs[i], stream))
+                return rc;
+        return HEFX_OK;
+    }
+    for (int i = 0; i < count; ++i)
+        if (!d_outs[i]) return fail(HEFX_ERR_INVALID, "null output pointer in batch");
+    const size_t words = (size_t)L * c->n;
+    const int cap = 256;  // vectors per slice: 256 x L x N words of scratch
+    hipStream_t s = (hipStream_t)stream;
+    return table_slices(
+        c, count, 1, s, [&](const uint64_t **hp, int i0, int cnt) { for (int i = 0; i < cnt; ++i) hp[i] = d_outs[i0 + i]; },
+        [&](const u64 *const *dp, int i0, int cnt) -> hipError_t {
+            // (hefx_ckks_encode sizes its own staging; the scratch region is only this call's output area)
+            if (ensure_scratch(c, words * (size_t)cnt) != HEFX_OK) return hipErrorOutOfMemory;
+            if (hefx_ckks_encode(c, L, h_re + (size_t)i0 * nvalues, h_im ? h_im + (size_t)i0 * nvalues : nullptr, nvalues, cnt, scale,
+                                 (uint64_t *)c->scratch, s) != HEFX_OK)
+                return hipErrorUnknown;
+            return launch_scatter_rows(c->scratch, dp, cnt, words, s);
+        },
+        cap);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Linear_Transform_Plain (helper.h:237-262 = linear_transformation2.cpp:149-174) as ONE call: the rotation plans
 // (SEAL rotate_internal: the direct key if present, else the NAF terms of the step, App. A.7), their batching and
@@ -1906,8 +2133,8 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
         it.flags = 0;
         if (int rc = get_perm(c, plan[0], &it.perm)) return rc;
     }
-    items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr, 1u, 0u};
-    items[nterms] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out, 1u, 0u};
+    items[0] = KsItem{(const u64 *)ct_new, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 1u, 0u};
+    items[nterms] = KsItem{(const u64 *)cbuf, nullptr, nullptr, nullptr, (u64 *)out, nullptr, nullptr, 1u, 0u};
     // ---- ct_new = ct + rotate(ct, -d); cbuf = ct_new * diag_0
     const uint64_t *src = ct;
     for (size_t t = 0; t < first.size(); ++t) {
@@ -2037,6 +2264,55 @@ extern "C" int hefx_encrypt(hefx_context *c, int L, const uint64_t *pk, const ui
     }
     HIPCHK(launch_encrypt_combine(c->T, L, (const u64 *)pk, u, e, (const u64 *)plain, (u64 *)out, s));
     return HEFX_OK;
+}
+
+// n encryptions under one public key and sampler key, item i with stream id first_stream_id + i: what n hefx_encrypt
+// calls with those ids produce, word for word (the sampler is counter mode: item i's polynomials are polynomial 0 of the
+// sub-streams 4 (first + i) + {0, 1, 2}), as three sampling launches, one transform launch and one combine launch per
+// slice of items instead of five launches per item.  d_plains[i] may be NULL (encryption of zero); outputs through a
+// pointer table.  The 4018 + 2013 encode / encrypt calls in front of the reference's LR training loop
+// (logistic_regression_ckks.cpp:560-640) arrive here as a handful of calls (include/seal/seal.h records them).
+extern "C" int hefx_encrypt_batch(hefx_context *c, int L, int n, const uint64_t *pk, const uint64_t *const *plains,
+                                  const uint8_t *key32, uint64_t first_stream_id, uint64_t *const *outs, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_level(c, L)) return rc;
+    if (!pk || !key32 || !outs || n < 1) return fail(HEFX_ERR_INVALID, "bad encrypt arguments");
+    if ((first_stream_id + (uint64_t)n) >> 62) return fail(HEFX_ERR_INVALID, "stream id must be below 2^62");
+    for (int i = 0; i < n; ++i)
+        if (!outs[i]) return fail(HEFX_ERR_INVALID, "null output pointer in batch");
+    if (c->logn == 15) {  // the N = 32768 transform is out of place: item by item (no caller batches there yet)
+        for (int i = 0; i < n; ++i)
+            if (int rc = hefx_encrypt(c, L, pk, plains ? plains[i] : nullptr, key32, first_stream_id + (uint64_t)i, outs[i], stream))
+                return rc;
+        return HEFX_OK;
+    }
+    const size_t N = c->n, rowsz = (size_t)L * N;
+    hipStream_t s = (hipStream_t)stream;
+    const SampleKey k = sample_key(key32);
+    // slices of at most 256 items (3 polynomials of scratch each) and at most one pointer-table ring slot
+    const int cap = 256;
+    if (int rc = ensure_scratch(c, 3 * rowsz * (size_t)(n < cap ? n : cap))) return rc;
+    return table_slices(
+        c, n, 2, s,
+        [&](const uint64_t **hp, int i0, int cnt) {
+            for (int i = 0; i < cnt; ++i) {
+                hp[i] = plains ? plains[i0 + i] : nullptr;
+                hp[cnt + i] = outs[i0 + i];
+            }
+        },
+        [&](const u64 *const *dp, int i0, int cnt) -> hipError_t {  // cnt <= cap: one slice, one set of launches
+            u64 *u = c->scratch, *ee = u + (size_t)cnt * rowsz;
+            const uint64_t sid = 4 * (first_stream_id + (uint64_t)i0);
+            hipError_t e = launch_sample(c->T, SAMPLE_TERNARY, k, c->noise, sid + 0, cnt, L, 0, u, s, 4);
+            if (e == hipSuccess) e = launch_sample(c->T, SAMPLE_NOISE, k, c->noise, sid + 1, cnt, L, 0, ee, s, 4);
+            if (e == hipSuccess)
+                e = launch_sample(c->T, SAMPLE_NOISE, k, c->noise, sid + 2, cnt, L, 0, ee + (size_t)cnt * rowsz, s, 4);
+            if (e == hipSuccess) e = launch_ntt(c->T, false, u, 3 * cnt, L, 0, s);
+            if (e == hipSuccess) e = launch_encrypt_combine_table(c->T, L, cnt, (const u64 *)pk, u, ee, dp, s);
+            return e;
+        },
+        cap);
 }
 
 extern "C" int hefx_decrypt(hefx_context *c, int L, int size, const uint64_t *ct, const uint64_t *sk, uint64_t *out,

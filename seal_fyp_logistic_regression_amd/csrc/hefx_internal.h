@@ -56,6 +56,10 @@ struct KsItem {
     const uint32_t *perm;  // gather table of the Galois element (out[i] = in[perm[i]]), or nullptr for relin
     const u64 *pt;     // optional plaintext [L][N] multiplied into the result (fused multiply_plain)
     u64 *c_out;        // [2][L][N]
+    // optional accumulate (hefx_apply_galois_add_batch, helper.h:474-475 rotate_vector_inplace + add_inplace as one key
+    // switch): acc_out = acc_in + c_out, [2][L][N] each; acc_in == acc_out is the in-place sum; both null: none
+    const u64 *acc_in;
+    u64 *acc_out;
     uint32_t elt;      // Galois element of a rotation (the kernels compute the gather index from it); 0 / 1: identity
     uint32_t flags;    // KS_ALIASED: c_out is the caller's input as well -- c_in points at a scratch copy of it
 };
@@ -166,9 +170,14 @@ struct NoiseTable {
 };
 enum { SAMPLE_UNIFORM = 0, SAMPLE_TERNARY = 1, SAMPLE_NOISE = 2 };
 hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, const NoiseTable &tab, u64 stream,
-                         int npoly, int nrows, int mod_first, u64 *out, hipStream_t s);
+                         int npoly, int nrows, int mod_first, u64 *out, hipStream_t s, u64 stream_stride = 0);
 hipError_t launch_encrypt_combine(const DevTables &T, int L, const u64 *pk, const u64 *u, const u64 *e,
                                   const u64 *plain, u64 *out, hipStream_t s);
+// m encryptions: u [m][L][N], e [2][m][L][N], d_tab = m plaintext pointers (null allowed) | m output pointers
+hipError_t launch_encrypt_combine_table(const DevTables &T, int L, int m, const u64 *pk, const u64 *u, const u64 *e,
+                                        const u64 *const *d_tab, hipStream_t s);
+// dst[i][0..words) = src + i*words for i < n (device pointer table): contiguous batch results to their owners
+hipError_t launch_scatter_rows(const u64 *src, const u64 *const *d_tab, int n, size_t words, hipStream_t s);
 hipError_t launch_decrypt(const DevTables &T, int L, int size, const u64 *ct, const u64 *sk, u64 *out, hipStream_t s);
 hipError_t launch_keygen_combine(const DevTables &T, const u64 *sk, const u64 *new_sk, const u64 *a, const u64 *e,
                                  u64 *out, hipStream_t s);

@@ -369,6 +369,26 @@ __global__ __launch_bounds__(256) void multiply_table_kernel(DevTables T, int L,
     }
 }
 
+// tab[i][0..words) = src[i*words ..]: the contiguous results of a batched producer (hefx_ckks_encode over many vectors)
+// handed to their separately allocated owners in one launch
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const u64 *__restrict__ src, const u64 *const *__restrict__ tab,
+                                                           size_t pairs)
+{
+    const int i = blockIdx.y;
+    u64 *dst = const_cast<u64 *>(tab[i]);
+    const u64 *from = src + (size_t)i * pairs * 2;
+    for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < pairs; w += (size_t)gridDim.x * blockDim.x)
+        gst16(dst + 2 * w, *reinterpret_cast<const ulonglong2 *>(from + 2 * w));
+}
+hipError_t launch_scatter_rows(const u64 *src, const u64 *const *d_tab, int n, size_t words, hipStream_t s)
+{
+    const size_t pairs = words / 2;
+    int blocks = (int)((pairs + 255) / 256);
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks, n), dim3(256), 0, s, src, d_tab, pairs);
+    return hipGetLastError();
+}
+
 hipError_t launch_multiply_table(const DevTables &T, int L, const u64 *const *d_tab, int n, hipStream_t s)
 {
     const size_t pairs = (size_t)L * ((size_t)1 << T.logn) / 2;

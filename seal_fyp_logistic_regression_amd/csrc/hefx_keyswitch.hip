@@ -44,11 +44,7 @@ struct KsWaves {
     // (N = 8192 forward: two batches since round 3 -- with the lane-contiguous loader (eo_lane) one batch took the
     // 256-thread workgroups two registers past 128 and with them the fourth workgroup per CU; two batches + eo_lane:
     // digit NTTs 94 -> 87 us, mod-down finish 102 -> 98 us per chunk, profiles/r03/ab_c2_eo_lane.txt)
-#ifdef HEFX_NB_FWD
-    static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = HEFX_NB_FWD;
-#else
     static constexpr int NB_INV = (INV <= 2 && LOGN <= 13) ? 1 : 2, NB_FWD = (FWD <= 2 && LOGN < 13) ? 1 : 2;
-#endif
 };
 
 namespace hefx {
@@ -141,10 +137,7 @@ __device__ static __forceinline__ int eo_lane(int t)
 #ifdef HEFX_NO_EO_LANE  // A/B knob (tools/build_variant.sh): column t everywhere
 #define HEFX_EO_LANE(SC, t) (t)
 #else
-#ifndef HEFX_EO_LANE_MIN
-#define HEFX_EO_LANE_MIN 8192
-#endif
-#define HEFX_EO_LANE(SC, t) (SC::N >= HEFX_EO_LANE_MIN ? eo_lane<SC>(t) : (t))
+#define HEFX_EO_LANE(SC, t) (SC::N >= 8192 ? eo_lane<SC>(t) : (t))
 #endif
 
 // ------------------------------------------------------------------------------------------------
@@ -535,14 +528,11 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
 #pragma unroll
         for (int e = 0; e < NI; ++e) A[e].mac(P::xin(xb[e], true, cx), k, cx);
     }
-#ifndef HEFX_MAC_GROUP
-#define HEFX_MAC_GROUP 1
-#endif
-    // the other digits, HEFX_MAC_GROUP at a time: the operands of a whole group are requested up front in straight-line
+    // the other digits, G at a time (G = 1 measured best once the accesses were global, not FLAT -- profiles/EXPERIMENTS.md): the operands of a whole group are requested up front in straight-line
     // code, so the waits inside the group are COUNTED (digit g is accumulated while digits g+1.. are still in flight).
     // A software-pipelined rolled loop does not get that: the wait-count pass merges the pending loads that cross the
     // loop's back edge into s_waitcnt vmcnt(0).  Four covers the non-own digits of L = 5 in one group.
-    constexpr int G = HEFX_MAC_GROUP;
+    constexpr int G = 1;
     auto digit_at = [&](int r) { return r < jj ? r : r + 1; };  // r-th digit other than jj
     const int nd = jj < L ? L - 1 : L;
     int r0 = 0;
@@ -613,11 +603,8 @@ __device__ __forceinline__ void mac_unit(const DevTables &T, const KsItem *__res
     });
 }
 
-#ifndef HEFX_MAC_WAVES  // experiment knob: minimum waves per SIMD the MAC is register-allocated for (8 -> 64 VGPRs)
-#define HEFX_MAC_WAVES 1
-#endif
 template <bool STREAM>
-__global__ __launch_bounds__(256, HEFX_MAC_WAVES) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+__global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
                                                      int item0, int count, int int_only, KsScratch S)
 {
     // int_only: the FP64-policy target slots were accumulated by ks_ntt_macf_kernel; blockIdx.y counts the others
@@ -1002,27 +989,16 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
     u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
+    u64 keep[16];  // the outputs, for the optional accumulate behind the epilogue (dead otherwise)
     {
-        // Epilogue knobs (experiments; defaults are what the tree ships):
-        //   HEFX_EPI       operands fetched per group (2, 4, 8 or 16 of the thread's 16 coefficients)
-        //   HEFX_EPI_PIPE  1: the next group's operands are fetched before the current group is computed and stored;
-        //                  default in the 256-VGPR builds (N <= 8192), where the second buffer is free
+        // Operands are fetched in groups of four of the thread's sixteen coefficients; in the 256-VGPR builds (N <= 8192),
+        // where a second buffer is free, the next group is requested before the current one is computed and stored.
+        // (Groups of 2 / 8 / 16, pipelining everywhere or nowhere, separate settings for the FP64 rows: all measured,
+        // all within -1 .. -8 % of this -- profiles/EXPERIMENTS.md.)
         // Every ring size ends its forward transform in the pair layout idx_io (two adjacent words per lane, lanes
         // adjacent): 16-byte operand loads and stores, 1 KiB contiguous per instruction.
-#ifndef HEFX_EPI
-#define HEFX_EPI 4
-#endif
-#ifndef HEFX_EPI_PIPE
-#define HEFX_EPI_PIPE (KsWaves<LOGN>::FWD <= 2)
-#endif
-#ifndef HEFX_EPI_F64
-#define HEFX_EPI_F64 HEFX_EPI
-#endif
-#ifndef HEFX_EPI_F64_PIPE
-#define HEFX_EPI_F64_PIPE HEFX_EPI_PIPE
-#endif
-        constexpr int GS = A::IS_F64 ? HEFX_EPI_F64 : HEFX_EPI, NG = 16 / GS;
-        constexpr bool PIPE = A::IS_F64 ? HEFX_EPI_F64_PIPE : HEFX_EPI_PIPE;
+        constexpr int GS = 4, NG = 16 / GS;
+        constexpr bool PIPE = KsWaves<LOGN>::FWD <= 2;
         constexpr int NBUF = PIPE ? 2 : 1;
         // registers (r, r+1), r even, are one record: two adjacent words at an even index (idx_io), so the rotated c0
         // is fetched as one gathered 16-byte pair per record -- half the index arithmetic and loads of a per-word gather
@@ -1060,6 +1036,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                     o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], HP, cx, pinv, mc);
                     o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], HP, cx, pinv, mc);
                     gst16(dst + C::idx_io(t, GS * g + r), o);
+                    if constexpr (!HP) keep[GS * g + r] = o.x, keep[GS * g + r + 1] = o.y;
                 }
                 if (!PIPE && g + 1 < NG) fetch(g + 1, 0);
             }
@@ -1074,6 +1051,19 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                 epilogue(std::false_type{}, std::true_type{});
             else
                 epilogue(std::false_type{}, std::false_type{});
+        }
+        // accumulate (hefx_apply_galois_add_batch; never together with a fused plaintext product): acc_out = acc_in + out,
+        // one workgroup-uniform branch behind the epilogue, all loads of the thread requested before the first is used
+        if (it.acc_out && !pt) {
+            const size_t arow = ((size_t)c * L + j) * SC::N + off;
+            const u64 *__restrict__ ain = it.acc_in + arow;
+            u64 *__restrict__ aout = it.acc_out + arow;
+            ulonglong2 av[8];
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) av[r / 2] = gld16(ain + C::idx_io(t, r));
+#pragma unroll
+            for (int r = 0; r < 16; r += 2)
+                gst16(aout + C::idx_io(t, r), make_ulonglong2(addmod(av[r / 2].x, keep[r], q), addmod(av[r / 2].y, keep[r + 1], q)));
         }
     }
 }
@@ -1286,12 +1276,28 @@ __device__ __forceinline__ void moddown_finish_q_body(const DevTables &T, const 
             fetch();
         }
         HEFX_STAMP_AT(14);
+        u64 keep[8];
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
             ulonglong2 o;
             o.x = md_epilogue(A{}, f[r], a[r], sadd[r], pp[r], HP, cx, pinv, mc);
             o.y = md_epilogue(A{}, f[r + 1], a[r + 1], sadd[r + 1], pp[r + 1], HP, cx, pinv, mc);
             gst16(dst + C::idx_out(t, r), o);
+            keep[r] = o.x, keep[r + 1] = o.y;
+        }
+        if constexpr (!HP) {  // accumulate: acc_out = acc_in + out (see moddown_finish_body)
+            if (it.acc_out) {
+                const size_t arow = ((size_t)c * L + j) * QC::N + off;
+                const u64 *__restrict__ ain = it.acc_in + arow;
+                u64 *__restrict__ aout = it.acc_out + arow;
+                ulonglong2 av[4];
+#pragma unroll
+                for (int r = 0; r < 8; r += 2) av[r / 2] = gld16(ain + C::idx_out(t, r));
+#pragma unroll
+                for (int r = 0; r < 8; r += 2)
+                    gst16(aout + C::idx_out(t, r),
+                          make_ulonglong2(addmod(av[r / 2].x, keep[r], mc.q), addmod(av[r / 2].y, keep[r + 1], mc.q)));
+            }
         }
     };
     if (has_add) {

@@ -786,11 +786,7 @@ __device__ __forceinline__ void split_inv_a(u64 (&v)[16], const LDP &ldp, u64 *l
     // ... and for R >= 2 as well, where a lane would walk four or eight consecutive records (64 / 128 bytes) through its
     // loads: N = 32768 +1.3 % end to end, the two inverse kernels -10 % and -4 % (profiles/r03/ab_inverse_record_order.txt).
     // R == 1 (N = 16384: two records, 32 bytes per lane) keeps idx_out: the transposition costs what it saves there.
-#ifdef HEFX_INV_NAT  // A/B knob: 1 = for every remainder size, 0 = only where the core's layout demands it
-    constexpr bool NATREC = HEFX_INV_NAT != 0 || C::R == 0;
-#else
     constexpr bool NATREC = C::R != 1;
-#endif
     auto rec = [&](int r) { return NATREC ? C::idx_nat(t, r) : C::idx_out(t, r); };
 #pragma unroll
     for (int g = 0; g < NB; ++g) {

@@ -85,14 +85,17 @@ __global__ __launch_bounds__(256) void sample_uniform_kernel(DevTables T, Sample
 
 // grid (N/8/256, npoly): one signed draw per coefficient, written to every row as its residue.
 // NOISE = false: ternary; true: clipped normal via the threshold table
+// stride != 0 (hefx_encrypt_batch): polynomial p is polynomial 0 of sub-stream `stream + p * stride` -- the words n single
+// calls with those stream ids would draw
 template <bool NOISE>
-__global__ __launch_bounds__(256) void sample_small_kernel(DevTables T, SampleKey key, NoiseTable tab, u64 stream,
-                                                           int nrows, int mod_first, u64 *out)
+__global__ __launch_bounds__(256) void sample_small_kernel(DevTables T, SampleKey key, NoiseTable tab, u64 stream0,
+                                                           u64 stride, int nrows, int mod_first, u64 *out)
 {
     const size_t n = (size_t)1 << T.logn;
     const u64 blk = (u64)blockIdx.x * blockDim.x + threadIdx.x;
     if (blk >= n / 8) return;
-    const u64 poly = blockIdx.y;
+    const u64 slot = blockIdx.y;  // where the polynomial is stored
+    const u64 stream = stream0 + slot * stride, poly = stride ? 0 : slot;
     u64 r[8];
     int v[8];
     if (NOISE) {
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256) void sample_small_kernel(DevTables T, SampleKe
         u64 o[8];
 #pragma unroll
         for (int w = 0; w < 8; ++w) o[w] = v[w] < 0 ? q - (u64)(-v[w]) : (u64)v[w];
-        store8(out + (poly * nrows + j) * n + blk * 8, o);
+        store8(out + (slot * nrows + j) * n + blk * 8, o);
     }
 }
 
@@ -138,6 +141,30 @@ __global__ __launch_bounds__(256) void encrypt_combine_kernel(DevTables T, int L
         r.y = addmod(r.y, p.y, mc.q);
     }
     *reinterpret_cast<ulonglong2 *>(out + ((size_t)c * L + j) * n + w) = r;
+}
+
+// m encryptions at once: u [m][L][N], e [2][m][L][N], tab = m plaintext pointers (null: encryption of zero) | m outputs
+__global__ __launch_bounds__(256) void encrypt_combine_table_kernel(DevTables T, int L, int m, const u64 *__restrict__ pk,
+                                                                    const u64 *__restrict__ u, const u64 *__restrict__ e,
+                                                                    const u64 *const *__restrict__ tab)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const size_t w = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int j = blockIdx.y, item = blockIdx.z >> 1, c = blockIdx.z & 1;
+    const ModConst mc = T.mods[j];
+    const ulonglong2 a = *reinterpret_cast<const ulonglong2 *>(pk + ((size_t)c * T.k + j) * n + w);
+    const ulonglong2 uu = *reinterpret_cast<const ulonglong2 *>(u + ((size_t)item * L + j) * n + w);
+    const ulonglong2 ee = *reinterpret_cast<const ulonglong2 *>(e + (((size_t)c * m + item) * L + j) * n + w);
+    ulonglong2 r;
+    r.x = addmod(mulmod(a.x, uu.x, mc), ee.x, mc.q);
+    r.y = addmod(mulmod(a.y, uu.y, mc), ee.y, mc.q);
+    const u64 *plain = tab[item];
+    if (c == 0 && plain) {
+        const ulonglong2 p = gld16(plain + (size_t)j * n + w);
+        r.x = addmod(r.x, p.x, mc.q);
+        r.y = addmod(r.y, p.y, mc.q);
+    }
+    gst16(const_cast<u64 *>(tab[m + item]) + ((size_t)c * L + j) * n + w, r);
 }
 
 // out[j] = sum_p ct[p][j] * s[j]^p (Horner from the top), any size >= 1
@@ -216,7 +243,7 @@ hipError_t launch_galois_permute(const DevTables &T, const uint32_t *perm, const
 }
 
 hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, const NoiseTable &tab, u64 stream,
-                         int npoly, int nrows, int mod_first, u64 *out, hipStream_t s)
+                         int npoly, int nrows, int mod_first, u64 *out, hipStream_t s, u64 stream_stride)
 {
     const int n8 = (1 << T.logn) / 8;
     const dim3 block(256);
@@ -225,10 +252,10 @@ hipError_t launch_sample(const DevTables &T, int mode, const SampleKey &key, con
                            nrows, mod_first, out);
     else if (mode == SAMPLE_TERNARY)
         hipLaunchKernelGGL((sample_small_kernel<false>), dim3((n8 + 255) / 256, npoly), block, 0, s, T, key, tab,
-                           stream, nrows, mod_first, out);
+                           stream, stream_stride, nrows, mod_first, out);
     else
         hipLaunchKernelGGL((sample_small_kernel<true>), dim3((n8 + 255) / 256, npoly), block, 0, s, T, key, tab, stream,
-                           nrows, mod_first, out);
+                           stream_stride, nrows, mod_first, out);
     return hipGetLastError();
 }
 
@@ -238,6 +265,15 @@ hipError_t launch_encrypt_combine(const DevTables &T, int L, const u64 *pk, cons
     const int n2 = (1 << T.logn) / 2;
     hipLaunchKernelGGL(encrypt_combine_kernel, dim3((n2 + 255) / 256, L, 2), dim3(256), 0, s, T, L, pk, u, e, plain,
                        out);
+    return hipGetLastError();
+}
+
+hipError_t launch_encrypt_combine_table(const DevTables &T, int L, int m, const u64 *pk, const u64 *u, const u64 *e,
+                                        const u64 *const *d_tab, hipStream_t s)
+{
+    const int n2 = (1 << T.logn) / 2;
+    hipLaunchKernelGGL(encrypt_combine_table_kernel, dim3((n2 + 255) / 256, L, 2 * m), dim3(256), 0, s, T, L, m, pk, u, e,
+                       d_tab);
     return hipGetLastError();
 }
 

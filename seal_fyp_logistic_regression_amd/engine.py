@@ -269,6 +269,30 @@ class Engine:
             capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
+    def apply_galois_add_batch(self, L, cts, elts, keys, accs, outs=None, acc_outs=None, stream=None):
+        """outs[i] = apply_galois(cts[i]); acc_outs[i] = accs[i] + outs[i] in the same key switch (helper.h:474-475);
+        acc_outs=None: new buffers; pass acc_outs=accs for the in-place sum.  Returns (outs, acc_outs)."""
+        n = len(cts)
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
+        acc_outs = acc_outs if acc_outs is not None else self.empty_many(n, (2, L, self.N))
+        capi.check(capi.lib().hefx_apply_galois_add_batch(
+            self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
+            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([a.ptr for a in accs]),
+            capi.ptr_array([a.ptr for a in acc_outs]), capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs, acc_outs
+
+    def rotate_add_chain(self, L, cts, elts, keys, accs, steps, outs=None, acc_outs=None, stream=None):
+        """`steps` times (t = apply_galois(t); a += t) for every pair (cts[i], accs[i]) in lockstep -- the loop of
+        helper.h:472-476 as one call (hefx_rotate_add_chain).  Returns (final rotations, final sums); inputs untouched."""
+        n = len(cts)
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
+        acc_outs = acc_outs if acc_outs is not None else self.empty_many(n, (2, L, self.N))
+        capi.check(capi.lib().hefx_rotate_add_chain(
+            self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
+            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([a.ptr for a in accs]),
+            capi.ptr_array([a.ptr for a in acc_outs]), capi.ptr_array([o.ptr for o in outs]), int(steps), stream))
+        return outs, acc_outs
+
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs=None, stream=None):
         n = len(cts)
         outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
@@ -417,6 +441,18 @@ class Engine:
                                            stream_id, out.ptr, stream))
         return out
 
+    def encrypt_batch(self, L, pk, plains, key32: bytes, first_stream_id: int, outs=None, stream=None):
+        """n encryptions, item i with stream id first_stream_id + i: the words of n encrypt() calls (hefx_encrypt_batch);
+        plains[i] may be None (encryption of zero)"""
+        if len(key32) != 32:
+            raise ValueError("key32 must be 32 bytes")
+        n = len(plains)
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
+        capi.check(capi.lib().hefx_encrypt_batch(
+            self._h, L, n, pk.ptr, capi.ptr_array([p.ptr if p is not None else None for p in plains]), key32,
+            int(first_stream_id), capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
     def decrypt(self, L, size, ct, sk, out=None, stream=None):
         out = out if out is not None else DeviceArray(self, (L, self.N))
         capi.check(capi.lib().hefx_decrypt(self._h, L, size, ct.ptr, sk.ptr, out.ptr, stream))
@@ -433,6 +469,18 @@ class Engine:
         capi.check(capi.lib().hefx_ckks_encode(self._h, L, re.ctypes.data, im.ctypes.data if im is not None else None,
                                                nvalues, count, float(scale), out.ptr, stream))
         return out
+
+    def ckks_encode_batch(self, L, values, scale, outs=None, stream=None):
+        """values: [count][nvalues] -> `count` separately allocated [L][N] plaintexts (hefx_ckks_encode_batch)"""
+        v = np.atleast_2d(np.asarray(values))
+        count, nvalues = v.shape
+        re = np.ascontiguousarray(v.real, dtype=np.float64)
+        im = np.ascontiguousarray(v.imag, dtype=np.float64) if np.iscomplexobj(v) else None
+        outs = outs if outs is not None else self.empty_many(count, (L, self.N))
+        capi.check(capi.lib().hefx_ckks_encode_batch(
+            self._h, L, re.ctypes.data, im.ctypes.data if im is not None else None, nvalues, count, float(scale),
+            capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
 
     def ckks_decode(self, L, pt, scale, count=1, complex_out=True, stream=None):
         """[count][L][N] NTT-form plaintexts -> [count][N/2] slot values (complex, or real if complex_out=False)"""

@@ -182,6 +182,10 @@ class GpuBackend:
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts):
         return self.engine.rotate_multiply_plain_batch(L, cts, elts, keys, pts)
 
+    def rotate_add_chain(self, L, cts, elts, keys, accs, steps):
+        """`steps` x (t = apply_galois(t); a = a + t) per pair, in lockstep (helper.h:472-476 as one engine call)"""
+        return self.engine.rotate_add_chain(L, cts, elts, keys, accs, steps)
+
     def relinearize(self, L, ct3, key):
         return self.engine.relinearize(L, ct3, key)
 

@@ -52,3 +52,159 @@ def test_bench_two_ranks_a_dead_rank_ends_the_run_non_zero():
     assert r.returncode != 0
     assert dt < 180, f"the launcher took {dt:.0f} s to give up on a dead rank"
     assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")], "no result line from a failed run"
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# rotate + accumulate in one key switch, and the chain of them (helper.h:472-476)
+# ------------------------------------------------------------------------------------------------------------------
+def _engine_and_oracle(N, primes):
+    from oracle import oracle as O
+    from seal_fyp_logistic_regression_amd import Engine
+    return O.Oracle(N, primes), Engine(N, primes)
+
+
+def _key(o, seed):
+    return o.uniform(o.k, 2 * (o.k - 1), seed).reshape(o.k - 1, 2, o.k, o.N)
+
+
+@pytest.mark.parametrize("setname,L,n", [("C3", 5, 1), ("C3", 2, 8), ("C3", 5, 40), ("C2", 3, 7), ("C3", 3, 300)])
+def test_apply_galois_add_batch_bit_exact(setname, L, n):
+    """hefx_apply_galois_add_batch against the oracle's op-by-op sequence rotate (apply_galois) then add: the rotation AND
+    the sum, word for word.  n = 1 and 8: the small-batch path (descriptors in the kernel arguments, quarter-row kernels);
+    40: one split-2 chunk; 300: two chunks on the two internal streams, three keys (key-grouped order).  Separate output
+    sums first, then the in-place form (acc_out == acc_in) on top of the in-place rotation (ct_out == ct_in)."""
+    N, primes = C3 if setname == "C3" else C2
+    o, e = _engine_and_oracle(N, primes)
+    rng = np.random.default_rng(100 * L + n)
+    keys = [_key(o, 31 + i) for i in range(3)]
+    dkeys = [e.to_device(k) for k in keys]
+    if n <= 40:
+        cts = [o.uniform(L, 2, 1000 + i) for i in range(n)]
+        accs = [o.uniform(L, 2, 5000 + i) for i in range(n)]
+    else:  # device-drawn inputs keep the host side of the large case short
+        big = e.sample("uniform", bytes(range(32)), 9, 4 * n, L, 0).download().reshape(2 * n, 2, L, N)
+        cts, accs = list(big[:n]), list(big[n:])
+    elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
+    ki = [int(rng.integers(3)) for _ in range(n)]
+    dct, dacc = [e.to_device(c) for c in cts], [e.to_device(a) for a in accs]
+    outs, sums = e.apply_galois_add_batch(L, dct, elts, [dkeys[j] for j in ki], dacc)
+    check = range(n) if n <= 40 else sorted({0, 1, 127, 128, 255, 256, 257, 299} | set(int(x) for x in rng.integers(0, n, 12)))
+    want_rot = {i: o.apply_galois(cts[i], elts[i], keys[ki[i]]) for i in check}
+    for i in check:
+        assert (outs[i].download() == want_rot[i]).all(), ("rotation", i)
+        assert (sums[i].download() == o.add(accs[i], want_rot[i])).all(), ("sum", i)
+        assert (dacc[i].download() == accs[i]).all() and (dct[i].download() == cts[i]).all(), ("inputs untouched", i)
+    if n <= 40:  # in place: t = rot(t); a += t, twice
+        for _ in range(2):
+            e.apply_galois_add_batch(L, dct, elts, [dkeys[j] for j in ki], dacc, outs=dct, acc_outs=dacc)
+        for i in check:
+            t1 = want_rot[i]
+            t2 = o.apply_galois(t1, elts[i], keys[ki[i]])
+            assert (dct[i].download() == t2).all(), ("in-place rotation", i)
+            assert (dacc[i].download() == o.add(o.add(accs[i], t1), t2)).all(), ("in-place sum", i)
+
+
+def test_apply_galois_add_batch_refuses_overlapping_sums():
+    N, primes = C2
+    o, e = _engine_and_oracle(N, primes)
+    L = 3
+    dk = e.to_device(_key(o, 5))
+    cts = [e.to_device(o.uniform(L, 2, 10 + i)) for i in range(2)]
+    acc = e.to_device(o.uniform(L, 2, 20))
+    with pytest.raises(ValueError):
+        e.apply_galois_add_batch(L, cts, [3, 5], [dk, dk], [acc, acc], acc_outs=[acc, acc])   # two items, one sum
+    with pytest.raises(ValueError):
+        e.apply_galois_add_batch(L, cts, [3, 5], [dk, dk], [acc, acc], acc_outs=[cts[1], e.empty(2, L, N)])  # a sum over an input
+
+
+@pytest.mark.parametrize("setname,L,n,steps", [("C3", 2, 8, 1), ("C3", 2, 8, 2), ("C3", 2, 8, 3), ("C3", 2, 8, 12),
+                                               ("C3", 2, 8, 13), ("C3", 5, 1, 11), ("C2", 3, 3, 10), ("C3", 2, 40, 4)])
+def test_rotate_add_chain_bit_exact(setname, L, n, steps):
+    """hefx_rotate_add_chain = the loop of helper.h:472-476 (rotate_vector_inplace(dup, step); add_inplace(mult, dup)) for
+    n pairs in lockstep, against the oracle's loop: final rotation and final sum word for word, inputs untouched.  12 / 13
+    steps at n = 8, L = 2 is the shape of the LR gradient's chains (logistic_regression_ckks.cpp:295-300) and takes the
+    HIP-graph replay (an even and an odd count of middle levels); 1-3 steps the degenerate plans; n = 40 the wide path."""
+    N, primes = C3 if setname == "C3" else C2
+    o, e = _engine_and_oracle(N, primes)
+    keys = [_key(o, 61 + i) for i in range(2)]
+    dkeys = [e.to_device(k) for k in keys]
+    from seal_fyp_logistic_regression_amd.seal import galois_elt_from_step
+    elts = [galois_elt_from_step(1 if i % 2 == 0 else -2, N) for i in range(n)]
+    cts = [o.uniform(L, 2, 2000 + i) for i in range(n)]
+    accs = [o.uniform(L, 2, 6000 + i) for i in range(n)]
+    dct, dacc = [e.to_device(c) for c in cts], [e.to_device(a) for a in accs]
+    outs, sums = e.rotate_add_chain(L, dct, elts, [dkeys[i % 2] for i in range(n)], dacc, steps)
+    e.sync()
+    for i in (range(n) if n <= 8 else (0, 1, 17, 39)):
+        t, a = cts[i], accs[i]
+        for _ in range(steps):
+            t = o.apply_galois(t, elts[i], keys[i % 2])
+            a = o.add(a, t)
+        assert (outs[i].download() == t).all(), ("rotation", i)
+        assert (sums[i].download() == a).all(), ("sum", i)
+        assert (dct[i].download() == cts[i]).all() and (dacc[i].download() == accs[i]).all(), ("inputs untouched", i)
+
+
+def test_rotate_add_chain_without_graph_replay_bit_exact():
+    """HEFX_CHAIN_GRAPH=0 (plain launches instead of the captured two-level graph) gives the same words."""
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "from oracle import oracle as O\n"
+        "from seal_fyp_logistic_regression_amd import Engine\n"
+        "N, primes = %r\n"
+        "o, e = O.Oracle(N, primes), Engine(N, primes); L, n, steps = 2, 4, 12\n"
+        "key = o.uniform(o.k, 2*(o.k-1), 61).reshape(o.k-1, 2, o.k, o.N); dk = e.to_device(key)\n"
+        "cts = [o.uniform(L, 2, 2000+i) for i in range(n)]; accs = [o.uniform(L, 2, 6000+i) for i in range(n)]\n"
+        "outs, sums = e.rotate_add_chain(L, [e.to_device(c) for c in cts], [3]*n, [dk]*n, [e.to_device(a) for a in accs], steps)\n"
+        "ok = True\n"
+        "for i in range(n):\n"
+        "    t, a = cts[i], accs[i]\n"
+        "    for _ in range(steps):\n"
+        "        t = o.apply_galois(t, 3, key); a = o.add(a, t)\n"
+        "    ok = ok and bool((outs[i].download() == t).all()) and bool((sums[i].download() == a).all())\n"
+        "print('PARITY', ok)\n") % (ROOT, C3)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_CHAIN_GRAPH": "0"}, capture_output=True,
+                       text=True, timeout=600)
+    assert "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# batched encode / encrypt (what the C++ shim's recorder submits for a loop of encode + encrypt calls)
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("setname,L,n", [("C2", 3, 5), ("C3", 5, 300), ("C3", 2, 1)])
+def test_encrypt_batch_equals_single_encryptions_word_for_word(setname, L, n):
+    """hefx_encrypt_batch(first_stream_id = s) == n calls of hefx_encrypt with stream ids s, s+1, ... (same public key,
+    same sampler key): the sampler is counter mode, item i draws from the sub-streams 4(s+i)+{0,1,2}.  Integer work: bit
+    equality.  hefx_encrypt itself is pinned against the oracle's sampler in test_gpu_sampling.py; here additionally the
+    first, a middle and the last item of the batch against an oracle-side encryption.  300 items: two 256-item slices;
+    a None plaintext is an encryption of zero."""
+    N, primes = C3 if setname == "C3" else C2
+    o, e = _engine_and_oracle(N, primes)
+    k = len(primes)
+    key32 = bytes((11 * i + 5) & 0xFF for i in range(32))
+    pk = e.sample("uniform", bytes(range(32)), 3, 2, k, 0)
+    big = e.sample("uniform", bytes(range(32)), 4, n, L, 0)
+    plains = [big.view(i * L * N, (L, N)) for i in range(n)]
+    if n > 2:
+        plains[1] = None
+    s0 = 2 ** 33 + 7
+    outs = e.encrypt_batch(L, pk, plains, key32, s0)
+    for i in (range(n) if n <= 8 else (0, 1, 2, 127, 255, 256, 257, n - 1)):
+        single = e.encrypt(L, pk, plains[i], key32, s0 + i).download()
+        assert (outs[i].download() == single).all(), i
+
+
+@pytest.mark.parametrize("setname,L,count,nvalues", [("C2", 3, 7, 5), ("C3", 5, 300, 2000), ("C3", 3, 2, 8192)])
+def test_ckks_encode_batch_equals_contiguous_encode(setname, L, count, nvalues):
+    """hefx_ckks_encode_batch (separately allocated outputs through a pointer table) writes the words hefx_ckks_encode
+    writes for the same vectors -- the same kernels on the same inputs, then one scatter launch: bit equality."""
+    N, primes = C3 if setname == "C3" else C2
+    o, e = _engine_and_oracle(N, primes)
+    rng = np.random.default_rng(count)
+    vals = rng.uniform(-3, 3, (count, nvalues))
+    vals[0, :] = 0.0
+    vals[0, 0] = 1.0  # a one-hot mask, as in logistic_regression_ckks.cpp:222-225
+    want = e.ckks_encode(L, vals, 2.0 ** 40).download().reshape(count, L, N)
+    outs = e.ckks_encode_batch(L, vals, 2.0 ** 40)
+    for i in (range(count) if count <= 8 else (0, 1, 255, 256, count - 1)):
+        assert (outs[i].download() == want[i]).all(), i
