@@ -242,7 +242,7 @@ int main()
             e->live();
             e->lazy = lazy;
             const std::size_t old_budget = e->pend_budget;
-            e->pend_budget = budget;
+            e->pend_budget = e->pend_check = budget;
             vector<Ciphertext> results(rows);
             for (int i = 0; i < rows; i++) {
                 Ciphertext feat;
@@ -273,7 +273,7 @@ int main()
             Ciphertext diff;
             evaluator.sub(results[0], results[1], diff);
             e->lazy = true;
-            e->pend_budget = old_budget;
+            e->pend_budget = e->pend_check = old_budget;
             return std::make_tuple(shim::download(sum.buf), shim::download(diff.buf), recorded, sum.scale());
         };
         const auto lazy = run(true, (std::size_t)8192 << 20), eager = run(false, (std::size_t)8192 << 20),

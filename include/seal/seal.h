@@ -119,6 +119,12 @@ inline hefx_context *&sync_target()
     static thread_local hefx_context *ctx = nullptr;
     return ctx;
 }
+// wall-clock origin of the shim's timeline prints (SEAL_SHIM_STATS=2): the first time anything of the shim runs
+inline std::chrono::steady_clock::time_point process_epoch()
+{
+    static const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+    return t0;
+}
 inline bool sync_mode()
 {
     static const bool on = [] {
@@ -195,7 +201,7 @@ struct Engine {
     // (payloads are immutable shared device buffers), only its contents are late; level / scale / size bookkeeping and
     // every SEAL validity check happen eagerly, at the call, with SEAL's exceptions.  The graph runs when a result is
     // observed (decrypt, add_many, a download, any non-recorded member reading a recorded result) or when the recorded
-    // results exceed SEAL_SHIM_PENDING_MB (default 8192): nodes go to the device by dependency depth, all nodes of one
+    // results to be stored exceed SEAL_SHIM_PENDING_MB (default 8192): nodes go to the device by dependency depth, all nodes of one
     // depth, kind and level as ONE batched C-ABI call (hefx_apply_galois_batch, hefx_rotate_multiply_plain_batch,
     // hefx_multiply_batch, hefx_relinearize_batch, hefx_rescale_to_next_batch, hefx_add_batch, ...) -- the 2000 dot
     // products of the LR loop advance in lockstep.  Equal (source, Galois element, key) rotations are computed once; a
@@ -221,9 +227,9 @@ struct Engine {
         std::uint64_t stream_id = 0;
     };
     std::vector<Node> pend;
-    std::map<const std::uint64_t *, int> pend_dst;                                              // result buffer -> node
-    std::map<std::tuple<const std::uint64_t *, std::uint32_t, const std::uint64_t *>, int> pend_cse;  // rotations
-    std::size_t pend_bytes = 0, pend_budget = (std::size_t)8192 << 20;
+    std::map<const Buf *, int> pend_dst;                                                        // result buffer -> node
+    std::map<std::tuple<const Buf *, std::uint32_t, const Buf *>, int> pend_cse;                // rotations
+    std::size_t pend_bytes = 0, pend_budget = (std::size_t)8192 << 20, pend_check = (std::size_t)8192 << 20;
     std::string failed;  // a batched call of flush() failed: results recorded with it are garbage
     struct Stats {       // SEAL_SHIM_STATS=1 prints them when the process ends
         std::size_t flushes = 0, nodes = 0, calls = 0, levels = 0;
@@ -286,6 +292,7 @@ struct Engine {
 inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std::uint64_t> &primes)
 {
     static std::mutex mu;
+    (void)process_epoch();
     static auto *registry = new std::map<std::pair<std::uint32_t, std::vector<std::uint64_t>>, std::shared_ptr<Engine>>();
     std::lock_guard<std::mutex> lk(mu);
     auto key = std::make_pair(n, primes);
@@ -297,20 +304,27 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     int dev = 0;
     if (const char *d = std::getenv("HEFX_DEVICE")) dev = std::atoi(d);
     check(hefx_context_create(n, primes.data(), (int)primes.size(), dev, &e->ctx_raw));
+    if (std::getenv("SEAL_SHIM_STATS") && std::atoi(std::getenv("SEAL_SHIM_STATS")) > 1)
+        std::fprintf(stderr, "[seal shim] wall +%.3f s (cpu %.3f s) engine context for N=%u, %zu primes ready\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - process_epoch()).count(),
+                     (double)std::clock() / CLOCKS_PER_SEC, n, primes.size());
     if (const char *l = std::getenv("SEAL_SHIM_LAZY")) e->lazy = std::atoi(l) != 0;
     if (const char *nd = std::getenv("SEAL_SHIM_DEVICES")) e->ndev = std::max(1, std::min(64, std::atoi(nd)));
     // the one SEAL semantic that could not be verified offline: SEAL_SHIM_RESCALE=round switches
     // rescale_to_next from the floor division (3.4.x as App. A.9 reads it; default) to round-to-nearest (3.5+)
     if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
         check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "round" ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR));
-    {   // recorded results may hold up to a quarter of the device's memory (at most 64 GiB) before a submission is
-        // forced: the 2000-row loops of the LR driver (80 GB of intermediates at N = 16384, L = 8) then run as two or
-        // three lockstep submissions on a 288 GB MI355X instead of nine; SEAL_SHIM_PENDING_MB overrides
+    {   // results a submission will STORE may reach 8 GiB (a quarter of the device on a small one) before it is forced;
+        // elided results do not count (record()).  profiles/r04/lr_driver_pending_budget.txt has the measurements that led
+        // here: with every recorded result counted and allocated, 8 GiB cut the LR driver's eight gradient chains across
+        // two submissions (0.94 s), 16 GiB kept them together (0.69 s) but made every second back-to-back run wait 1.4 s
+        // for the driver to scrub the previous process's 20 GB, and 64 GiB spent 2.5 s allocating.
         std::size_t fr = 0, tot = 0;
         if (hefx_device_memory(e->ctx_raw, &fr, &tot) == HEFX_OK && tot)
-            e->pend_budget = std::min<std::size_t>((std::size_t)64 << 30, std::max<std::size_t>((std::size_t)1 << 30, tot / 4));
+            e->pend_budget = std::min<std::size_t>((std::size_t)8 << 30, std::max<std::size_t>((std::size_t)1 << 30, tot / 4));
+        e->pend_check = e->pend_budget;
     }
-    if (const char *m = std::getenv("SEAL_SHIM_PENDING_MB")) e->pend_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
+    if (const char *m = std::getenv("SEAL_SHIM_PENDING_MB")) e->pend_check = e->pend_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *m = std::getenv("SEAL_SHIM_REPLICA_MB")) e->replica_budget = (std::size_t)std::strtoull(m, nullptr, 10) << 20;
     if (const char *st = std::getenv("SEAL_SHIM_STATS")) {
         if (std::atoi(st)) {
@@ -330,28 +344,44 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
     return e;
 }
 
-// immutable device payload
+// immutable device payload.  The device memory behind it is allocated on FIRST USE of `p` (round 4): a recorded node's
+// result buffer exists as a handle from the moment of the call, but nodes that a submission runs inside another call and
+// never stores -- the rotation inside a fused product, the 2 x 1998 intermediate rotations and sums of every gradient chain
+// of the LR driver (16 GB at N = 16384) -- never ask for their address and so never take pool memory.
 struct Buf {
     std::shared_ptr<Engine> eng;
-    std::uint64_t *p = nullptr;
     std::size_t words = 0;
-    Buf(std::shared_ptr<Engine> e, std::size_t w) : eng(std::move(e)), p(eng->alloc(w)), words(w) {}
+    struct Ptr {
+        Buf *b;
+        operator std::uint64_t *() const { return b->get(); }
+        std::uint64_t *operator+(std::size_t off) const { return b->get() + off; }
+    } p;
+    Buf(std::shared_ptr<Engine> e, std::size_t w) : eng(std::move(e)), words(w), p{this} {}
     ~Buf()
     {
-        if (p) eng->release(p, words);
+        if (addr_) eng->release(addr_, words);
     }
     Buf(const Buf &) = delete;
     Buf &operator=(const Buf &) = delete;
+    std::uint64_t *get()
+    {
+        if (!addr_) addr_ = eng->alloc(words);
+        return addr_;
+    }
+    bool allocated() const { return addr_ != nullptr; }
+
+private:
+    std::uint64_t *addr_ = nullptr;
 };
 inline BufPtr new_buf(const std::shared_ptr<Engine> &e, std::size_t words) { return std::make_shared<Buf>(e, words); }
 
-inline bool Engine::pending(const Buf *b) const { return pend_dst.count(b->p) != 0; }
+inline bool Engine::pending(const Buf *b) const { return pend_dst.count(b) != 0; }
 
 inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, std::uint32_t elt, int L, int size,
                              std::size_t out_words, const std::shared_ptr<Engine> &self, const Node *extra)
 {
     if (kind == Node::ROT) {  // the same rotation of the same buffer with the same key: computed once
-        auto hit = pend_cse.find(std::make_tuple((const std::uint64_t *)a->p, elt, (const std::uint64_t *)b->p));
+        auto hit = pend_cse.find(std::make_tuple((const Buf *)a.get(), elt, (const Buf *)b.get()));
         if (hit != pend_cse.end() && pend[hit->second].L == L) return pend[hit->second].dst;
     }
     Node nd{kind, a, b, new_buf(self, out_words), elt, L, size, 0, 0, -1};
@@ -364,7 +394,7 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     const int idx = (int)pend.size();
     auto link = [&](const BufPtr &in, bool ct_input) {
         if (!in) return;
-        auto p = pend_dst.find(in->p);
+        auto p = pend_dst.find(in.get());
         if (p == pend_dst.end()) return;
         Node &src = pend[p->second];
         nd.depth = std::max(nd.depth, src.depth + 1);
@@ -378,11 +408,26 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
         link(b, false);  // the plaintext may be a recorded encode
     }
     pend.push_back(nd);
-    pend_dst[nd.dst->p] = idx;
-    if (kind == Node::ROT) pend_cse[std::make_tuple((const std::uint64_t *)a->p, elt, (const std::uint64_t *)b->p)] = idx;
+    pend_dst[nd.dst.get()] = idx;
+    if (kind == Node::ROT) pend_cse[std::make_tuple((const Buf *)a.get(), elt, (const Buf *)b.get())] = idx;
     pend_bytes += out_words * 8;
     BufPtr out = nd.dst;
-    if (pend_bytes > pend_budget || pend.size() > 400000) flush();  // bounded memory: run what is recorded
+    // bounded memory: run what is recorded once the results it will STORE exceed the budget.  Result buffers take memory
+    // only when a submission writes them (Buf is lazy), and the nodes a submission elides -- chain intermediates, rotations
+    // inside fused products -- never do: the eight 2000-level gradient chains of the LR driver record 16 GB of results and
+    // store 8 ciphertexts.  So when the recorded total passes the mark, the fusion plan says what would really be written.
+    if (pend_bytes > pend_check || pend.size() > 400000) {
+        std::size_t need = 0;
+        if (pend.size() <= 400000) {
+            const Fusion fz = plan_fusion(pend);
+            for (std::size_t i = 0; i < pend.size(); ++i)
+                if (!fz.unwritten[i]) need += pend[i].dst->words * 8;
+        }
+        if (need > pend_budget || pend.size() > 400000)
+            flush();
+        else
+            pend_check = pend_bytes + pend_budget / 4;  // look again after another quarter budget of recording
+    }
     // SEAL_SHIM_SYNC=1 promises a caller's chrono timers completed work: only the rotations and the products of the
     // linear-transform loops (helper.h:216-229, 252-257) stay recorded there -- their add_many observes them inside the
     // timed region; relinearize / rescale / add run (and are waited for) at the call
@@ -414,6 +459,7 @@ inline void Engine::flush()
     pend_dst.clear();
     pend_cse.clear();
     pend_bytes = 0;
+    pend_check = pend_budget;
     if (K.empty()) return;
     const auto t_start = std::chrono::steady_clock::now();
     int max_depth = 0;
@@ -429,8 +475,8 @@ inline void Engine::flush()
             std::vector<int> all(K.size());
             for (std::size_t i = 0; i < K.size(); ++i) all[i] = (int)i;
             submit_nodes(ctx_raw, stats, K, nodes_by_depth(K, all, max_depth), fz, 0, max_depth,
-                         [](const std::uint64_t *p_) { return p_; },
-                   [&](int i) { return K[i].dst->p; });
+                         [](const Buf *b_) -> const std::uint64_t * { return const_cast<Buf *>(b_)->get(); },
+                   [&](int i) -> std::uint64_t * { return K[i].dst->get(); });
         }
     } catch (const std::exception &ex) {
         // results recorded with the failed batch (and everything after it) were never computed: every later use of
@@ -442,7 +488,8 @@ inline void Engine::flush()
     stats.seconds += dt;
     static const bool verbose = std::getenv("SEAL_SHIM_STATS") && std::atoi(std::getenv("SEAL_SHIM_STATS")) > 1;
     if (verbose)
-        std::fprintf(stderr, "[seal shim] +%.3f s submission %zu: %zu operations, %d dependency levels, %.1f ms host time\n",
+        std::fprintf(stderr, "[seal shim] wall +%.3f s (cpu %.3f s) submission %zu: %zu operations, %d dependency levels, %.1f ms host time\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - process_epoch()).count(),
                      (double)std::clock() / CLOCKS_PER_SEC, stats.flushes, K.size(), max_depth + 1, dt * 1e3);
 }
 template <class In, class Out>
@@ -457,13 +504,13 @@ inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vect
     for (int depth = depth_first; depth <= depth_last; ++depth) {
         if (by_depth[depth].empty()) continue;
         // groups of this depth: (kind, fusion, L, size, shared key); fusion of a ROT: 0 none, 1 + multiply_plain, 2 + add
-        std::map<std::tuple<int, int, int, int, const std::uint64_t *>, std::vector<int>> groups;
+        std::map<std::tuple<int, int, int, int, const Buf *>, std::vector<int>> groups;
         // chains that start at this depth, in lockstep per (level, length): (L, steps) -> chain indices
         std::map<std::pair<int, int>, std::vector<int>> chain_groups;
         for (int i : by_depth[depth]) {
             const Node &k = K[i];
             if (fz.skip[i]) continue;  // runs inside another node's call
-            const std::uint64_t *shared = (k.kind == Node::RELIN || k.kind == Node::ENCRYPT) ? k.b->p : nullptr;
+            const Buf *shared = (k.kind == Node::RELIN || k.kind == Node::ENCRYPT) ? k.b.get() : nullptr;
             int f = 0;
             if (k.kind == Node::ROT) f = fz.mul_of[i] >= 0 ? 1 : (fz.add_of[i] >= 0 ? 2 : 0);
             groups[std::make_tuple((int)k.kind, f, k.L, k.size, shared)].push_back(i);
@@ -481,10 +528,10 @@ inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vect
             ++stats.calls;
             for (int ci : g.second) {
                 const auto &ch = fz.chains[ci];
-                va.push_back(in(ch.ct_in->p));
-                vb.push_back(in(K[ch.first_rot].b->p));
+                va.push_back(in(ch.ct_in));
+                vb.push_back(in(K[ch.first_rot].b.get()));
                 ve.push_back(K[ch.first_rot].elt);
-                vc.push_back(in(ch.acc_in->p));
+                vc.push_back(in(ch.acc_in));
                 vo.push_back(out(ch.last_rot));
                 vo2.push_back(out(ch.last_add));
             }
@@ -500,16 +547,16 @@ inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vect
             for (int i : gi) {
                 const Node &k = K[i];
                 if (kind == Node::ENCODE || kind == Node::ENCRYPT) continue;  // gather their own operands below
-                va.push_back(in(k.a->p));
-                if (k.b) vb.push_back(in(k.b->p));
+                va.push_back(in(k.a.get()));
+                if (k.b) vb.push_back(in(k.b.get()));
                 ve.push_back(k.elt);
                 if (kind == Node::ROT && f == 1) {
                     const Node &m = K[fz.mul_of[i]];
-                    vc.push_back(in(m.b->p));
+                    vc.push_back(in(m.b.get()));
                     vo.push_back(out(fz.mul_of[i]));
                 } else if (kind == Node::ROT && f == 2) {
                     const Node &ad = K[fz.add_of[i]];
-                    vc.push_back(in(ad.a.get() == k.dst.get() ? ad.b->p : ad.a->p));  // the sum's other operand
+                    vc.push_back(in(ad.a.get() == k.dst.get() ? ad.b.get() : ad.a.get()));  // the sum's other operand
                     vo.push_back(out(i));
                     vo2.push_back(out(fz.add_of[i]));
                 } else {
@@ -547,7 +594,7 @@ inline void submit_nodes(hefx_context *cx, Engine::Stats &stats, const std::vect
                         std::vector<const std::uint64_t *> plains;
                         std::vector<std::uint64_t *> outs;
                         for (std::size_t t = t0; t < t1; ++t) {
-                            plains.push_back(K[order[t]].a ? in(K[order[t]].a->p) : nullptr);
+                            plains.push_back(K[order[t]].a ? in(K[order[t]].a.get()) : nullptr);
                             outs.push_back(out(order[t]));
                         }
                         check(hefx_encrypt_batch(cx, L, (int)(t1 - t0), in(std::get<4>(g.first)), plains.data(),
@@ -612,13 +659,13 @@ inline Engine::Fusion Engine::plan_fusion(const std::vector<Node> &K) const
         fz.unwritten[i] = 1;  // the rotation inside a fused product is never stored
     }
     if (!fuse_add) return fz;
-    std::map<const std::uint64_t *, int> producer;
-    for (int i = 0; i < nk; ++i) producer[K[i].dst->p] = i;
+    std::map<const Buf *, int> producer;
+    for (int i = 0; i < nk; ++i) producer[K[i].dst.get()] = i;
     // the depth at which a node's result EXISTS: its own, or -- for a sum fused into a rotation -- the rotation's
     std::vector<int> eff_depth(nk);
     for (int i = 0; i < nk; ++i) eff_depth[i] = K[i].depth;
     auto depth_of = [&](const BufPtr &b) {  // -1: not produced by this submission
-        auto p = producer.find(b->p);
+        auto p = producer.find(b.get());
         return p == producer.end() ? -1 : eff_depth[p->second];
     };
     // rot_add: the first ADD (size 2, same level) that reads a rotation's result; its other operand must exist when the
@@ -630,7 +677,7 @@ inline Engine::Fusion Engine::plan_fusion(const std::vector<Node> &K) const
         if (ad.kind != Node::ADD || ad.size != 2 || ad.a.get() == ad.b.get()) continue;
         for (int side = 0; side < 2; ++side) {
             const BufPtr &rin = side ? ad.b : ad.a, &other = side ? ad.a : ad.b;
-            auto p = producer.find(rin->p);
+            auto p = producer.find(rin.get());
             if (p == producer.end()) continue;
             const int i = p->second;
             const Node &r = K[i];
@@ -647,16 +694,16 @@ inline Engine::Fusion Engine::plan_fusion(const std::vector<Node> &K) const
     // chains: pair (r', a') continues pair (r, a) when r' rotates r's result with the same element and key, a' adds r' to
     // a's sum, and nobody but these nodes holds r's result (node + a + r' = 3 references) or a's sum (node + a' = 2)
     std::vector<int> next_pair(nk, -1), has_prev(nk, 0);
-    std::map<const std::uint64_t *, int> rot_reading;  // buffer -> a paired ROT that rotates it (unique or -2)
+    std::map<const Buf *, int> rot_reading;  // buffer -> a paired ROT that rotates it (unique or -2)
     for (int i = 0; i < nk; ++i)
         if (K[i].kind == Node::ROT && fz.add_of[i] >= 0) {
-            auto ins = rot_reading.emplace(K[i].a->p, i);
+            auto ins = rot_reading.emplace(K[i].a.get(), i);
             if (!ins.second) ins.first->second = -2;
         }
     for (int i = 0; i < nk; ++i) {
         if (K[i].kind != Node::ROT || fz.add_of[i] < 0) continue;
         const Node &r = K[i], &a = K[fz.add_of[i]];
-        auto nx = rot_reading.find(r.dst->p);
+        auto nx = rot_reading.find(r.dst.get());
         if (nx == rot_reading.end() || nx->second < 0) continue;
         const int i2 = nx->second;
         const Node &r2 = K[i2], &a2 = K[fz.add_of[i2]];
@@ -732,8 +779,8 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
     const int nk = (int)K.size();
     // connected sub-graphs of the recorded dependencies (shared EXTERNAL inputs -- keys, the weight ciphertext -- do not
     // connect: they are replicated)
-    std::map<const std::uint64_t *, int> producer;
-    for (int i = 0; i < nk; ++i) producer[K[i].dst->p] = i;
+    std::map<const Buf *, int> producer;
+    for (int i = 0; i < nk; ++i) producer[K[i].dst.get()] = i;
     std::vector<int> root(nk);
     for (int i = 0; i < nk; ++i) root[i] = i;
     std::function<int(int)> find = [&](int x) { return root[x] == x ? x : root[x] = find(root[x]); };
@@ -741,7 +788,7 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
     for (int i = 0; i < nk; ++i)
         for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
             if (!*inp) continue;
-            auto p_ = producer.find((*inp)->p);
+            auto p_ = producer.find(inp->get());
             if (p_ != producer.end() && p_->second != i) unite(i, p_->second);
         }
     // cost of a sub-graph = its key switches (everything else is cheap); heaviest first onto the least loaded device
@@ -770,7 +817,7 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
     for (int i = 0; i < nk; ++i)
         for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
             if (!*inp) continue;
-            auto p_ = producer.find((*inp)->p);
+            auto p_ = producer.find(inp->get());
             if (p_ != producer.end()) ++inner[p_->second];
         }
     // per device > 0: result buffers of its nodes, replicas of the external inputs they read
@@ -821,13 +868,14 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
         };
         bool fits = true;
         for (int i : share[d]) {
-            if (!(tmp[i] = dev_alloc(K[i].dst->words * 8, false))) {
+            if (!fz.unwritten[i] && !(tmp[i] = dev_alloc(K[i].dst->words * 8, false))) {
                 fits = false;
                 break;
             }
             for (const BufPtr *inp : {&K[i].a, &K[i].b}) {
-                if (!*inp || producer.count((*inp)->p)) continue;
-                auto hit = rep.find((*inp)->p);
+                if (!*inp || producer.count(inp->get())) continue;
+                const std::uint64_t *home = (*inp)->get();  // an external input: it has content, hence an address
+                auto hit = rep.find(home);
                 if (hit != rep.end() && hit->second.owner.lock().get() == inp->get()) {
                     hit->second.used = submission;
                     continue;
@@ -842,8 +890,8 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
                     fits = false;
                     break;
                 }
-                check(hefx_copy_peer(cx, r_, ctx_raw, (*inp)->p, (*inp)->words * 8, nullptr));  // on the home stream
-                rep[(*inp)->p] = Replica{*inp, r_, (*inp)->words, submission};
+                check(hefx_copy_peer(cx, r_, ctx_raw, home, (*inp)->words * 8, nullptr));  // on the home stream
+                rep[home] = Replica{*inp, r_, (*inp)->words, submission};
                 replica_bytes[d] += (*inp)->words * 8;
                 copied_in = true;
             }
@@ -863,13 +911,14 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
             auto &rep = replicas[d];
             if (d == 0)
                 submit_nodes(cx, stats, K, by_depth[d], fz, depth, depth,
-                             [](const std::uint64_t *p_) { return p_; }, [&](int i) { return K[i].dst->p; });
+                             [](const Buf *b_) -> const std::uint64_t * { return const_cast<Buf *>(b_)->get(); },
+                             [&](int i) -> std::uint64_t * { return K[i].dst->get(); });
             else
                 submit_nodes(cx, stats, K, by_depth[d], fz, depth, depth,
-                             [&](const std::uint64_t *p_) -> const std::uint64_t * {
-                                 auto pr = producer.find(p_);
+                             [&](const Buf *b_) -> const std::uint64_t * {
+                                 auto pr = producer.find(b_);
                                  if (pr != producer.end()) return tmp[pr->second];
-                                 return rep.at(p_).p;
+                                 return rep.at(const_cast<Buf *>(b_)->get()).p;
                              },
                              [&](int i) { return tmp[i]; });
         }

@@ -4,6 +4,7 @@
 // compute entry point dispatches HIP kernels from hefx_kernels.hip or fails.
 #include "../../include/hefx.h"
 
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -517,7 +518,15 @@ extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
         int n = next;
         while (n > 1 && (size_t)n * rounded > ((size_t)256 << 20)) n >>= 1;
         void *base = nullptr;
+        const auto t_alloc = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&base, (size_t)n * rounded);
+        {   // a slab normally takes ~20 us; a driver that makes the caller wait (seen on this pool: seconds, with the process
+            // asleep) is worth a line on stderr -- it is not the engine's time
+            const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
+            if (ms > 100.0)
+                fprintf(stderr, "[hefx] hipMalloc of a %zu MiB pool slab took %.0f ms (pool holds %zu MiB in %zu slabs)\n",
+                        ((size_t)n * rounded) >> 20, ms, c->pool_cached >> 20, c->pool_slabs.size());
+        }
         if (e != hipSuccess) {  // out of memory: give back what is parked, then ask for a single block
             (void)hipGetLastError();
             pool_release(c);
@@ -958,9 +967,14 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         return fail(HEFX_ERR_INVALID, "accumulate: rotations only, input and output sums together, no fused plaintext");
     const size_t per = ks_words_per_item(c, L);
     int chunk = c->chunk;
-    if (chunk <= 0) {  // auto: about 1 GiB of scratch per in-flight chunk, multiple of 8, at most KS_MAX_CHUNK
+    if (chunk <= 0) {  // auto: about 1 GiB of scratch per in-flight chunk, multiple of 8, at most KS_AUTO_CHUNK
         chunk = (int)(((size_t)1 << 30) / (per * sizeof(u64)));
-        chunk = chunk > KS_MAX_CHUNK ? KS_MAX_CHUNK : (chunk < 16 ? 16 : chunk & ~7);
+        // ... and at most 256 items from N = 16384 on (2 workgroups per CU x 256 CUs: 256 items fill the chip in whole rounds
+        // in every launch; 384 / 512 measure the same at C3 and C5 and 3 % less at C4), 512 below (N = 8192: three or four
+        // 256-thread workgroups per CU, and five launches of ~60 us each per 256 items are mostly ramp and tail: 788 k ->
+        // 921 k ops/s at C2 with 512, 904 k / 910 k with 768 / 1024; profiles/r04/chunk_size_by_ring.txt)
+        const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
+        chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
     }
     const int nchunks = (n + chunk - 1) / chunk;
     const bool two = nchunks > 1 && c->use_streams && !c->profiling;
@@ -1223,8 +1237,8 @@ extern "C" int hefx_apply_galois_add_batch(hefx_context *c, int L, int n, const 
 // 2000 levels each).  t_0 = ct_in, t_s = apply_galois(t_(s-1)), a_s = a_(s-1) + t_s; ct_out = t_steps, acc_out = a_steps;
 // the inputs are never written.  Every level is the key switch the op-by-op sequence runs (same descriptors, same
 // kernels, hence the same bits); what the call removes is the host: the intermediate rotations ping-pong between two
-// buffer sets, so the levels are two alternating launch sequences -- captured once as a HIP graph of two levels and
-// replayed (HEFX_CHAIN_GRAPH=0: plain launches), no validation, allocation or bookkeeping per level.
+// buffer sets, so the levels are two alternating launch sequences issued from one loop -- no validation, allocation or
+// bookkeeping per level (HEFX_CHAIN_GRAPH=1: captured once as a HIP graph of two levels and replayed; measured slower).
 // ---------------------------------------------------------------------------------------------
 namespace {
 struct ChainLevel {
@@ -1285,7 +1299,11 @@ extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64
     const int mid = steps - 2;  // levels 2 .. steps-1 alternate A -> B, B -> A; the last level writes ct_out
     const uint64_t *const *lastsrc = (mid & 1) ? B.data() : A.data();
     hipStream_t user = (hipStream_t)stream;
-    static const bool graph_ok = !(getenv("HEFX_CHAIN_GRAPH") && atoi(getenv("HEFX_CHAIN_GRAPH")) == 0);
+    // HIP-graph replay of the two alternating levels: opt-in (HEFX_CHAIN_GRAPH=1).  Measured on MI355X / ROCm 7.2
+    // (tools/chain_latency.py, profiles/r04/chain_latency.txt): 60.3 us per level replayed against 53.9 us with plain
+    // launches at n = 8, L = 2 (52.4 / 46.6 at n = 1) -- the graph's kernel nodes are dispatched with larger gaps than
+    // back-to-back stream launches, and the host is not the bottleneck once the levels are issued from one C loop.
+    static const bool graph_ok = getenv("HEFX_CHAIN_GRAPH") && atoi(getenv("HEFX_CHAIN_GRAPH")) != 0;
     if (n > ks_small_max() || n > 64) {  // wide chains: the regular batched path per level (descriptor ring, chunks)
         for (int sidx = 0; sidx < mid; ++sidx) {
             const bool ab = (sidx & 1) == 0;

@@ -122,8 +122,8 @@ def test_apply_galois_add_batch_refuses_overlapping_sums():
 def test_rotate_add_chain_bit_exact(setname, L, n, steps):
     """hefx_rotate_add_chain = the loop of helper.h:472-476 (rotate_vector_inplace(dup, step); add_inplace(mult, dup)) for
     n pairs in lockstep, against the oracle's loop: final rotation and final sum word for word, inputs untouched.  12 / 13
-    steps at n = 8, L = 2 is the shape of the LR gradient's chains (logistic_regression_ckks.cpp:295-300) and takes the
-    HIP-graph replay (an even and an odd count of middle levels); 1-3 steps the degenerate plans; n = 40 the wide path."""
+    steps at n = 8, L = 2 is the shape of the LR gradient's chains (logistic_regression_ckks.cpp:295-300), an even and an odd
+    count of middle levels; 1-3 steps the degenerate plans; n = 40 the wide path."""
     N, primes = C3 if setname == "C3" else C2
     o, e = _engine_and_oracle(N, primes)
     keys = [_key(o, 61 + i) for i in range(2)]
@@ -145,8 +145,9 @@ def test_rotate_add_chain_bit_exact(setname, L, n, steps):
         assert (dct[i].download() == cts[i]).all() and (dacc[i].download() == accs[i]).all(), ("inputs untouched", i)
 
 
-def test_rotate_add_chain_without_graph_replay_bit_exact():
-    """HEFX_CHAIN_GRAPH=0 (plain launches instead of the captured two-level graph) gives the same words."""
+def test_rotate_add_chain_with_graph_replay_bit_exact():
+    """HEFX_CHAIN_GRAPH=1 (the two alternating levels captured as a HIP graph and replayed; opt-in, measured slower than
+    plain launches) gives the same words."""
     code = (
         "import sys; sys.path.insert(0, %r)\n"
         "from oracle import oracle as O\n"
@@ -163,7 +164,7 @@ def test_rotate_add_chain_without_graph_replay_bit_exact():
         "        t = o.apply_galois(t, 3, key); a = o.add(a, t)\n"
         "    ok = ok and bool((outs[i].download() == t).all()) and bool((sums[i].download() == a).all())\n"
         "print('PARITY', ok)\n") % (ROOT, C3)
-    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_CHAIN_GRAPH": "0"}, capture_output=True,
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_CHAIN_GRAPH": "1"}, capture_output=True,
                        text=True, timeout=600)
     assert "PARITY True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
@@ -208,3 +209,29 @@ def test_ckks_encode_batch_equals_contiguous_encode(setname, L, count, nvalues):
     outs = e.ckks_encode_batch(L, vals, 2.0 ** 40)
     for i in (range(count) if count <= 8 else (0, 1, 255, 256, count - 1)):
         assert (outs[i].download() == want[i]).all(), i
+
+
+def test_large_chunks_bit_exact_and_device_memory():
+    """HEFX_CHUNK above 256 (the descriptor ring's slots hold 512 items since round 4; the size rule itself still stops at
+    256): 600 items at N = 8192 as chunks of 512 + 88, a sample of outputs word for word against the oracle; and
+    hefx_device_memory reports a plausible device."""
+    code = (
+        "import sys, ctypes; sys.path.insert(0, %r)\n"
+        "import numpy as np\n"
+        "from oracle import oracle as O\n"
+        "from seal_fyp_logistic_regression_amd import Engine, capi\n"
+        "N, primes = %r\n"
+        "o, e = O.Oracle(N, primes), Engine(N, primes); L, n, k = 3, 600, len(primes)\n"
+        "key = e.sample('uniform', bytes(range(32)), 1, 2 * L, k, 0)\n"
+        "ct = e.sample('uniform', bytes(range(32)), 2, 2 * n, L, 0); pt = e.sample('uniform', bytes(range(32)), 3, n, L, 0)\n"
+        "cts = [ct.view(i * 2 * L * N, (2, L, N)) for i in range(n)]; pts = [pt.view(i * L * N, (L, N)) for i in range(n)]\n"
+        "outs = e.rotate_multiply_plain_batch(L, cts, [3] * n, [key] * n, pts)\n"
+        "hk = key.download().reshape(L, 2, k, N)\n"
+        "ok = all(bool((outs[i].download() == o.rotate_mulplain(cts[i].download(), 3, hk, pts[i].download())).all())\n"
+        "         for i in (0, 255, 256, 511, 512, 599))\n"
+        "f, t = ctypes.c_size_t(0), ctypes.c_size_t(0)\n"
+        "capi.check(capi.lib().hefx_device_memory(e._h, ctypes.byref(f), ctypes.byref(t)))\n"
+        "print('PARITY', ok, 'MEM', 0 < f.value <= t.value and t.value > (16 << 30))\n") % (ROOT, C2)
+    r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_CHUNK": "512"}, capture_output=True, text=True,
+                       timeout=600)
+    assert "PARITY True MEM True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
