@@ -575,7 +575,7 @@ def main():
         # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
         traffic, traffic_src = None, None
-        for rnd in ("r03", "r02", "r01"):
+        for rnd in ("r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_bench_pmc_traffic.json")
             if args.set == "C3" and os.path.exists(pmc):
                 try:
@@ -590,14 +590,16 @@ def main():
         # engine clock sampled during this run that is cycles of wall time per instruction and SIMD -- against ~5 cycles
         # of issue cost for this mix (4 for 32-bit ops, 4.75 v_fma_f64, 5.7 v_mad_u64_u32: profiles/r01_valu_issue_rates.txt)
         issue = None
-        sqf = os.path.join(ROOT, "profiles", "r03_bench_sq_counters.json")
+        sqf = os.path.join(ROOT, "profiles", "r04_bench_sq_counters.json")
+        if not os.path.exists(sqf):
+            sqf = os.path.join(ROOT, "profiles", "r03_bench_sq_counters.json")
         if args.set == "C3" and os.path.exists(sqf):
             try:
                 sq = json.load(open(sqf))
                 per_op = sum(v["SQ_INSTS_VALU"] / (v["launches"] * 256) for v in sq.values())  # 256 items per chunk launch
                 mhz = (board_rec or {}).get("sclk_mhz")
                 issue = {"valu_wave_instr_per_op": per_op,
-                         "source": "profiles/r03_bench_sq_counters.json (rocprofv3 --pmc SQ_INSTS_VALU of this command)",
+                         "source": f"profiles/{os.path.basename(sqf)} (rocprofv3 --pmc SQ_INSTS_VALU of this command)",
                          "sclk_mhz": mhz}
                 if mhz:
                     cyc = (dt / total_ops * world) * mhz * 1e6 * SIMDS / per_op

@@ -15,6 +15,10 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 C3 = (16384, [0xffffffffffd8001, 0xffffb20001, 0xffffc40001, 0xffffca8001, 0xffffe80001, 0xffffffffffe8001])
 C2 = (8192, [0xffffffffffe8001, 0xfffff4c001, 0xfffffdc001, 0xfffffffffffc001])
+C4 = (16384, [0xffffffffffd8001, 0xffff940001, 0xffffa78001, 0xffffaf8001, 0xffffb20001, 0xffffc40001, 0xffffca8001,
+              0xffffe80001, 0xffffffffffe8001])
+C5 = (32768, [0xfffffffff840001, 0xffff940001, 0xffffb20001, 0xffffc40001, 0xffffe80001, 0xffffffffffc0001])
+SETS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
 def _bench(extra_env, *flags, timeout=900):
@@ -67,13 +71,14 @@ def _key(o, seed):
     return o.uniform(o.k, 2 * (o.k - 1), seed).reshape(o.k - 1, 2, o.k, o.N)
 
 
-@pytest.mark.parametrize("setname,L,n", [("C3", 5, 1), ("C3", 2, 8), ("C3", 5, 40), ("C2", 3, 7), ("C3", 3, 300)])
+@pytest.mark.parametrize("setname,L,n", [("C3", 5, 1), ("C3", 2, 8), ("C3", 5, 40), ("C2", 3, 7), ("C3", 3, 300),
+                                         ("C4", 8, 3), ("C4", 7, 36), ("C5", 5, 2), ("C5", 5, 34)])
 def test_apply_galois_add_batch_bit_exact(setname, L, n):
     """hefx_apply_galois_add_batch against the oracle's op-by-op sequence rotate (apply_galois) then add: the rotation AND
     the sum, word for word.  n = 1 and 8: the small-batch path (descriptors in the kernel arguments, quarter-row kernels);
     40: one split-2 chunk; 300: two chunks on the two internal streams, three keys (key-grouped order).  Separate output
     sums first, then the in-place form (acc_out == acc_in) on top of the in-place rotation (ct_out == ct_in)."""
-    N, primes = C3 if setname == "C3" else C2
+    N, primes = SETS[setname]
     o, e = _engine_and_oracle(N, primes)
     rng = np.random.default_rng(100 * L + n)
     keys = [_key(o, 31 + i) for i in range(3)]
@@ -118,13 +123,14 @@ def test_apply_galois_add_batch_refuses_overlapping_sums():
 
 
 @pytest.mark.parametrize("setname,L,n,steps", [("C3", 2, 8, 1), ("C3", 2, 8, 2), ("C3", 2, 8, 3), ("C3", 2, 8, 12),
-                                               ("C3", 2, 8, 13), ("C3", 5, 1, 11), ("C2", 3, 3, 10), ("C3", 2, 40, 4)])
+                                               ("C3", 2, 8, 13), ("C3", 5, 1, 11), ("C2", 3, 3, 10), ("C3", 2, 40, 4),
+                                               ("C4", 7, 8, 5), ("C5", 5, 2, 4)])
 def test_rotate_add_chain_bit_exact(setname, L, n, steps):
     """hefx_rotate_add_chain = the loop of helper.h:472-476 (rotate_vector_inplace(dup, step); add_inplace(mult, dup)) for
     n pairs in lockstep, against the oracle's loop: final rotation and final sum word for word, inputs untouched.  12 / 13
     steps at n = 8, L = 2 is the shape of the LR gradient's chains (logistic_regression_ckks.cpp:295-300), an even and an odd
     count of middle levels; 1-3 steps the degenerate plans; n = 40 the wide path."""
-    N, primes = C3 if setname == "C3" else C2
+    N, primes = SETS[setname]
     o, e = _engine_and_oracle(N, primes)
     keys = [_key(o, 61 + i) for i in range(2)]
     dkeys = [e.to_device(k) for k in keys]
