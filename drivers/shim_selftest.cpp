@@ -1,6 +1,7 @@
 // shim_selftest.cpp -- exercises include/seal/seal.h the way the reference's drivers do (both API spellings) and
 // checks decrypted values and SEAL's error behaviour.  Exit code 0 = all checks passed.  Needs a HIP device.
 #include <cmath>
+#include <cstdlib>
 #include <iostream>
 
 #include "seal/seal.h"
@@ -299,7 +300,9 @@ int main()
             const std::size_t fused_calls = e->stats.calls - calls0;
             // (row 0's feature is an external ciphertext, rows 1 and 2 are rotations: two depth classes, each with its own
             // calls; call by call the loop is 3 x (5 + 2 x 11 + 2) = 87 engine calls)
-            CHECK(fused_calls <= 24, "the 3 x 11-level loop submits in <= 24 batched engine calls (87 call by call)");
+            const auto off = [](const char *name) { return getenv(name) && atoi(getenv(name)) == 0; };
+            if (!off("SEAL_SHIM_FUSE_ADD") && !off("SEAL_SHIM_CHAINS"))  // (the test suite also runs this file with them off)
+                CHECK(fused_calls <= 24, "the 3 x 11-level loop submits in <= 24 batched engine calls (87 call by call)");
             rows = 5, size = 4;
         }
         // several devices behind the same program (SEAL_SHIM_DEVICES): the rows are independent sub-graphs, dealt over

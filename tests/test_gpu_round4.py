@@ -241,3 +241,17 @@ def test_large_chunks_bit_exact_and_device_memory():
     r = subprocess.run([sys.executable, "-c", code], env={**os.environ, "HEFX_CHUNK": "512"}, capture_output=True, text=True,
                        timeout=600)
     assert "PARITY True MEM True" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
+
+
+@pytest.mark.parametrize("env", [{"SEAL_SHIM_CHAINS": "0"}, {"SEAL_SHIM_FUSE_ADD": "0"}, {"HEFX_CHAIN_GRAPH": "1"},
+                                 {"SEAL_SHIM_PENDING_MB": "64"}])
+def test_cpp_shim_selftest_with_the_fusions_switched_off(env):
+    """drivers/shim_selftest.cpp compares every recorded run with call-by-call execution bit for bit; here again with the
+    chain detection off (pairs go out as hefx_apply_galois_add_batch per level), with the pair fusion off (round 3's
+    rotate batch + add batch), with the chain levels replayed as a HIP graph, and with a 64 MB pending budget (submissions
+    forced in the middle of everything)."""
+    exe = os.path.join(ROOT, "drivers", "_ref", "shim_selftest")
+    if not os.path.exists(exe):
+        pytest.skip("drivers/_ref/shim_selftest is not built (make -C drivers)")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
+    assert r.returncode == 0 and "SELFTEST PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
