@@ -194,6 +194,8 @@ struct hefx_context {
     size_t pool_cached = 0, pool_cap = (size_t)64 << 30;          // bytes parked / allowed to stay parked (HEFX_POOL_MB)
     // descriptor ring: pinned host mirror + device copy + "slot free" events
     KsItem *h_items = nullptr, *d_items = nullptr;
+    u64 *lt_head = nullptr;  // ping / pong / ct_new / product 0 of hefx_linear_transform_plain (lt_ws: one ciphertext per node)
+    size_t lt_head_cap = 0;
     KsItem *chain_items = nullptr;  // device descriptors of hefx_rotate_add_chain's two replayed levels
     hipEvent_t ring_ev[KS_RING] = {};
     bool ring_busy[KS_RING] = {};
@@ -448,6 +450,7 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->h_items) (void)hipHostFree(c->h_items);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->chain_items) (void)hipFree(c->chain_items);
+    if (c->lt_head) (void)hipFree(c->lt_head);
     if (c->scratch) (void)hipFree(c->scratch);
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
@@ -1083,9 +1086,12 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // round-robin: without the grouping every neighbour pair differs (16 keys round-robin: 183 k against 214 k ops/s).
     std::vector<int> ord;
     if (!relin && n > 2) {
-        bool mixed = false;
-        for (int i = 1; i < n && !mixed; ++i) mixed = keys[i] != keys[0];
-        if (mixed) {
+        bool mixed = false, grouped = true;  // grouped: equal keys are already neighbours (non-decreasing addresses)
+        for (int i = 1; i < n; ++i) {
+            mixed = mixed || keys[i] != keys[0];
+            grouped = grouped && !std::less<const void *>()(keys[i], keys[i - 1]);
+        }
+        if (mixed && !grouped) {
             ord.resize((size_t)n);
             for (int i = 0; i < n; ++i) ord[(size_t)i] = i;
             std::stable_sort(ord.begin(), ord.end(), [&](int a, int b) { return std::less<const void *>()(keys[a], keys[b]); });
@@ -1843,9 +1849,35 @@ extern "C" int hefx_ckks_encode_batch(hefx_context *c, int L, const double *h_re
 // batch, (c) the last key switch of each plan is fused with its multiply_plain.
 // ---------------------------------------------------------------------------------------------
 namespace {
+// Galois element -> key payload.  A sorted vector (callers hand the elements over in increasing order: one pass, no
+// allocation per key), looked up by binary search: building an unordered_map of 512 keys was 30 us in front of the first
+// launch of every direct-key linear transform.
 struct LtKeys {
-    std::unordered_map<uint32_t, const uint64_t *> m;
-    bool has(uint32_t e) const { return m.count(e) != 0; }
+    std::vector<std::pair<uint32_t, const uint64_t *>> v;
+    void set(int n, const uint32_t *elts, const uint64_t *const *keys)
+    {
+        v.resize((size_t)n);
+        bool sorted = true;
+        for (int i = 0; i < n; ++i) {
+            v[(size_t)i] = {elts[i], keys[i]};
+            sorted = sorted && (i == 0 || elts[i - 1] < elts[i]);
+        }
+        if (!sorted) {  // later entries of an element win, like repeated assignment to a map
+            std::stable_sort(v.begin(), v.end(), [](const auto &a, const auto &b) { return a.first < b.first; });
+            size_t w = 0;
+            for (size_t i = 0; i < v.size(); ++i) {
+                if (i + 1 < v.size() && v[i + 1].first == v[i].first) continue;
+                v[w++] = v[i];
+            }
+            v.resize(w);
+        }
+    }
+    const uint64_t *at(uint32_t e) const
+    {
+        auto it = std::lower_bound(v.begin(), v.end(), e, [](const auto &a, uint32_t x) { return a.first < x; });
+        return it != v.end() && it->first == e ? it->second : nullptr;
+    }
+    bool has(uint32_t e) const { return at(e) != nullptr; }
 };
 uint32_t lt_elt_from_step(int step, size_t n)
 {
@@ -1901,14 +1933,43 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     for (int i = 0; i < d; ++i)
         if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
     LtKeys K;
-    for (int i = 0; i < nkeys; ++i) {
+    for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
-        K.m[key_elts[i]] = keys[i];
-    }
+    K.set(nkeys, key_elts, keys);
     const size_t N = c->n, ctw = 2 * (size_t)L * N;
-    // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
     std::vector<uint32_t> first;
     if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
+    // a missing key or a step too large must be reported before anything runs, like the op-by-op sequence would: plans of
+    // every step first (cheap), the node forest later -- while the GPU is already at work on ct_new
+    std::vector<std::vector<uint32_t>> plans((size_t)d);
+    for (int l = 1; l < d; ++l) {
+        if (const char *err = lt_plan(l, N, K, plans[(size_t)l])) return fail(HEFX_ERR_INVALID, err);
+        if (hoisted && plans[(size_t)l].size() != 1)
+            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
+    }
+    // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
+    if (c->lt_head_cap < 4 * ctw) {
+        HIPCHK(hipDeviceSynchronize());
+        if (c->lt_head) HIPCHK(hipFree(c->lt_head));
+        c->lt_head = nullptr;
+        c->lt_head_cap = 0;
+        HIPCHK(hipMalloc((void **)&c->lt_head, 4 * ctw * sizeof(u64)));
+        c->lt_head_cap = 4 * ctw;
+    }
+    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_head), *pong = ping + ctw, *ct_new = pong + ctw, *prod0 = ct_new + ctw;
+    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247): launched FIRST, so that the planning below (0.1 ms of host
+    // time at d = 512) runs beside it instead of in front of it
+    const uint64_t *src = ct;
+    for (size_t t = 0; t < first.size(); ++t) {
+        uint64_t *dst = (t & 1) ? pong : ping;
+        const uint64_t *key = K.at(first[t]);
+        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
+        src = dst;
+    }
+    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
+    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
+    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
+    // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
     struct Node {
         int parent;  // -1: ct_new
         uint32_t elt;
@@ -1916,19 +1977,19 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         int depth;
     };
     std::vector<Node> nodes;
-    std::map<std::tuple<int, uint32_t, int>, int> index;
+    // (parent node + 1, element, fused diagonal + 1) packed into 64 bits: parent < 2^22 nodes, element < 2^16 (N <= 32768),
+    // diagonal < 2^22
+    std::unordered_map<uint64_t, int> index;
+    index.reserve((size_t)d * 2);
+    nodes.reserve((size_t)d * 2);
     std::vector<int> leaf(d, -1);
     int max_depth = 0;
-    std::vector<uint32_t> plan;
     for (int l = 1; l < d; ++l) {
-        plan.clear();
-        if (const char *err = lt_plan(l, N, K, plan)) return fail(HEFX_ERR_INVALID, err);
-        if (hoisted && plan.size() != 1)
-            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
+        const std::vector<uint32_t> &plan = plans[(size_t)l];
         int cur = -1;
         for (size_t t = 0; t < plan.size(); ++t) {
             const int fused = t + 1 == plan.size() ? l : -1;
-            const auto key = std::make_tuple(cur, plan[t], fused);
+            const uint64_t key = ((uint64_t)(cur + 1) << 42) | ((uint64_t)plan[t] << 24) | (uint64_t)(fused + 1);
             auto it = index.find(key);
             if (it == index.end()) {
                 nodes.push_back(Node{cur, plan[t], fused, (int)t});
@@ -1939,30 +2000,18 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         }
         leaf[l] = cur;
     }
-    // ---- workspace: ping/pong for the first rotation chain, ct_new, product 0, one ciphertext per node
-    const size_t need = ctw * (4 + nodes.size());
+    // ---- workspace, part 2: one ciphertext per node
+    const size_t need = ctw * nodes.size();
     if (c->lt_cap < need) {
         HIPCHK(hipDeviceSynchronize());
         if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
         c->lt_ws = nullptr;
         c->lt_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lt_ws, need * sizeof(u64)));
+        HIPCHK(hipMalloc((void **)&c->lt_ws, (need ? need : 1) * sizeof(u64)));
         c->lt_cap = need;
     }
-    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw,
-             *prod0 = ct_new + ctw, *node0 = prod0 + ctw;
+    uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
     auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
-    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247)
-    const uint64_t *src = ct;
-    for (size_t t = 0; t < first.size(); ++t) {
-        uint64_t *dst = (t & 1) ? pong : ping;
-        const uint64_t *key = K.m[first[t]];
-        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
-        src = dst;
-    }
-    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
-    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
-    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
     // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth   (helper.h:252-257)
     std::vector<const uint64_t *> in, kk, pp;
     std::vector<uint64_t *> oo;
@@ -1975,7 +2024,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
                 if (nd.depth != depth || (nd.fused >= 0) != (fused != 0)) continue;
                 in.push_back(node_ptr(nd.parent));
                 ee.push_back(nd.elt);
-                kk.push_back(K.m[nd.elt]);
+                kk.push_back(K.at(nd.elt));
                 oo.push_back(node_ptr((int)i));
                 if (fused) pp.push_back(diag_pts[nd.fused]);
             }
@@ -2024,10 +2073,9 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
     for (int i = 0; i < d; ++i)
         if (!shifted_diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
     LtKeys K;
-    for (int i = 0; i < nkeys; ++i) {
+    for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
-        K.m[key_elts[i]] = keys[i];
-    }
+    K.set(nkeys, key_elts, keys);
     const size_t N = c->n, ctw = 2 * (size_t)L * N;
     std::vector<uint32_t> first, plan, belt, gelt;
     if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
@@ -2056,7 +2104,7 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
     const uint64_t *src = ct;
     for (size_t t = 0; t < first.size(); ++t) {
         uint64_t *dst = (t & 1) ? pong : ping;
-        const uint64_t *key = K.m[first[t]];
+        const uint64_t *key = K.at(first[t]);
         if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
         src = dst;
     }
@@ -2067,7 +2115,7 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
     if (n1 > 1) {
         for (int i = 1; i < n1; ++i) {
             in.push_back(ct_new);
-            kk.push_back(K.m[belt[i - 1]]);
+            kk.push_back(K.at(belt[i - 1]));
             oo.push_back(rots + (size_t)(i - 1) * ctw);
         }
         if (int rc = ks_run(c, L, n1 - 1, false, in.data(), belt.data(), kk.data(), nullptr, nullptr, oo.data(), stream,
@@ -2087,7 +2135,7 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
         in.clear(), kk.clear(), oo.clear();
         for (int j = 1; j < n2; ++j) {
             in.push_back(inner + (size_t)j * ctw);
-            kk.push_back(K.m[gelt[j - 1]]);
+            kk.push_back(K.at(gelt[j - 1]));
             oo.push_back(grot + (size_t)(j - 1) * ctw);
             res[j] = oo.back();
         }
@@ -2114,10 +2162,9 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     for (int i = 0; i < nterms; ++i)
         if (!diag_pts_keylevel[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
     LtKeys K;
-    for (int i = 0; i < nkeys; ++i) {
+    for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
-        K.m[key_elts[i]] = keys[i];
-    }
+    K.set(nkeys, key_elts, keys);
     const size_t N = c->n, ctw = 2 * (size_t)L * N;
     const int k = c->k, nrot = nterms - 1, chunks = nrot > 0 ? (nrot + lt2_chunk() - 1) / lt2_chunk() : 0;
     std::vector<uint32_t> first, plan;
@@ -2145,7 +2192,7 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
         KsItem &it = items[l];
         it.c_in = nullptr;
         it.c_out = nullptr;
-        it.key = (const u64 *)K.m[plan[0]];
+        it.key = (const u64 *)K.at(plan[0]);
         it.pt = (const u64 *)diag_pts_keylevel[l];
         it.elt = plan[0];
         it.flags = 0;
@@ -2157,7 +2204,7 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     const uint64_t *src = ct;
     for (size_t t = 0; t < first.size(); ++t) {
         uint64_t *dst = (t & 1) ? pong : ping;
-        const uint64_t *key = K.m[first[t]];
+        const uint64_t *key = K.at(first[t]);
         if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
         src = dst;
     }

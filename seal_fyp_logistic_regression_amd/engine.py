@@ -383,9 +383,11 @@ class Engine:
         out = out if out is not None else DeviceArray(self, (2, L, self.N))
         f = {False: capi.lib().hefx_linear_transform_plain, True: capi.lib().hefx_linear_transform_plain_hoisted,
              2: capi.lib().hefx_linear_transform_plain_hoisted2}[hoisted]
+        # key_elts / keys may be prebuilt C arrays (algorithms caches them per key set: a Galois-key set does not change)
+        karr = keys if isinstance(keys, C.Array) else capi.ptr_array([k.ptr for k in keys])
+        darr = diag_pts if isinstance(diag_pts, C.Array) else capi.ptr_array([p.ptr for p in diag_pts])
         capi.check(f(
-            self._h, L, ct.ptr, len(diag_pts), capi.ptr_array([p.ptr for p in diag_pts]), len(keys),
-            capi.u32_array(key_elts), capi.ptr_array([k.ptr for k in keys]), out.ptr, stream))
+            self._h, L, ct.ptr, len(darr), darr, len(karr), capi.u32_array(key_elts), karr, out.ptr, stream))
         return out
 
     def linear_transform_plain_hoisted2_sparse(self, L, ct, d, steps, diag_pts_keylevel, key_elts, keys, out=None,
