@@ -13,6 +13,7 @@
 #include <tuple>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <algorithm>
 #include <functional>
 #include <vector>
@@ -1101,7 +1102,20 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     const int cmax = n < chunk ? n : chunk;
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     const size_t x_words = ks_x_words(c, L, fused || sub > cmax ? cmax : sub);
-    const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
+    // Shared sources (ks_digit_permute_kernel): when at most a quarter as many DISTINCT source ciphertexts as items are
+    // rotated -- the d-1 rotations of a linear transform rotate ONE; with a source per 2-3 items the extra launch costs what
+    // it saves (profiles/r04/ab_shared_source.txt) -- every distinct source is inverse-transformed once per chunk
+    // and the items' digit rows are signed permutations of those.  Not for the small-batch latency path (one more launch),
+    // in-place rotations (their sources are per-item scratch copies), N = 32768 (the row does not fit LDS), the fused path.
+    static const bool share_ok = !(getenv("HEFX_SHARE_SRC") && atoi(getenv("HEFX_SHARE_SRC")) == 0);
+    bool share = share_ok && !relin && !hoist && !fused && !any_alias && c->logn <= 14 && n > ks_small_max() && sub >= cmax;
+    if (share) {
+        std::unordered_set<const void *> distinct;
+        for (int i = 0; i < n && distinct.size() * 4 <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
+        share = distinct.size() * 4 <= (size_t)n;
+    }
+    const size_t dsrc_words = share ? (size_t)(cmax / 4 + 1) * L * c->n : 0;
+    const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0) + dsrc_words;
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (two) {
@@ -1133,7 +1147,15 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.x = S.u + (size_t)cnt * 2 * N;
         S.alias = S.x + ks_x_words(c, L, fused || sub > cnt ? cnt : sub);
+        S.dsrc = S.alias + (any_alias ? (size_t)cnt * 2 * L * N : 0);
         bool chunk_alias = false;
+        int nsrc = 0;  // > 0: this chunk runs in shared-source mode with that many distinct sources
+        std::unordered_map<const void *, uint32_t> src_of;
+        if (share && cnt > ks_small_max()) {
+            for (int i = 0; i < cnt && src_of.size() * 4 <= (size_t)cnt; ++i)
+                src_of.emplace((const void *)ct_in[src(base + i)], (uint32_t)src_of.size());
+            if (src_of.size() * 4 <= (size_t)cnt && cnt + (int)src_of.size() <= KS_MAX_CHUNK) nsrc = (int)src_of.size();
+        }
         for (int i = 0; i < cnt; ++i) {
             KsItem &it = hb[i];
             const int j = src(base + i);
@@ -1146,6 +1168,13 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.flags = 0;
             it.acc_in = acc_out ? (const u64 *)acc_in[j] : nullptr;
             it.acc_out = acc_out ? (u64 *)acc_out[j] : nullptr;
+            it.dsrc = it.ginv = 0;
+            if (nsrc) {
+                it.dsrc = src_of[(const void *)ct_in[j]];
+                uint32_t e = it.elt ? it.elt : 1u, x = e;  // elt^-1 mod 2N (elt odd): Newton, doubling the correct bits
+                for (int r = 0; r < 5; ++r) x *= 2u - e * x;
+                it.ginv = x & (2u * (uint32_t)N - 1u);
+            }
             if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
                 it.c_in = S.alias + (size_t)i * 2 * L * N;
                 it.flags = KS_ALIASED;
@@ -1192,9 +1221,16 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
                 quarter = (cnt * L * 4 <= 256 ? KS_Q_INTT : 0) | (cnt * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
                           (cnt * 2 * 4 <= 192 ? KS_Q_MDI : 0) | (cnt * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
         }
-        if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * cnt, hipMemcpyHostToDevice, cs));
+        for (const auto &so : src_of) {  // the distinct sources, behind the items: only c_in and elt are read (noperm)
+            if (!nsrc) break;
+            KsItem &sd = hb[cnt + (int)so.second];
+            sd = KsItem{};
+            sd.c_in = (const u64 *)so.first;
+            sd.elt = 1u;
+        }
+        if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * (cnt + nsrc), hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, hoist, chunk_alias, small ? hb : nullptr,
-                                      quarter, cs, prof));
+                                      quarter, cs, prof, nsrc));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
 #undef KS_TRY
@@ -1332,6 +1368,7 @@ extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64
     S.u = S.acc + (size_t)n * 2 * (L + 1) * N;
     S.x = S.u + (size_t)n * 2 * N;
     S.alias = S.x + ks_x_words(c, L, n);
+    S.dsrc = nullptr;
     static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
     static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
     const int quarter = qmask_force >= 0    ? (qmask_force & KS_Q_ALL)
@@ -2223,6 +2260,7 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     S.u = S.acc + (size_t)2 * (L + 1) * N;
     S.x = S.u + (size_t)2 * N;
     S.alias = nullptr;
+    S.dsrc = nullptr;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(d_items, items.data(), sizeof(KsItem) * items.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));  // `items` is a local

@@ -62,6 +62,9 @@ struct KsItem {
     u64 *acc_out;
     uint32_t elt;      // Galois element of a rotation (the kernels compute the gather index from it); 0 / 1: identity
     uint32_t flags;    // KS_ALIASED: c_out is the caller's input as well -- c_in points at a scratch copy of it
+    // shared-source decomposition (ks_digit_permute_kernel): which entry of the chunk's source list this item rotates,
+    // and elt^-1 mod 2N
+    uint32_t dsrc, ginv;
 };
 constexpr uint32_t KS_ALIASED = 1;
 
@@ -95,6 +98,7 @@ struct KsScratch {
     u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
     u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
     u64 *alias;  // [chunk][2][L][N]   copies of the inputs of in-place rotations (c_in == c_out), else unused
+    u64 *dsrc;   // [sources][L][N]    shared-source mode: the digits of the chunk's DISTINCT source ciphertexts, unrotated
 };
 
 constexpr int ADD_MANY_GROUP = 48;
@@ -133,9 +137,11 @@ struct KsProf {
 // small_items != nullptr (host copy of the n <= ks_small_max() descriptors of a non-hoisted, non-aliasing chunk): the
 // descriptors are passed in the first launch's arguments; d_items is then written by that launch, not copied to
 // quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
+// nsrc > 0: shared-source mode -- d_items[n .. n + nsrc) describe the chunk's distinct source ciphertexts; their digits are
+// decomposed once (into scr.dsrc) and every item's digit rows are the coefficient-domain automorphism of its source's
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  int quarter, hipStream_t s, KsProf *prof);
+                                  int quarter, hipStream_t s, KsProf *prof, int nsrc = 0);
 // `quarter`: which of the four transform launches run on quarter-row workgroups
 constexpr int KS_Q_INTT = 1, KS_Q_NTT = 2, KS_Q_MDI = 4, KS_Q_FIN = 8, KS_Q_ALL = 15;
 int ks_small_max();

@@ -234,6 +234,50 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 }
 
 // ------------------------------------------------------------------------------------------------
+// (1s) SHARED SOURCES (round 4).  The rotations of a linear transform rotate ONE ciphertext by many steps
+// (helper.h:252-257: rotate_vector(ct_new, l) for l = 1..d-1), and (1) would inverse-transform the same row once per
+// item.  But INTT(perm_g(c1)) IS the automorphism X -> X^g of INTT(c1) in the coefficient domain: coefficient k goes to
+// position g k mod 2N, negated when that wraps past N -- exactly the canonical words SEAL's sequence produces (it applies
+// the Galois map in the NTT domain and the key switch transforms back; the polynomial, and so every canonical residue, is
+// the same).  So the distinct sources of a chunk are decomposed ONCE (ks_intt_digits_kernel with noperm, into S.dsrc) and
+// this kernel writes each item's digit rows as the signed permutation of its source's: the whole source row sits in LDS
+// (one parity half per workgroup: 64 KiB at N = 16384), read at an odd stride in 8-byte words (conflict-free), written
+// coalesced in the [evens | odds] layout the digit transforms read.  L inverse transforms per item become L row copies; same bits.
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(512) void ks_digit_permute_kernel(DevTables T, const KsItem *__restrict__ items, int L, KsScratch S)
+{
+    extern __shared__ __align__(16) u64 lds[];
+    constexpr uint32_t N = 1u << LOGN, H = N / 2;
+    // X -> X^g keeps the parity of a coefficient index (g is odd): the even half of the [evens | odds] row only reads the
+    // even half of the source and the odd half the odd one -- a workgroup owns one PARITY of one digit row (H words of LDS:
+    // 64 KiB at N = 16384, so two of these, or one and a transform workgroup, share a CU)
+    const int b = blockIdx.y, i = blockIdx.x >> 1;
+    const uint32_t par = blockIdx.x & 1;
+    const KsItem it = items[b];
+    const u64 q = T.mods[i].q;
+    const u64 *__restrict__ src = S.dsrc + ((size_t)it.dsrc * L + i) * N + (size_t)par * H;
+    u64 *__restrict__ dst = S.d + ((size_t)b * L + i) * N + (size_t)par * H;
+    for (uint32_t w = threadIdx.x; w < H / 2; w += 512) *reinterpret_cast<ulonglong2 *>(lds + 2 * w) = gld16(src + 2 * w);
+    __syncthreads();
+    const uint32_t ginv = it.ginv;
+    // output slot e of this half holds coefficient c = 2 e + par; its value is coefficient j = c ginv mod 2N of the source
+    // polynomial: +a_j for j < N, -a_(j - N) otherwise; j has c's parity, so a_(j mod N) sits at slot (j mod N) >> 1 of the
+    // same half -- read at stride ginv (odd) in 8-byte words: conflict-free
+    for (uint32_t e = 2 * threadIdx.x; e < H; e += 1024) {
+        u64 o[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const uint32_t c = 2 * (e + u) + par;
+            const uint32_t j = (c * ginv) & (2 * N - 1);
+            const u64 v = lds[(j & (N - 1)) >> 1];
+            o[u] = (j >> LOGN) && v ? q - v : v;
+        }
+        gst16(dst + e, make_ulonglong2(o[0], o[1]));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
@@ -1360,7 +1404,7 @@ static void set_lds(K kernel, size_t bytes)
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, int sub, bool hoist, bool alias,
-                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof)
+                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -1468,7 +1512,20 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL(ks_alias_copy_kernel, dim3(SC::N / 2 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L);
     }
     mark(1);
-    if (small)
+    if (nsrc > 0) {  // shared sources: decompose the distinct ones (descriptors batch[n..n+nsrc)), then one row copy per digit
+        if constexpr (LOGN <= 14) {
+            static PerDeviceOnce pattr;
+            if (pattr.first()) set_lds(ks_digit_permute_kernel<LOGN>, sizeof(u64) << (LOGN - 1));
+            KsScratch srcs = scr;
+            srcs.d = scr.dsrc;
+            hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(nsrc * L)), dim3(SC::T), lds_intt, s, T, batch + n, L,
+                               0, 1, nsrc * L, srcs);
+            hipLaunchKernelGGL((ks_digit_permute_kernel<LOGN>), dim3(2 * L, n), dim3(512), sizeof(u64) << (LOGN - 1), s, T, batch, L,
+                               scr);
+        } else {
+            return hipErrorInvalidValue;
+        }
+    } else if (small)
         hipLaunchKernelGGL((ks_intt_digits_small_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
     else
@@ -1624,7 +1681,7 @@ int lt2_chunk() { return LT2_CHUNK; }
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
-                                  int quarter, hipStream_t s, KsProf *prof)
+                                  int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
@@ -1634,7 +1691,7 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
         small = &sm;
     }
     if (T.logn < 12) quarter = 0;  // quarter rows of N = 2048 would be half-wave workgroups
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof, nsrc)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

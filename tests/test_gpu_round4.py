@@ -255,3 +255,35 @@ def test_cpp_shim_selftest_with_the_fusions_switched_off(env):
         pytest.skip("drivers/_ref/shim_selftest is not built (make -C drivers)")
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300, env={**os.environ, **env})
     assert r.returncode == 0 and "SELFTEST PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("setname,L,n,nsrc", [("C3", 5, 100, 3), ("C2", 3, 600, 1), ("C3", 2, 72, 18), ("C3", 2, 70, 35),
+                                              ("C4", 8, 40, 2)])
+def test_shared_source_decomposition_bit_exact(setname, L, n, nsrc):
+    """Batches in which many items rotate the SAME ciphertext (the d-1 rotations of Linear_Transform_Plain, helper.h:252-257)
+    run in shared-source mode: the distinct sources are inverse-transformed once per chunk and every item's digit rows are
+    the coefficient-domain automorphism of its source's (ks_digit_permute_kernel) -- the canonical words of
+    INTT(perm_g(c1)), hence SEAL's bits.  Mixed elements (incl. conjugation 2N-1 and large ones), two keys, with and
+    without the fused plaintext product, sources interleaved; every output (a sample at n = 600) against the oracle, which
+    decomposes every item on its own.  n = 600 at N = 8192: two chunks; nsrc = n/4: the boundary case of the mode; nsrc = n/2:
+    the same inputs through the ordinary per-item decomposition."""
+    N, primes = SETS[setname]
+    o, e = _engine_and_oracle(N, primes)
+    rng = np.random.default_rng(7 * n + nsrc)
+    keys = [_key(o, 91 + i) for i in range(2)]
+    dkeys = [e.to_device(k) for k in keys]
+    srcs = [o.uniform(L, 2, 3000 + i) for i in range(nsrc)]
+    dsrcs = [e.to_device(c) for c in srcs]
+    pts = [o.uniform(L, 1, 4000 + i)[0] for i in range(min(n, 8))]
+    dpts = [e.to_device(p) for p in pts]
+    si = [int(rng.integers(nsrc)) for _ in range(n)]
+    elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
+    elts[0], elts[-1] = 2 * N - 1, 3
+    ki = [int(rng.integers(2)) for _ in range(n)]
+    outs = e.rotate_multiply_plain_batch(L, [dsrcs[s] for s in si], elts, [dkeys[k] for k in ki], [dpts[i % len(pts)] for i in range(n)])
+    plain = e.apply_galois_batch(L, [dsrcs[s] for s in si], elts, [dkeys[k] for k in ki])
+    for i in (range(n) if n <= 100 else sorted({0, 1, 255, 256, 511, 512, 513, n - 1} | set(int(x) for x in rng.integers(0, n, 10)))):
+        assert (outs[i].download() == o.rotate_mulplain(srcs[si[i]], elts[i], keys[ki[i]], pts[i % len(pts)])).all(), ("fused", i)
+        assert (plain[i].download() == o.apply_galois(srcs[si[i]], elts[i], keys[ki[i]])).all(), ("plain", i)
+    for s in range(nsrc):
+        assert (dsrcs[s].download() == srcs[s]).all(), "sources untouched"
