@@ -91,6 +91,13 @@ int hefx_context_device(const hefx_context *ctx);
 /* free and total memory of that device in bytes (hipMemGetInfo; blocks parked in the context's pool count as used):
  * what a host side sizes its budgets with (the shim's pending-results budget is a quarter of the device) */
 int hefx_device_memory(hefx_context *ctx, size_t *free_bytes, size_t *total_bytes);
+/* How many key-switch chunks of this context were REDONE item by item so far: batches that rotate few distinct
+ * ciphertexts many times (the d-1 rotations of Linear_Transform_Plain, /root/reference/helper.h:252-257) run exactly
+ * hoisted -- the source is decomposed once per chunk -- which covers every input except a source whose c1 has a zero
+ * coefficient in some RNS component (a transparent or hand-made ciphertext); such a chunk falls back on the device to
+ * the per-item sequence, same bits either way.  Waits for the device.  A diagnostic: tests assert 0 on random inputs
+ * (the fast path ran) and > 0 on planted zeros (the fallback ran). */
+int hefx_ks_fallback_count(hefx_context *ctx, uint64_t *chunks);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
 int hefx_stream_sync(hefx_context *ctx, void *stream);
 

@@ -147,6 +147,13 @@ struct hefx_context {
     void *d_tables = nullptr;  // one allocation holding tw, itw, mods, invmod, halfmod
     std::mutex mu;
     std::unordered_map<uint32_t, uint32_t *> perm;  // Galois element -> device gather table
+    // exact hoisting (ks_mac_exact_kernel): Galois element -> NTT_m(flip mask) rows [k][N], built on first use, several
+    // elements per allocation; q_i mod q_m [k][k]; one gate word per descriptor-ring slot + the count of chunks redone
+    std::unordered_map<uint32_t, u64 *> flipw;
+    std::vector<void *> flipw_slabs;
+    u64 *d_qmod = nullptr;
+    uint32_t *d_gate = nullptr;
+    uint32_t gate_seq = 0;
     // scratch (grown on demand, reused across calls so it stays cache-resident)
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
@@ -392,6 +399,15 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
     for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
+    if (e == hipSuccess) {
+        std::vector<u64> qm((size_t)k * k);
+        for (int i = 0; i < k; ++i)
+            for (int m = 0; m < k; ++m) qm[(size_t)i * k + m] = c->primes[(size_t)i] % c->primes[(size_t)m];
+        e = hipMalloc((void **)&c->d_qmod, qm.size() * sizeof(u64));
+        if (e == hipSuccess) e = hipMemcpy(c->d_qmod, qm.data(), qm.size() * sizeof(u64), hipMemcpyHostToDevice);
+        if (e == hipSuccess) e = hipMalloc((void **)&c->d_gate, sizeof(uint32_t) * (KS_RING + 1));
+        if (e == hipSuccess) e = hipMemset(c->d_gate, 0, sizeof(uint32_t) * (KS_RING + 1));
+    }
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
@@ -440,6 +456,9 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     for (auto &sl : c->pool_slabs)  // every slab, parked or not: the context's memory ends with the context
         if (sl.base) (void)hipFree(sl.base);
     for (auto &kv : c->perm) (void)hipFree(kv.second);
+    for (void *p : c->flipw_slabs) (void)hipFree(p);
+    if (c->d_qmod) (void)hipFree(c->d_qmod);
+    if (c->d_gate) (void)hipFree(c->d_gate);
     for (hipEvent_t e : c->prof_events) (void)hipEventDestroy(e);
     for (int s = 0; s < hefx_context::MAX_STREAMS; ++s) {
         if (c->streams[s]) (void)hipStreamDestroy(c->streams[s]);
@@ -624,6 +643,16 @@ extern "C" int hefx_device_memory(hefx_context *c, size_t *free_bytes, size_t *t
     HIPCHK(hipMemGetInfo(&f, &t));
     if (free_bytes) *free_bytes = f;
     if (total_bytes) *total_bytes = t;
+    return HEFX_OK;
+}
+extern "C" int hefx_ks_fallback_count(hefx_context *c, uint64_t *chunks)
+{
+    CTXCHK(c);
+    if (!chunks) return fail(HEFX_ERR_INVALID, "null pointer");
+    uint32_t v = 0;
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(&v, c->d_gate + KS_RING, sizeof(v), hipMemcpyDeviceToHost));
+    *chunks = v;
     return HEFX_OK;
 }
 extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
@@ -943,6 +972,53 @@ static int get_perm(hefx_context *c, uint32_t elt, const uint32_t **out)
     return HEFX_OK;
 }
 
+static uint32_t inv_mod_2n(uint32_t elt, uint32_t n)
+{
+    uint32_t x = elt;  // elt odd: x = elt is its inverse mod 8; Newton doubles the correct bits
+    for (int r = 0; r < 5; ++r) x *= 2u - elt * x;
+    return x & (2u * n - 1u);
+}
+// exact hoisting's per-element tables (ks_mac_exact_kernel: W_g[m] = NTT_m(F_g)), for every element of `elts` that has none
+// yet: one allocation, one mask launch, one transform launch for all of them, then a wait -- a cached table may be read
+// from any stream later.  First use only; a linear transform's d tables cost about what its d gather tables do.
+static int ensure_flipw(hefx_context *c, const uint32_t *elts, int n, hipStream_t s)
+{
+    std::vector<uint32_t> miss;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        for (int i = 0; i < n; ++i) {
+            const uint32_t e = elts[i] ? elts[i] : 1u;
+            if (!c->flipw.count(e) && std::find(miss.begin(), miss.end(), e) == miss.end()) miss.push_back(e);
+        }
+    }
+    if (miss.empty()) return HEFX_OK;
+    std::sort(miss.begin(), miss.end());
+    miss.erase(std::unique(miss.begin(), miss.end()), miss.end());
+    const size_t per = (size_t)c->k * c->n;
+    std::vector<uint32_t> ginv(miss.size());
+    for (size_t i = 0; i < miss.size(); ++i) ginv[i] = inv_mod_2n(miss[i], c->n);
+    u64 *rows = nullptr;
+    uint32_t *d_ginv = nullptr;
+    HIPCHK(hipMalloc((void **)&rows, per * miss.size() * sizeof(u64) + ginv.size() * sizeof(uint32_t)));
+    d_ginv = reinterpret_cast<uint32_t *>(rows + per * miss.size());
+    hipError_t e = hipMemcpy(d_ginv, ginv.data(), ginv.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
+    int rc = HEFX_OK;
+    for (size_t i0 = 0; i0 < miss.size() && e == hipSuccess && rc == HEFX_OK; i0 += 1024) {  // (grid.z; bounded scratch at N = 32768)
+        const int cnt = (int)std::min<size_t>(1024, miss.size() - i0);
+        e = launch_flip_rows(c->T, d_ginv + i0, cnt, rows + per * i0, s);
+        if (e == hipSuccess) rc = ntt_common(c, false, (uint64_t *)(rows + per * i0), cnt, c->k, 0, (void *)s);
+    }
+    if (e == hipSuccess && rc == HEFX_OK) e = hipStreamSynchronize(s);
+    if (e != hipSuccess || rc != HEFX_OK) {
+        (void)hipFree(rows);
+        return rc != HEFX_OK ? rc : hipfail(e, "flip-mask tables");
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->flipw_slabs.push_back(rows);
+    for (size_t i = 0; i < miss.size(); ++i) c->flipw[miss[i]] = rows + per * i;
+    return HEFX_OK;
+}
+
 // ---------------------------------------------------------------------------------------------
 // key switching
 // ---------------------------------------------------------------------------------------------
@@ -1102,20 +1178,22 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     const int cmax = n < chunk ? n : chunk;
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     const size_t x_words = ks_x_words(c, L, fused || sub > cmax ? cmax : sub);
-    // Shared sources (ks_digit_permute_kernel): when at most a quarter as many DISTINCT source ciphertexts as items are
-    // rotated -- the d-1 rotations of a linear transform rotate ONE; with a source per 2-3 items the extra launch costs what
-    // it saves (profiles/r04/ab_shared_source.txt) -- every distinct source is inverse-transformed once per chunk
-    // and the items' digit rows are signed permutations of those.  Not for the small-batch latency path (one more launch),
-    // in-place rotations (their sources are per-item scratch copies), N = 32768 (the row does not fit LDS), the fused path.
+    // EXACT HOISTING (ks_mac_exact_kernel): when at most a quarter as many DISTINCT source ciphertexts as items are rotated
+    // -- the d-1 rotations of a linear transform rotate ONE (helper.h:252-257) -- every distinct source is decomposed and
+    // extended to the key moduli once per chunk and the items run the gathered key MAC with the flip-mask correction:
+    // SEAL's bits at (L+1)(L+2) -> 2 + 2L transforms per item (profiles/r04/ab_exact_hoisting.txt).  Not for the
+    // small-batch latency path (more launches), in-place rotations (their sources are per-item scratch copies), the
+    // fused-transform path, relinearisations.  HEFX_SHARE_SRC=0 switches it off.
     static const bool share_ok = !(getenv("HEFX_SHARE_SRC") && atoi(getenv("HEFX_SHARE_SRC")) == 0);
-    bool share = share_ok && !relin && !hoist && !fused && !any_alias && c->logn <= 14 && n > ks_small_max() && sub >= cmax;
+    bool share = share_ok && !relin && !hoist && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
     if (share) {
         std::unordered_set<const void *> distinct;
         for (int i = 0; i < n && distinct.size() * 4 <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
         share = distinct.size() * 4 <= (size_t)n;
     }
-    const size_t dsrc_words = share ? (size_t)(cmax / 4 + 1) * L * c->n : 0;
-    const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0) + dsrc_words;
+    if (share)
+        if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream)) return rc;
+    const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (two) {
@@ -1141,15 +1219,20 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             c->ring_busy[slot] = false;
         }
         KsItem *hb = c->h_items + (size_t)slot * KS_MAX_CHUNK, *db = c->d_items + (size_t)slot * KS_MAX_CHUNK;
-        KsScratch S;
+        KsScratch S{};
         S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
         S.acc = S.d + (size_t)cnt * L * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.x = S.u + (size_t)cnt * 2 * N;
         S.alias = S.x + ks_x_words(c, L, fused || sub > cnt ? cnt : sub);
-        S.dsrc = S.alias + (any_alias ? (size_t)cnt * 2 * L * N : 0);
+        S.qmod = c->d_qmod;
+        S.gate = c->d_gate + slot;
+        S.gate_hits = c->d_gate + KS_RING;
+        if (++c->gate_seq == 0) c->gate_seq = 1;
+        S.gate_tag = c->gate_seq;
+        S.gate_mode = 0;
         bool chunk_alias = false;
-        int nsrc = 0;  // > 0: this chunk runs in shared-source mode with that many distinct sources
+        int nsrc = 0;  // > 0: this chunk runs exactly hoisted over that many distinct sources
         std::unordered_map<const void *, uint32_t> src_of;
         if (share && cnt > ks_small_max()) {
             for (int i = 0; i < cnt && src_of.size() * 4 <= (size_t)cnt; ++i)
@@ -1168,12 +1251,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.flags = 0;
             it.acc_in = acc_out ? (const u64 *)acc_in[j] : nullptr;
             it.acc_out = acc_out ? (u64 *)acc_out[j] : nullptr;
-            it.dsrc = it.ginv = 0;
+            it.dsrc = it.pad_ = 0;
+            it.flipw = nullptr;
             if (nsrc) {
                 it.dsrc = src_of[(const void *)ct_in[j]];
-                uint32_t e = it.elt ? it.elt : 1u, x = e;  // elt^-1 mod 2N (elt odd): Newton, doubling the correct bits
-                for (int r = 0; r < 5; ++r) x *= 2u - e * x;
-                it.ginv = x & (2u * (uint32_t)N - 1u);
+                it.flipw = c->flipw.at(it.elt ? it.elt : 1u);
             }
             if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
                 it.c_in = S.alias + (size_t)i * 2 * L * N;
@@ -1305,6 +1387,8 @@ hipError_t chain_level(hefx_context *c, int L, int n, const uint64_t *const *in,
         it.flags = 0;
         it.acc_in = (const u64 *)acc_in[i];
         it.acc_out = (u64 *)acc_out[i];
+        it.dsrc = it.pad_ = 0;
+        it.flipw = nullptr;
     }
     return launch_keyswitch_chunk(c->T, L, n, db, false, S, n, false, false, hb, quarter, s, nullptr);
 }
@@ -1362,13 +1446,12 @@ extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64
     const size_t per = ks_words_per_item(c, L);
     if (int rc = ensure_scratch(c, per * (size_t)n + ks_x_words(c, L, n))) return rc;
     const size_t N = c->n;
-    KsScratch S;
+    KsScratch S{};
     S.d = c->scratch;
     S.acc = S.d + (size_t)n * L * N;
     S.u = S.acc + (size_t)n * 2 * (L + 1) * N;
     S.x = S.u + (size_t)n * 2 * N;
     S.alias = S.x + ks_x_words(c, L, n);
-    S.dsrc = nullptr;
     static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
     static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
     const int quarter = qmask_force >= 0    ? (qmask_force & KS_Q_ALL)
@@ -2254,13 +2337,12 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     // ---- decomposition of ct_new (once), gathered MACs of all rotations, one mod-down
     const size_t per = ks_words_per_item(c, L) + ks_x_words(c, L, 1);
     if (int rc = ensure_scratch(c, per)) return rc;
-    KsScratch S;
+    KsScratch S{};
     S.d = c->scratch;
     S.acc = S.d + (size_t)L * N;
     S.u = S.acc + (size_t)2 * (L + 1) * N;
     S.x = S.u + (size_t)2 * N;
     S.alias = nullptr;
-    S.dsrc = nullptr;
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(hipMemcpyAsync(d_items, items.data(), sizeof(KsItem) * items.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipStreamSynchronize(s));  // `items` is a local

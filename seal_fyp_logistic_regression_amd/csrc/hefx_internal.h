@@ -62,9 +62,11 @@ struct KsItem {
     u64 *acc_out;
     uint32_t elt;      // Galois element of a rotation (the kernels compute the gather index from it); 0 / 1: identity
     uint32_t flags;    // KS_ALIASED: c_out is the caller's input as well -- c_in points at a scratch copy of it
-    // shared-source decomposition (ks_digit_permute_kernel): which entry of the chunk's source list this item rotates,
-    // and elt^-1 mod 2N
-    uint32_t dsrc, ginv;
+    // exact hoisting (ks_mac_exact_kernel): which entry of the chunk's source list this item rotates, and NTT_m of the 0/1
+    // polynomial that marks the coefficients X -> X^elt negates, [k][N] (row k-1: the special prime) -- one table per
+    // Galois element, cached by the context like `perm`
+    uint32_t dsrc, pad_;
+    const u64 *flipw;
 };
 constexpr uint32_t KS_ALIASED = 1;
 
@@ -98,7 +100,12 @@ struct KsScratch {
     u64 *acc;  // [chunk][2][L+1][N]   sum_i x_i * key_i, reduced
     u64 *u;    // [chunk][2][N]        INTT_P(acc_P) + P/2, coefficient form
     u64 *alias;  // [chunk][2][L][N]   copies of the inputs of in-place rotations (c_in == c_out), else unused
-    u64 *dsrc;   // [sources][L][N]    shared-source mode: the digits of the chunk's DISTINCT source ciphertexts, unrotated
+    // exact hoisting: q_i mod q_m for every pair of key moduli ([k][k], device), and the chunk's gate -- the source
+    // decomposition stores gate_tag into *gate when a digit holds a ZERO coefficient (the one case the hoisted form does not
+    // cover); gate_mode 1: the launch does nothing when the gate was hit, 2: only when it was hit (the per-item fallback), 0: no gate
+    const u64 *qmod;
+    uint32_t *gate, *gate_hits;  // gate_hits: chunks redone by the fallback so far (hefx_ks_fallback_count)
+    uint32_t gate_tag, gate_mode;
 };
 
 constexpr int ADD_MANY_GROUP = 48;
@@ -137,11 +144,14 @@ struct KsProf {
 // small_items != nullptr (host copy of the n <= ks_small_max() descriptors of a non-hoisted, non-aliasing chunk): the
 // descriptors are passed in the first launch's arguments; d_items is then written by that launch, not copied to
 // quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
-// nsrc > 0: shared-source mode -- d_items[n .. n + nsrc) describe the chunk's distinct source ciphertexts; their digits are
-// decomposed once (into scr.dsrc) and every item's digit rows are the coefficient-domain automorphism of its source's
+// nsrc > 0: exact hoisting (ks_mac_exact_kernel) -- d_items[n .. n + nsrc) describe the chunk's distinct source
+// ciphertexts; they are decomposed and extended once (scr.d / scr.x hold SOURCE rows), every item runs the gathered MAC
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
                                   int quarter, hipStream_t s, KsProf *prof, int nsrc = 0);
+// tables of exact hoisting: rows[e][m][.] = the flip mask (coefficient order) of the Galois element whose inverse mod 2N is
+// d_ginv[e], once per modulus row m = 0..k-1; the caller transforms the rows
+hipError_t launch_flip_rows(const DevTables &T, const uint32_t *d_ginv, int count, u64 *rows, hipStream_t s);
 // `quarter`: which of the four transform launches run on quarter-row workgroups
 constexpr int KS_Q_INTT = 1, KS_Q_NTT = 2, KS_Q_MDI = 4, KS_Q_FIN = 8, KS_Q_ALL = 15;
 int ks_small_max();

@@ -154,6 +154,12 @@ __device__ __forceinline__ ulonglong2 gather_pair(const u64 *__restrict__ src, u
     return (p & 1u) ? make_ulonglong2(v.y, v.x) : v;
 }
 __device__ __forceinline__ uint32_t item_elt(const KsItem &it) { return it.elt ? it.elt : 1u; }
+// exact hoisting's gate (KsScratch): true when this launch has nothing to do.  Workgroup-uniform; ordinary chunks carry
+// gate_mode 0 and pay one scalar compare.
+__device__ __forceinline__ bool ks_gated_out(const KsScratch &S)
+{
+    return S.gate_mode != 0 && ((*S.gate == S.gate_tag) != (S.gate_mode == 2));
+}
 
 // (0) in-place rotations only (c_in == c_out at the ABI, e.g. rotate_vector_inplace, helper.h:474): the epilogue of the
 // last kernel writes c_out while it still gathers from c0, so the host points such an item's c_in at a scratch copy
@@ -191,6 +197,12 @@ __device__ __forceinline__ void intt_digits_body(const DevTables &T, const KsIte
     u64 *__restrict__ dd = S.d + ((size_t)b * L + i) * SC::N + (size_t)h * SC::H;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dd[C::idx_nat(t, r)] = v[r];
+    if (noperm && S.gate_mode) {  // the sources of an exactly hoisted chunk: any zero coefficient hits the chunk's gate
+        bool z = false;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z |= v[r] == 0;
+        if (z) *S.gate = S.gate_tag;
+    }
 }
 
 template <int LOGN>
@@ -201,7 +213,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
     extern __shared__ __align__(16) u64 lds[];
     int p, h;
     split_decode(blockIdx.x, p, h);
-    if (p >= rows) return;
+    if (p >= rows || (!noperm && ks_gated_out(S))) return;  // (noperm: the source decomposition itself is never gated)
     intt_digits_body<LOGN>(T, items[p / L], L, relin, noperm, p / L, p % L, h, S, lds);
 }
 
@@ -234,50 +246,6 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 }
 
 // ------------------------------------------------------------------------------------------------
-// (1s) SHARED SOURCES (round 4).  The rotations of a linear transform rotate ONE ciphertext by many steps
-// (helper.h:252-257: rotate_vector(ct_new, l) for l = 1..d-1), and (1) would inverse-transform the same row once per
-// item.  But INTT(perm_g(c1)) IS the automorphism X -> X^g of INTT(c1) in the coefficient domain: coefficient k goes to
-// position g k mod 2N, negated when that wraps past N -- exactly the canonical words SEAL's sequence produces (it applies
-// the Galois map in the NTT domain and the key switch transforms back; the polynomial, and so every canonical residue, is
-// the same).  So the distinct sources of a chunk are decomposed ONCE (ks_intt_digits_kernel with noperm, into S.dsrc) and
-// this kernel writes each item's digit rows as the signed permutation of its source's: the whole source row sits in LDS
-// (one parity half per workgroup: 64 KiB at N = 16384), read at an odd stride in 8-byte words (conflict-free), written
-// coalesced in the [evens | odds] layout the digit transforms read.  L inverse transforms per item become L row copies; same bits.
-// ------------------------------------------------------------------------------------------------
-template <int LOGN>
-__global__ __launch_bounds__(512) void ks_digit_permute_kernel(DevTables T, const KsItem *__restrict__ items, int L, KsScratch S)
-{
-    extern __shared__ __align__(16) u64 lds[];
-    constexpr uint32_t N = 1u << LOGN, H = N / 2;
-    // X -> X^g keeps the parity of a coefficient index (g is odd): the even half of the [evens | odds] row only reads the
-    // even half of the source and the odd half the odd one -- a workgroup owns one PARITY of one digit row (H words of LDS:
-    // 64 KiB at N = 16384, so two of these, or one and a transform workgroup, share a CU)
-    const int b = blockIdx.y, i = blockIdx.x >> 1;
-    const uint32_t par = blockIdx.x & 1;
-    const KsItem it = items[b];
-    const u64 q = T.mods[i].q;
-    const u64 *__restrict__ src = S.dsrc + ((size_t)it.dsrc * L + i) * N + (size_t)par * H;
-    u64 *__restrict__ dst = S.d + ((size_t)b * L + i) * N + (size_t)par * H;
-    for (uint32_t w = threadIdx.x; w < H / 2; w += 512) *reinterpret_cast<ulonglong2 *>(lds + 2 * w) = gld16(src + 2 * w);
-    __syncthreads();
-    const uint32_t ginv = it.ginv;
-    // output slot e of this half holds coefficient c = 2 e + par; its value is coefficient j = c ginv mod 2N of the source
-    // polynomial: +a_j for j < N, -a_(j - N) otherwise; j has c's parity, so a_(j mod N) sits at slot (j mod N) >> 1 of the
-    // same half -- read at stride ginv (odd) in 8-byte words: conflict-free
-    for (uint32_t e = 2 * threadIdx.x; e < H; e += 1024) {
-        u64 o[2];
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const uint32_t c = 2 * (e + u) + par;
-            const uint32_t j = (c * ginv) & (2 * N - 1);
-            const u64 v = lds[(j & (N - 1)) >> 1];
-            o[u] = (j >> LOGN) && v ? q - v : v;
-        }
-        gst16(dst + e, make_ulonglong2(o[0], o[1]));
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
 // ------------------------------------------------------------------------------------------------
 template <int LOGN>
@@ -288,7 +256,7 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     using C = typename SC::C;
     int g, jj, h;
     group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
-    if (g >= rows) return;
+    if (g >= rows || (S.gate_mode == 2 && ks_gated_out(S))) return;  // (mode 1 gates only the launch that writes outputs)
     const int t = threadIdx.x;
     const int bl = g / L, i = g % L;  // bl: item index inside the sub-chunk
     const int b = item0 + bl;
@@ -652,6 +620,7 @@ __global__ __launch_bounds__(256) void ks_mac_kernel(DevTables T, const KsItem *
                                                      int item0, int count, int int_only, KsScratch S)
 {
     // int_only: the FP64-policy target slots were accumulated by ks_ntt_macf_kernel; blockIdx.y counts the others
+    if (S.gate_mode == 2 && ks_gated_out(S)) return;
     const int jj = int_only ? nth_int_slot(T, L, blockIdx.y) : (int)blockIdx.y;
 #ifdef HEFX_STAMP
     const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
@@ -727,6 +696,80 @@ __global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const 
         mac_store<false>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n,
                          w, r0, r1);
     });
+}
+
+// ------------------------------------------------------------------------------------------------
+// (3x) EXACT hoisting (round 4): the hoisted form with SEAL's bits.  SEAL decomposes the ROTATED polynomial: digit i of
+// item b is t = sigma_g(T_i) with T_i = INTT_i(c1_i) in [0, q_i) and sigma_g the signed coefficient permutation taken to
+// canonical residues -- a negated non-zero coefficient a becomes q_i - a.  As integers
+//     t = sigma_g^Z(T_i) + q_i F_g        (sigma_g^Z: the signed permutation over Z, F_g: 1 where X -> X^g negates),
+// PROVIDED no coefficient of T_i is zero (a negated zero stays 0, not q_i).  Modulo a key modulus m the first term is the
+// automorphism of T_i mod m, whose transform is the evaluation-domain gather of x[i][m] = NTT_m(T_i mod m); so
+//     NTT_m(t mod m) = perm_g(x[i][m]) + (q_i mod m) W_g[m],      W_g[m] = NTT_m(F_g)   (one [k][N] table per element)
+// and the key MAC of the item is
+//     acc[c][m] = sum_i perm_g(x[i][m]) key[i][c][m]  +  W_g[m] * sum_(i != m) (q_i mod m) key[i][c][m]     (mod m)
+// -- the hoisted gather plus a second accumulation over the SAME key words with scalar operands, multiplied by one table
+// row.  Everything downstream of the MAC only sees acc mod m, so the outputs are SEAL's words.  The zero proviso is
+// checked where T_i is produced (intt_digits_body stores the chunk's gate tag); a chunk whose gate was hit -- a source
+// with a zero c1 coefficient: probability ~ N L / q per source for a real ciphertext, certain for a transparent one -- is
+// redone item by item by the ordinary kernels, which otherwise exit at once (gate_mode 2).
+// The sources' rows x are computed once per chunk by (1) and (2) over the source list; per item only this MAC and the
+// mod-down remain: (L+1)(L+2) -> 2 + 2L transforms, key words read once.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ks_mac_exact_kernel(DevTables T, const KsItem *__restrict__ items, int L, KsScratch S)
+{
+    const size_t n = (size_t)1 << T.logn;
+    const int jj = blockIdx.y, b = blockIdx.z;
+    const int m = jj < L ? jj : T.k - 1;
+    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
+    const KsItem it = items[b];
+    // (diagnostic, hefx_ks_fallback_count: one thread of the launch counts a chunk whose gate was hit -- the fallback redoes it)
+    if (w == 0 && jj == 0 && b == 0 && *S.gate == S.gate_tag) atomicAdd(S.gate_hits, 1u);
+    const u64 *__restrict__ c1 = it.c_in + (size_t)L * n;  // the source's c1: digit i in NTT form mod its own prime
+    const u64 *__restrict__ xs = S.x + (size_t)it.dsrc * L * (L + 1) * n;
+    mac_dispatch(T, m, L, [&](auto pol) {
+        using P = decltype(pol);
+        const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
+        P A, B;
+        // positions 2w, 2w+1 gather an aligned pair in either order (galois_index): one 16-byte load and a swap
+        const uint32_t p0 = gld_u32x2(it.perm + 2 * w).x;
+        for (int i = 0; i < L; ++i) {
+            const u64 *__restrict__ xrow = i == jj ? c1 + (size_t)i * n : xs + ((size_t)i * (L + 1) + jj) * n;
+            ulonglong2 xb = gld16(xrow + (p0 & ~1u));
+            if (p0 & 1u) xb = make_ulonglong2(xb.y, xb.x);
+            const u64 *kbase = it.key + ((size_t)i * 2 * T.k + m) * n;
+            const ulonglong2 k0 = gld16(kbase + 2 * w);
+            const ulonglong2 k1 = gld16(kbase + (size_t)T.k * n + 2 * w);
+            const typename P::K k = P::kin(k0, k1, cx);
+            A.mac(P::xin(xb, i == jj, cx), k, cx);
+            if (i != jj) {
+                const u64 c = S.qmod[(size_t)i * T.k + m];  // q_i mod m (uniform)
+                B.mac(P::xin(make_ulonglong2(c, c), true, cx), k, cx);
+            }
+        }
+        ulonglong2 r0, r1, f0, f1;
+        A.result(r0, r1, cx);
+        P C;
+        C.mac_diag(B, gld16(it.flipw + (size_t)m * n + 2 * w), cx);
+        C.result(f0, f1, cx);
+        const u64 q = T.mods[m].q;
+        r0.x = addmod(r0.x, f0.x, q);
+        r0.y = addmod(r0.y, f0.y, q);
+        r1.x = addmod(r1.x, f1.x, q);
+        r1.y = addmod(r1.y, f1.y, q);
+        mac_store<false>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n,
+                         w, r0, r1);
+    });
+}
+
+// F_g in coefficient order, once per modulus row: rows[e][m][c] = 1 when X -> X^g negates the coefficient that lands at c,
+// i.e. when c g^-1 mod 2N >= N (coefficient c of a(X^g) is +-a_s with s g = c or c + N mod 2N); transformed by the caller
+__global__ __launch_bounds__(256) void flip_mask_kernel(DevTables T, const uint32_t *__restrict__ ginv, u64 *__restrict__ rows)
+{
+    const uint32_t n = 1u << T.logn;
+    const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t e = blockIdx.z, m = blockIdx.y;
+    rows[((size_t)e * T.k + m) * n + c] = ((c * ginv[e]) & (2 * n - 1)) >> T.logn;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -953,7 +996,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_modd
     HEFX_STAMP_AT(0);
     int p, h;
     split_decode(blockIdx.x, p, h);
-    if (p >= rows) return;
+    if (p >= rows || (S.gate_mode == 2 && ks_gated_out(S))) return;
     const int t = threadIdx.x;
     const int sp = T.k - 1;
     const ModConst mc = T.mods[sp];
@@ -1122,7 +1165,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
     HEFX_STAMP_AT(0);
     int g, j, h;
     group_decode(blockIdx.x, L, g, j, h);  // g = remainder polynomial (b, c); j = one of the L data primes
-    if (g >= rows) return;
+    if (g >= rows || ks_gated_out(S)) return;
     const int t = threadIdx.x;
     const int b = g >> 1, c = g & 1;
     const ModConst mc = T.mods[j];
@@ -1438,6 +1481,37 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             prof->stage[prof->used++] = stage;
         }
     };
+    if (nsrc > 0) {  // exact hoisting: sources batch[n .. n + nsrc), see ks_mac_exact_kernel
+        KsScratch hs = scr, fb = scr;
+        hs.gate_mode = 1;
+        fb.gate_mode = 2;
+        mark(1);
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(nsrc * L)), dim3(SC::T), lds_intt, s, T, batch + n, L,
+                           0, 1, nsrc * L, hs);
+        mark(2);
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(nsrc * L, L)), dim3(SC::T), lds_ntt, s, T, L, nsrc * L,
+                           0, 0, hs);
+        mark(3);
+        hipLaunchKernelGGL(ks_mac_exact_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, hs);
+        mark(4);
+        hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, hs);
+        mark(5);
+        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                           0, n * 2, hs);
+        // the fallback: the ordinary five launches, which exit at once unless a source of this chunk held a zero coefficient
+        mark(0);
+        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, 0, 0,
+                           n * L, fb);
+        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds_ntt, s, T, L, n * L, 0, 0,
+                           fb);
+        hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, 0, 0, n,
+                           0, fb);
+        hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, fb);
+        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                           0, n * 2, fb);
+        mark(-1);
+        return hipGetLastError();
+    }
     if (hoist) {  // one shared source (item 0's ciphertext, unrotated); per item only the gathered MAC and the mod-down
         mark(1);
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, batch, L, 0, 1, L,
@@ -1512,20 +1586,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL(ks_alias_copy_kernel, dim3(SC::N / 2 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L);
     }
     mark(1);
-    if (nsrc > 0) {  // shared sources: decompose the distinct ones (descriptors batch[n..n+nsrc)), then one row copy per digit
-        if constexpr (LOGN <= 14) {
-            static PerDeviceOnce pattr;
-            if (pattr.first()) set_lds(ks_digit_permute_kernel<LOGN>, sizeof(u64) << (LOGN - 1));
-            KsScratch srcs = scr;
-            srcs.d = scr.dsrc;
-            hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(nsrc * L)), dim3(SC::T), lds_intt, s, T, batch + n, L,
-                               0, 1, nsrc * L, srcs);
-            hipLaunchKernelGGL((ks_digit_permute_kernel<LOGN>), dim3(2 * L, n), dim3(512), sizeof(u64) << (LOGN - 1), s, T, batch, L,
-                               scr);
-        } else {
-            return hipErrorInvalidValue;
-        }
-    } else if (small)
+    if (small)
         hipLaunchKernelGGL((ks_intt_digits_small_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
     else
@@ -1694,6 +1755,12 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 #define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof, nsrc)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
+}
+
+hipError_t launch_flip_rows(const DevTables &T, const uint32_t *d_ginv, int count, u64 *rows, hipStream_t s)
+{
+    hipLaunchKernelGGL(flip_mask_kernel, dim3((1u << T.logn) / 256, T.k, count), dim3(256), 0, s, T, d_ginv, rows);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------------

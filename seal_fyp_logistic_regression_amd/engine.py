@@ -129,6 +129,14 @@ class Engine:
     def sync(self, stream=None):
         capi.check(capi.lib().hefx_stream_sync(self._h, stream))
 
+    def ks_fallback_count(self) -> int:
+        """key-switch chunks redone item by item because a shared source held a zero c1 coefficient (hefx.h:
+        hefx_ks_fallback_count); waits for the device"""
+        import ctypes
+        v = ctypes.c_uint64(0)
+        capi.check(capi.lib().hefx_ks_fallback_count(self._h, ctypes.byref(v)))
+        return int(v.value)
+
     def psi(self, j: int) -> int:
         return int(capi.lib().hefx_psi(self._h, j))
 

@@ -257,33 +257,73 @@ def test_cpp_shim_selftest_with_the_fusions_switched_off(env):
     assert r.returncode == 0 and "SELFTEST PASSED" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
-@pytest.mark.parametrize("setname,L,n,nsrc", [("C3", 5, 100, 3), ("C2", 3, 600, 1), ("C3", 2, 72, 18), ("C3", 2, 70, 35),
-                                              ("C4", 8, 40, 2)])
-def test_shared_source_decomposition_bit_exact(setname, L, n, nsrc):
+def _plant_zero_coefficients(o, ct, L, rng, rows, count):
+    """ct with `count` zero COEFFICIENTS in the inverse transform of c1's RNS rows `rows` (the digits of a key switch)"""
+    ct = ct.copy()
+    for i in rows:
+        coef = o.ntt_inv(i, ct[1, i])
+        coef[rng.choice(o.N, size=count, replace=False)] = 0
+        ct[1, i] = o.ntt_fwd(i, coef)
+    return ct
+
+
+@pytest.mark.parametrize("setname,L,n,nsrc,zeros", [
+    ("C3", 5, 100, 3, None), ("C2", 3, 600, 1, None), ("C3", 2, 72, 18, None), ("C3", 2, 70, 35, None), ("C4", 8, 40, 2, None),
+    ("C5", 5, 36, 1, None), ("C4", 3, 64, 4, None),
+    ("C3", 5, 64, 2, "one"), ("C3", 5, 40, 1, "transparent"), ("C2", 3, 600, 2, "second_chunk"), ("C4", 8, 40, 2, "many")])
+def test_shared_source_decomposition_bit_exact(setname, L, n, nsrc, zeros):
     """Batches in which many items rotate the SAME ciphertext (the d-1 rotations of Linear_Transform_Plain, helper.h:252-257)
-    run in shared-source mode: the distinct sources are inverse-transformed once per chunk and every item's digit rows are
-    the coefficient-domain automorphism of its source's (ks_digit_permute_kernel) -- the canonical words of
-    INTT(perm_g(c1)), hence SEAL's bits.  Mixed elements (incl. conjugation 2N-1 and large ones), two keys, with and
-    without the fused plaintext product, sources interleaved; every output (a sample at n = 600) against the oracle, which
-    decomposes every item on its own.  n = 600 at N = 8192: two chunks; nsrc = n/4: the boundary case of the mode; nsrc = n/2:
-    the same inputs through the ordinary per-item decomposition."""
+    run EXACTLY HOISTED: the distinct sources are decomposed and extended to every key modulus once per chunk, every item
+    runs the gathered key MAC with the flip-mask correction (ks_mac_exact_kernel) and its own mod-down -- SEAL's words,
+    because the rotated digit is the signed permutation of the source's plus q_i on the negated coefficients.  Mixed
+    elements (incl. conjugation 2N-1 and large ones), two keys, with and without the fused plaintext product, sources
+    interleaved; every output (a sample at n = 600) against the oracle, which decomposes every item on its own.
+    n = 600 at N = 8192: two chunks; nsrc = n/4: the boundary of the mode; nsrc = n/2: the same inputs through the
+    ordinary per-item decomposition; C5: N = 32768.
+    zeros: the one input class the hoisted identity does not cover -- a source whose INTT(c1) has a ZERO coefficient in some
+    RNS row (a negated zero stays 0, not q_i).  The source decomposition detects it on the device and the chunk is redone
+    by the per-item kernels: "one" plants a single zero in one row of one source, "many" 50 in every row, "transparent" is
+    c1 = 0, "second_chunk" has the zero in a source only items of the second chunk rotate.  hefx_ks_fallback_count tells
+    which path ran: 0 without zeros (the fast path really ran), >= 1 with."""
     N, primes = SETS[setname]
     o, e = _engine_and_oracle(N, primes)
     rng = np.random.default_rng(7 * n + nsrc)
     keys = [_key(o, 91 + i) for i in range(2)]
     dkeys = [e.to_device(k) for k in keys]
     srcs = [o.uniform(L, 2, 3000 + i) for i in range(nsrc)]
+    si = [int(rng.integers(nsrc)) for _ in range(n)]
+    if zeros == "one":
+        srcs[1] = _plant_zero_coefficients(o, srcs[1], L, rng, [L - 2], 1)
+    elif zeros == "many":
+        srcs[0] = _plant_zero_coefficients(o, srcs[0], L, rng, range(L), 50)
+    elif zeros == "transparent":
+        srcs[0][1] = 0
+    elif zeros == "second_chunk":
+        srcs[1] = _plant_zero_coefficients(o, srcs[1], L, rng, [0], 3)
+        si = [0] * 512 + [int(rng.integers(2)) for _ in range(n - 512)]
+        si[-1] = 1
     dsrcs = [e.to_device(c) for c in srcs]
     pts = [o.uniform(L, 1, 4000 + i)[0] for i in range(min(n, 8))]
     dpts = [e.to_device(p) for p in pts]
-    si = [int(rng.integers(nsrc)) for _ in range(n)]
     elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
     elts[0], elts[-1] = 2 * N - 1, 3
     ki = [int(rng.integers(2)) for _ in range(n)]
+    if zeros == "second_chunk":
+        ki = [0] * n  # one key: the items keep their order (no grouping by key), so the chunks are [0, 512) and [512, 600)
+    before = e.ks_fallback_count()
     outs = e.rotate_multiply_plain_batch(L, [dsrcs[s] for s in si], elts, [dkeys[k] for k in ki], [dpts[i % len(pts)] for i in range(n)])
+    mid = e.ks_fallback_count()
     plain = e.apply_galois_batch(L, [dsrcs[s] for s in si], elts, [dkeys[k] for k in ki])
+    after = e.ks_fallback_count()
     for i in (range(n) if n <= 100 else sorted({0, 1, 255, 256, 511, 512, 513, n - 1} | set(int(x) for x in rng.integers(0, n, 10)))):
         assert (outs[i].download() == o.rotate_mulplain(srcs[si[i]], elts[i], keys[ki[i]], pts[i % len(pts)])).all(), ("fused", i)
         assert (plain[i].download() == o.apply_galois(srcs[si[i]], elts[i], keys[ki[i]])).all(), ("plain", i)
     for s in range(nsrc):
         assert (dsrcs[s].download() == srcs[s]).all(), "sources untouched"
+    if os.environ.get("HEFX_SHARE_SRC", "1") != "0" and nsrc * 4 <= n:
+        if zeros is None:
+            assert after == before, "a chunk of random ciphertexts fell back to the per-item path"
+        elif zeros == "second_chunk":
+            assert (mid - before, after - mid) == (1, 1), "exactly the second chunk of each call falls back"
+        else:
+            assert mid > before and after > mid, "a source with a zero coefficient must take the per-item path"
