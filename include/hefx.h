@@ -171,7 +171,8 @@ int hefx_apply_galois(hefx_context *ctx, int L, const uint64_t *d_ct_in, uint32_
  * refused with HEFX_ERR_INVALID before anything is submitted; the check is on byte ranges, so views into one allocation
  * are covered: two outputs that overlap, an input (or, in hefx_rotate_multiply_plain_batch, a plaintext) that overlaps
  * another item's output, an input that overlaps its own output other than exactly (d_ct_in[i] == d_ct_out[i], the
- * in-place rotation).  The *_hoisted entry points are stricter: their one shared source may be no item's output. */
+ * in-place rotation).  The *_hoisted entry points are stricter: their one shared source may be no item's output.
+ * Batches of more than 32 items that rotate few distinct ciphertexts run exactly hoisted (see hefx_rotate_hoisted_batch). */
 int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                             const uint32_t *galois_elts, const uint64_t *const *d_keys,
                             uint64_t *const *d_ct_out, void *stream);
@@ -266,20 +267,24 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
                                 const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                 const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
 
-/* ---- HOISTED rotations -- a separate fast mode, NOT bit-identical to Evaluator::rotate_vector.
- *      n rotations of ONE ciphertext share its digit decomposition: INTT + digit x modulus NTTs of c1 are done once,
- *      each rotation gathers them through its Galois table, multiplies with its key and mods down --
- *      (L+1)(L+2) -> 2 + 2L transforms per rotation.  Difference to SEAL's sequence: the automorphism negates the
- *      coefficients that wrap; SEAL re-decomposes the rotated polynomial (digit of -a = q_i - a, lifted as a
- *      positive integer), the hoisted form carries the sign through the lift (-a).  Both are exact key switches of
- *      the same rotated ciphertext with the same noise bound; the RNS words differ.  Parity: bit-exact against the
- *      oracle's statement of THIS algorithm (orc_apply_galois_hoisted) and equal decryptions to CKKS precision.
- *      d_pts may be NULL (no fused multiply_plain); outputs must not alias the source. */
+/* ---- HOISTED rotations: n rotations of ONE ciphertext share its digit decomposition -- INTT and
+ *      digit x modulus NTTs of c1 once, each rotation gathers them through its Galois table, multiplies with its key and
+ *      mods down: (L+1)(L+2) -> 2 + 2L transforms per rotation.  EXACT since round 4, i.e. the same words as
+ *      hefx_apply_galois_batch / Evaluator::rotate_vector with these keys: SEAL decomposes the rotated polynomial, whose
+ *      digit is the signed permutation of the source's plus q_i on the negated coefficients; the key MAC adds that term
+ *      as (q_i mod m) * NTT_m(flip mask of the element) (csrc/hefx_keyswitch.hip ks_mac_exact_kernel; the identity is
+ *      pinned on the CPU in tests/test_oracle_pinning.py, and it excludes zero coefficients, which the device detects
+ *      and redoes per item).  Rounds 1-3 shipped the uncorrected sum as a fast mode with other words.
+ *      hefx_apply_galois_batch / hefx_rotate_multiply_plain_batch / hefx_apply_galois_add_batch take this path by
+ *      themselves when a batch of more than 32 items rotates at most n/4 distinct ciphertexts, so this entry is now the
+ *      same computation with a stricter contract (one source, which no output may alias) -- kept for its callers.
+ *      d_pts may be NULL (no fused multiply_plain). */
 int hefx_rotate_hoisted_batch(hefx_context *ctx, int L, const uint64_t *d_ct_in, int n, const uint32_t *galois_elts,
                               const uint64_t *const *d_keys, const uint64_t *const *d_pts, uint64_t *const *d_ct_out,
                               void *stream);
 /* Linear_Transform_Plain with the d-1 rotations of ct_new hoisted; needs a DIRECT Galois key for every step 1..d-1
- * (keygen.galois_keys(steps)); the -d rotation is a regular one. */
+ * (keygen.galois_keys(steps)); the -d rotation is a regular one.  Same words as hefx_linear_transform_plain with those
+ * keys (which hoists by itself from d = 34 on); refuses key sets without the direct keys. */
 int hefx_linear_transform_plain_hoisted(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
                                         const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                         const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
@@ -306,9 +311,10 @@ int hefx_linear_transform_plain_hoisted2_sparse(hefx_context *ctx, int L, const 
  * and l = j*n1 + i:  sum_l diag_l (.) rot_l(ct_new) = sum_j rot_(j*n1)( sum_i diag'_l (.) rot_i(ct_new) ), where
  * d_shifted_diag_pts[l] encodes diag_l shifted RIGHT by j*n1 slots (done in the clear before encoding).  Needs direct
  * Galois keys for the steps 1..n1-1 and n1, 2*n1, .., (n2-1)*n1 (n1+n2-2 key switches instead of d-1); rotate(-d) may
- * use a NAF chain.  d + n1*n2 <= N/2.  hoisted_baby != 0 shares the digit decomposition of ct_new over the baby
- * rotations (hefx_rotate_hoisted_batch's algorithm).  A different operation sequence than the reference's loop: the
- * same plaintext result with different noise bits; the checker is the same composition over the oracle. */
+ * use a NAF chain.  d + n1*n2 <= N/2.  hoisted_baby: the baby rotations go through hefx_rotate_hoisted_batch (same
+ * words either way).  A different operation sequence than the reference's loop -- every primitive in it is one of SEAL's
+ * bit for bit -- so the same plaintext result with different noise bits than Linear_Transform_Plain; the checker is the
+ * same composition over the oracle. */
 int hefx_linear_transform_plain_bsgs(hefx_context *ctx, int L, const uint64_t *d_ct, int d, int n1,
                                      const uint64_t *const *d_shifted_diag_pts, int nkeys, const uint32_t *key_elts,
                                      const uint64_t *const *d_keys, int hoisted_baby, uint64_t *d_out, void *stream);

@@ -537,8 +537,14 @@ static void moddown_into(const orc_ctx *c, int L, const uint64_t *S, uint64_t *c
  * the UNROTATED c1; its digits are extended to every modulus once and each extended row is read through the Galois
  * gather table, i.e. the automorphism is applied AFTER the decomposition.  Not SEAL's bits: where the automorphism
  * negates a coefficient, SEAL's digit is q_i - a (positive lift) and this one is -a. */
-static void switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key,
-                            const uint32_t *tab)
+/* flip != NULL (with tab): the EXACT hoisted form (csrc/hefx_keyswitch.hip, ks_mac_exact_kernel).  flip[a] = 1 where the
+ * automorphism negates the coefficient that lands at position a.  SEAL's digit of the rotated polynomial is
+ * sigma(T_i) + q_i * flip as an integer vector (T_i = the unrotated digit, sigma the signed permutation over Z) unless T_i
+ * has a zero coefficient, so its transform modulo m is the gathered row plus (q_i mod m) * NTT_m(flip): adding that term
+ * to the hoisted sum gives SEAL's accumulator modulo m, hence SEAL's bits.  Returns 1 if a zero coefficient was met (the
+ * identity does not hold then and the caller must take the regular sequence), else 0. */
+static int switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key,
+                           const uint32_t *tab, const uint64_t *flip)
 {
     const uint64_t n = c->N;
     const int k = c->k, sp = k - 1; /* special-prime index at key level */
@@ -558,10 +564,17 @@ static void switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_
     uint64_t *d = (uint64_t *)malloc(sizeof(uint64_t) * n);
     uint64_t *x = (uint64_t *)malloc(sizeof(uint64_t) * n);
     uint64_t *xg = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t *w = flip ? (uint64_t *)malloc(sizeof(uint64_t) * (size_t)nm * n) : NULL; /* w[jj] = NTT_m(flip) */
+    int zero_seen = 0;
+    for (int jj = 0; flip && jj < nm; jj++) {
+        memcpy(w + (size_t)jj * n, flip, sizeof(uint64_t) * n);
+        orc_ntt_fwd(c, jj < L ? jj : sp, w + (size_t)jj * n);
+    }
 
     for (int i = 0; i < L; i++) {
         memcpy(d, target + (size_t)i * n, sizeof(uint64_t) * n);
         orc_ntt_inv(c, i, d); /* digit in coefficient form, [0,q_i) */
+        for (uint64_t a = 0; flip && a < n; a++) zero_seen |= d[a] == 0;
         for (int jj = 0; jj < nm; jj++) {
             int mi = jj < L ? jj : sp; /* modulus / key-row index at key level */
             const mod_t *m = &c->t[mi].m;
@@ -584,9 +597,14 @@ static void switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_
                 const uint64_t *kr = key + ((((size_t)i * 2 + cc) * k) + mi) * n;
                 u128 *ac = acc + ((size_t)cc * nm + jj) * n;
                 for (uint64_t a = 0; a < n; a++) ac[a] += (u128)xs[a] * kr[a];
+                if (flip && mi != i) { /* + (q_i mod m) * NTT_m(flip) * key */
+                    const uint64_t qim = c->t[i].m.q % m->q, *wj = w + (size_t)jj * n;
+                    for (uint64_t a = 0; a < n; a++) ac[a] += (u128)mulmod_m(qim, wj[a], m) * kr[a];
+                }
             }
         }
     }
+    free(w);
 
     const mod_t *mp = &c->t[sp].m;
     const uint64_t half = mp->q >> 1;
@@ -614,11 +632,12 @@ static void switch_key_impl(const orc_ctx *c, int L, uint64_t *ct, const uint64_
     free(d);
     free(x);
     free(xg);
+    return zero_seen;
 }
 
 void orc_switch_key(const orc_ctx *c, int L, uint64_t *ct, const uint64_t *target, const uint64_t *key)
 {
-    switch_key_impl(c, L, ct, target, key, NULL);
+    (void)switch_key_impl(c, L, ct, target, key, NULL, NULL);
 }
 
 /* hoisted rotation: c0' = perm(c0) + ks0, c1' = ks1 with the key switch of the hoisted variant above */
@@ -634,10 +653,42 @@ void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, ui
         uint64_t *r0 = res + (size_t)j * n;
         for (uint64_t i = 0; i < n; i++) r0[i] = s0[tab[i]];
     }
-    switch_key_impl(c, L, res, ct_in + (size_t)L * n, key, tab);
+    (void)switch_key_impl(c, L, res, ct_in + (size_t)L * n, key, tab, NULL);
     memcpy(ct_out, res, sizeof(uint64_t) * (size_t)2 * L * n);
     free(tab);
     free(res);
+}
+
+/* EXACT hoisted rotation (test infrastructure for csrc/hefx_keyswitch.hip ks_mac_exact_kernel): the hoisted sequence
+ * plus the flip-mask term.  Coefficient a of p(X^elt) is +-p_s with s = a * elt^-1 mod 2N, negative when s >= N.
+ * Returns 0 when the identity applied (ct_out then equals orc_apply_galois's words -- tests/test_oracle_cpu.py checks
+ * exactly that), 1 when c1 had a zero coefficient in some digit: ct_out is then computed by orc_apply_galois itself. */
+int orc_apply_galois_hoisted_exact(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
+                                   uint64_t *ct_out)
+{
+    const uint64_t n = c->N;
+    uint32_t *tab = (uint32_t *)malloc(sizeof(uint32_t) * n);
+    uint64_t *res = (uint64_t *)calloc((size_t)2 * L * n, sizeof(uint64_t));
+    uint64_t *flip = (uint64_t *)malloc(sizeof(uint64_t) * n);
+    uint64_t ginv = elt; /* odd: its own inverse mod 8; Newton doubles the correct bits */
+    for (int r = 0; r < 5; r++) ginv *= 2 - elt * ginv;
+    ginv &= 2 * n - 1;
+    for (uint64_t a = 0; a < n; a++) flip[a] = ((a * ginv) & (2 * n - 1)) >= n;
+    orc_galois_table(n, elt, tab);
+    for (int j = 0; j < L; j++) {
+        const uint64_t *s0 = ct_in + (size_t)j * n;
+        uint64_t *r0 = res + (size_t)j * n;
+        for (uint64_t i = 0; i < n; i++) r0[i] = s0[tab[i]];
+    }
+    const int zero = switch_key_impl(c, L, res, ct_in + (size_t)L * n, key, tab, flip);
+    if (zero)
+        orc_apply_galois(c, L, ct_in, elt, key, ct_out);
+    else
+        memcpy(ct_out, res, sizeof(uint64_t) * (size_t)2 * L * n);
+    free(tab);
+    free(res);
+    free(flip);
+    return zero;
 }
 
 /* DOUBLE-HOISTED linear transform, core (csrc/hefx_keyswitch.hip lt2_mac_kernel), top data level

@@ -110,6 +110,10 @@ void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, doubl
 void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
                               uint64_t *ct_out);
 
+/* exactly hoisted rotation (ks_mac_exact_kernel's identity): orc_apply_galois's words; returns 1 if a zero coefficient of
+ * c1 made it take the regular sequence, 0 if the hoisted identity applied */
+int orc_apply_galois_hoisted_exact(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
+                                   uint64_t *ct_out);
 /* double-hoisted linear transform, core on ct_new (second fast mode; see ckks_oracle.c); elts[l], l = 1..d-1;
  * keys = [d-1][k-1][2][k][N]; diag = [d][k][N] key-level plaintexts; L must be k-1 */
 void orc_lt_double_hoisted_core(const orc_ctx *c, int L, const uint64_t *ct_new, int d, const uint64_t *diag,

@@ -69,6 +69,7 @@ def lib():
     sig("orc_switch_key", None, vp, i, u64p, u64p, u64p)
     sig("orc_apply_galois", None, vp, i, u64p, u64, u64p, u64p)
     sig("orc_apply_galois_hoisted", None, vp, i, u64p, u64, u64p, u64p)
+    sig("orc_apply_galois_hoisted_exact", i, vp, i, u64p, u64, u64p, u64p)
     sig("orc_lt_double_hoisted_core", None, vp, i, u64p, i, u64p, u64p, u64p, u64p)
     sig("orc_relinearize", None, vp, i, u64p, u64p, u64p)
     sig("orc_rescale", None, vp, i, i, u64p, u64p, i)
@@ -223,6 +224,12 @@ class Oracle:
         out = np.zeros_like(ct)
         lib().orc_apply_galois_hoisted(self._h, ct.shape[1], np.ascontiguousarray(ct), elt, key, out)
         return out
+
+    def apply_galois_hoisted_exact(self, ct, elt, key):
+        """the hoisted sequence plus the flip-mask term (ks_mac_exact_kernel's identity): (words, took_regular_path)"""
+        out = np.zeros_like(ct)
+        z = lib().orc_apply_galois_hoisted_exact(self._h, ct.shape[1], np.ascontiguousarray(ct), elt, key, out)
+        return out, bool(z)
 
     def lt_double_hoisted_core(self, ct_new, diags_keylevel, elts, keys):
         """second fast mode: ct_new [2][L][N], diags [d][k][N], elts[1..d-1] (index 0 ignored), keys list for l>=1"""

@@ -1064,7 +1064,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     if (sub <= 0 || sub > chunk) sub = chunk;
     // fused digit-NTT + MAC kernel (no x scratch at all) when enabled and N <= 16384 (longer rows do not fit the
     // 8-coefficient-per-thread workgroup); the launcher takes sub < 0 as "fused"
-    // (never for a hoisted batch: its shared digit x modulus products live in the x scratch the fused kernel does without)
+    // (never for a hoisted batch: the sources' digit x modulus products live in the x scratch the fused kernel does without)
     bool fused = c->fused && c->logn <= 14 && !hoist;
     int fused_code = 0;
     if (fused) {
@@ -1075,7 +1075,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         fused_code = nf | ((special_f ? 0 : 1) << 8);
         if (nf == 0) fused = false;  // nothing to fuse: every target modulus is integer-policy
     }
-    // hoisting (explicit, hefx_*_hoisted): every item rotates the same source, decomposed once per chunk
+    // hoisting asked for explicitly (hefx_*_hoisted): every item rotates the same source, which no item may overwrite.
+    // Since the hoisted form is exact (same words as the per-item sequence) the flag no longer selects an algorithm: the
+    // rule below picks the hoisted kernels for more than 32 items and the latency path for fewer, where it measures the
+    // same or better (baby-step/giant-step transforms with 9..31 baby rotations: 178 / 215 / 430 us against 202 / 237 /
+    // 445 at N = 8192, d = 10 / 100 / 1000; profiles/r04/ab_exact_hoisting.txt)
     if (hoist) {
         if (relin) return fail(HEFX_ERR_INVALID, "hoisting applies to rotations only");
         for (int i = 0; i < n; ++i)
@@ -1177,7 +1181,6 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     auto src = [&](int i) { return ord.empty() ? i : ord[(size_t)i]; };
     const int cmax = n < chunk ? n : chunk;
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
-    const size_t x_words = ks_x_words(c, L, fused || sub > cmax ? cmax : sub);
     // EXACT HOISTING (ks_mac_exact_kernel): when at most a quarter as many DISTINCT source ciphertexts as items are rotated
     // -- the d-1 rotations of a linear transform rotate ONE (helper.h:252-257) -- every distinct source is decomposed and
     // extended to the key moduli once per chunk and the items run the gathered key MAC with the flip-mask correction:
@@ -1185,7 +1188,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // small-batch latency path (more launches), in-place rotations (their sources are per-item scratch copies), the
     // fused-transform path, relinearisations.  HEFX_SHARE_SRC=0 switches it off.
     static const bool share_ok = !(getenv("HEFX_SHARE_SRC") && atoi(getenv("HEFX_SHARE_SRC")) == 0);
-    bool share = share_ok && !relin && !hoist && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
+    bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
     if (share) {
         std::unordered_set<const void *> distinct;
         for (int i = 0; i < n && distinct.size() * 4 <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
@@ -1193,6 +1196,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     }
     if (share)
         if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream)) return rc;
+    // (a hoisted chunk's fallback runs the digit transforms of all its items at once: x for the whole chunk)
+    const size_t x_words = ks_x_words(c, L, fused || share || sub > cmax ? cmax : sub);
     const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
     if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
@@ -1224,7 +1229,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         S.acc = S.d + (size_t)cnt * L * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.x = S.u + (size_t)cnt * 2 * N;
-        S.alias = S.x + ks_x_words(c, L, fused || sub > cnt ? cnt : sub);
+        S.alias = S.x + ks_x_words(c, L, fused || share || sub > cnt ? cnt : sub);
         S.qmod = c->d_qmod;
         S.gate = c->d_gate + slot;
         S.gate_hits = c->d_gate + KS_RING;
@@ -1282,7 +1287,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         hipStream_t cs = two ? c->streams[ci % ns] : user;
         // small chunks carry their descriptors in the first launch's kernel arguments (HEFX_SMALL=0 restores the copy)
         static const bool small_ok = !(getenv("HEFX_SMALL") && atoi(getenv("HEFX_SMALL")) == 0);
-        const bool small = small_ok && cnt <= ks_small_max() && !hoist && !chunk_alias;
+        const bool small = small_ok && cnt <= ks_small_max() && !nsrc && !chunk_alias;
         // ... and run on quarter-row workgroups when split-2 workgroups (2 L (L+1) per item in the widest launch) would
         // leave CUs idle: HEFX_QUARTER=0/1 overrides the size test
         // per launch: quarter rows where the quarter grid (4 workgroups per row) still gets a CU per workgroup -- measured
@@ -1311,7 +1316,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             sd.elt = 1u;
         }
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * (cnt + nsrc), hipMemcpyHostToDevice, cs));
-        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, hoist, chunk_alias, small ? hb : nullptr,
+        KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, chunk_alias, small ? hb : nullptr,
                                       quarter, cs, prof, nsrc));
         if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
@@ -1390,7 +1395,7 @@ hipError_t chain_level(hefx_context *c, int L, int n, const uint64_t *const *in,
         it.dsrc = it.pad_ = 0;
         it.flipw = nullptr;
     }
-    return launch_keyswitch_chunk(c->T, L, n, db, false, S, n, false, false, hb, quarter, s, nullptr);
+    return launch_keyswitch_chunk(c->T, L, n, db, false, S, n, false, hb, quarter, s, nullptr);
 }
 }  // namespace
 

@@ -141,13 +141,13 @@ struct KsProf {
     int *stage;      // stage[i] = launch kind that follows ev[i]; -1 terminates a chunk
     int cap, used;
 };
-// small_items != nullptr (host copy of the n <= ks_small_max() descriptors of a non-hoisted, non-aliasing chunk): the
+// small_items != nullptr (host copy of the n <= ks_small_max() descriptors of a non-aliasing chunk without sources): the
 // descriptors are passed in the first launch's arguments; d_items is then written by that launch, not copied to
 // quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
 // nsrc > 0: exact hoisting (ks_mac_exact_kernel) -- d_items[n .. n + nsrc) describe the chunk's distinct source
 // ciphertexts; they are decomposed and extended once (scr.d / scr.x hold SOURCE rows), every item runs the gathered MAC
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
-                                  const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
+                                  const KsScratch &scr, int sub, bool alias, const KsItem *small_items,
                                   int quarter, hipStream_t s, KsProf *prof, int nsrc = 0);
 // tables of exact hoisting: rows[e][m][.] = the flip mask (coefficient order) of the Galois element whose inverse mod 2N is
 // d_ginv[e], once per modulus row m = 0..k-1; the caller transforms the rows

@@ -646,17 +646,9 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_ntt_
 }
 
 // ------------------------------------------------------------------------------------------------
-// (3h) hoisted MAC: all items of the chunk rotate the SAME source ciphertext (the d-1 rotations of a linear
-// transform with direct Galois keys).  NTT_m(a(X^g)) = perm_g(NTT_m(a)), so the digit x modulus products x[i][jj] of
-// the UNPERMUTED source are computed once ((1),(2) with one item) and every item reads them through its gather table:
-//   acc[b][c][jj][w] = sum_i x[i][jj][perm_b[w]] * key_b[i][c][m][w].
-// This is a DIFFERENT (equally valid) lift than the per-item path, NOT the same bits: where the automorphism negates a
-// coefficient a of digit i, SEAL decomposes the rotated polynomial and lifts q_i - a (a positive integer) to modulus
-// m, whereas permuting the transformed digit carries -(a mod m); the two differ by q_i mod m.  Both are exact key
-// switches of the same rotated ciphertext with the same noise bound (DESIGN.md "Hoisted rotations"); parity for this
-// mode is against the oracle's statement of THIS algorithm (orc_apply_galois_hoisted).  Per item only the MAC and the
-// mod-down remain ((L+1)(L+2) -> 2 + 2L transforms).  The gathered rows are L2-resident (one source), the keys stream
-// from HBM.
+// gathered MAC of the DOUBLE-hoisted transform (lt2_mac_kernel): NTT_m(a(X^g)) = perm_g(NTT_m(a)), so the digit x modulus
+// products x[i][jj] of the UNPERMUTED source are read through the item's gather table.  (The single-hoisted form of rounds
+// 1-3 -- this sum alone, a different lift than SEAL's -- gave way to ks_mac_exact_kernel below, which adds the missing term.)
 // ------------------------------------------------------------------------------------------------
 // sum over the digits of one rotation `it`, gathered through its table: the inner loop of both hoisted forms
 template <class P>
@@ -675,27 +667,6 @@ __device__ __forceinline__ void mac_gathered(P &A, const typename P::Ctx &cx, co
         const ulonglong2 k1 = gld16(kbase + (size_t)T.k * n + 2 * w);
         A.mac(P::xin(xb, i == jj, cx), P::kin(k0, k1, cx), cx);
     }
-}
-
-__global__ __launch_bounds__(256) void ks_mac_hoisted_kernel(DevTables T, const KsItem *__restrict__ items, int L,
-                                                             KsScratch S)
-{
-    const size_t n = (size_t)1 << T.logn;
-    const int jj = blockIdx.y, b = blockIdx.z;
-    const int m = jj < L ? jj : T.k - 1;
-    const size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // pair index within the row
-    const KsItem it = items[b];
-    mac_dispatch(T, m, L, [&](auto pol) {
-        using P = decltype(pol);
-        const typename P::Ctx cx = P::make(T.mods[m], T.modsf[m]);
-        P A;
-        // the shared source's c1: digit i in NTT form mod its own prime
-        mac_gathered(A, cx, T, it, it.c_in + (size_t)L * n, S, L, jj, m, n, w);
-        ulonglong2 r0, r1;
-        A.result(r0, r1, cx);
-        mac_store<false>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n,
-                         w, r0, r1);
-    });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1446,7 +1417,7 @@ static void set_lds(K kernel, size_t bytes)
 
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                           const KsScratch &scr, int sub, bool hoist, bool alias,
+                                           const KsScratch &scr, int sub, bool alias,
                                            const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     using SC = SplitCfg<LOGN>;
@@ -1509,23 +1480,6 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, fb);
         hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
                            0, n * 2, fb);
-        mark(-1);
-        return hipGetLastError();
-    }
-    if (hoist) {  // one shared source (item 0's ciphertext, unrotated); per item only the gathered MAC and the mod-down
-        mark(1);
-        hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(L)), dim3(SC::T), lds, s, T, batch, L, 0, 1, L,
-                           scr);
-        mark(2);
-        hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(L, L)), dim3(SC::T), lds, s, T, L, L, 0, 0, scr);
-        mark(3);
-        hipLaunchKernelGGL(ks_mac_hoisted_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, scr);
-        mark(4);
-        hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds, s, T, L, n * 2,
-                           scr);
-        mark(5);
-        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds, s, T, batch,
-                           L, 0, n * 2, scr);
         mark(-1);
         return hipGetLastError();
     }
@@ -1741,18 +1695,18 @@ int lt2_chunk() { return LT2_CHUNK; }
 
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
-                                  const KsScratch &scr, int sub, bool hoist, bool alias, const KsItem *small_items,
+                                  const KsScratch &scr, int sub, bool alias, const KsItem *small_items,
                                   int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
-    if (small_items && n <= KS_SMALL_MAX && !hoist && !alias) {
+    if (small_items && n <= KS_SMALL_MAX && !nsrc && !alias) {
         for (int i = 0; i < n; ++i) sm.it[i] = small_items[i];
         for (int i = n; i < KS_SMALL_MAX; ++i) sm.it[i] = KsItem{};
         small = &sm;
     }
     if (T.logn < 12) quarter = 0;  // quarter rows of N = 2048 would be half-wave workgroups
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, hoist, alias, small, quarter, s, prof, nsrc)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, alias, small, quarter, s, prof, nsrc)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

@@ -325,9 +325,9 @@ def test_lr_prediction_fast_window_sum_bit_exact_against_the_twin():
 
 def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
     """Direct keys for every step (keygen.galois_keys(steps)): SEAL then applies ONE key switch per rotation and the
-    regular path stays bit-exact.  hoisted=True additionally shares the digit decomposition of ct_new across the
-    d-1 rotations: a different algorithm (not SEAL's bits) -- bit-exact against the oracle twin running the hoisted
-    oracle, and the same decrypted values to CKKS precision."""
+    regular path stays bit-exact.  hoisted=True shares the digit decomposition of ct_new across the d-1 rotations
+    explicitly (at this d = 12 the regular call would not: batches of <= 32 items take the latency path) -- with the
+    flip-mask term of round 4 (ks_mac_exact_kernel) that is the SAME words: hoisted == regular == the oracle twin."""
     from seal_fyp_logistic_regression_amd import algorithms as alg
     rng = np.random.default_rng(9)
     d = 12
@@ -346,10 +346,9 @@ def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
     (eg, (cg, hg)), (eo, (co, ho)) = r["gpu"], r["oracle"]
     assert (bits(eg, cg) == bits(eo, co)).all()
     assert (bits(eg, hg) == bits(eo, ho)).all()
-    assert (bits(eg, hg) != bits(eg, cg)).any()
+    assert (bits(eg, hg) == bits(eg, cg)).all()
     assert np.allclose(decode(eg, cg, d), M @ v, atol=1e-5)
     assert np.allclose(decode(eg, hg, d), M @ v, atol=1e-5)
-    assert np.abs(decode(eg, hg, d) - decode(eg, cg, d)).max() < 1e-5  # two noise samples of ~1e-6
     # (the GPU side ran hefx_linear_transform_plain_hoisted in one call, the oracle twin the Python composition)
     e = eg
     scale = 2.0 ** 40
@@ -363,8 +362,8 @@ def test_linear_transform_with_direct_galois_keys_and_hoisted_fast_mode():
 
 @pytest.mark.parametrize("d,n1,hoisted", [(12, None, True), (13, 3, True), (12, None, False)])
 def test_bsgs_linear_transform_bit_exact_against_the_twin(d, n1, hoisted):
-    """Baby-step / giant-step Linear_Transform_Plain: n1-1 hoisted + n2-1 regular key switches, inner
-    sums through hefx_multiply_plain_sum.  Same composition on the oracle twin -> same bits; M.v to CKKS precision; and
+    """Baby-step / giant-step Linear_Transform_Plain: n1-1 hoisted (exactly: SEAL's words) + n2-1 regular
+    key switches, inner sums through hefx_multiply_plain_sum.  Same composition on the oracle twin -> same bits; M.v to CKKS precision; and
     with regular (non-hoisted) baby steps every primitive is SEAL's, so the twin's bits are op-by-op SEAL bits."""
     from seal_fyp_logistic_regression_amd import algorithms as alg
     rng = np.random.default_rng(100 + d)

@@ -379,11 +379,13 @@ def test_alternative_launch_paths_bit_exact(c3):
 
 
 @pytest.mark.parametrize("setname", ["C2", "C3", "C5"])
-def test_hoisted_rotations_bit_exact_against_the_hoisted_oracle(setname):
-    """hefx_rotate_hoisted_batch (fast mode): n rotations of ONE ciphertext share its digit
-    decomposition.  Not SEAL's bits (signed digit lifts), so the checker is the oracle's statement of the SAME
-    algorithm, orc_apply_galois_hoisted -- bit-exact, with and without the fused plaintext product, at a lower
-    level, and over more than one chunk."""
+def test_hoisted_rotations_bit_exact_against_the_regular_key_switch(setname):
+    """hefx_rotate_hoisted_batch: n rotations of ONE ciphertext share its digit decomposition -- since
+    round 4 with the flip-mask term (ks_mac_exact_kernel), so the words are SEAL's: the checker is orc_apply_galois, the
+    regular per-item sequence, with and without the fused plaintext product, at a lower level.  (7 items: the latency
+    path serves them; the hoisted kernels take over above 32 items -- test_hoisted_chunking... with HEFX_CHUNK and
+    tests/test_gpu_round4.py::test_shared_source_decomposition_bit_exact cover those.)  The uncorrected hoisted statement
+    of rounds 1-3 (orc_apply_galois_hoisted) has other words."""
     from oracle import oracle as O
     o, e, primes = _mk(setname)
     L = len(primes) - 1
@@ -396,21 +398,23 @@ def test_hoisted_rotations_bit_exact_against_the_hoisted_oracle(setname):
     pts = [o.uniform(L, 1, 600 + i)[0] for i in range(n)]
     elts = [O.galois_elt_from_step(o.N, s) for s in steps]
     outs = e.rotate_hoisted_batch(L, dct, elts, [dkeys[s] for s in steps], [e.to_device(p) for p in pts])
+    before = e.ks_fallback_count()
     differs = 0
     for i in range(n):
-        h = o.apply_galois_hoisted(ct, elts[i], keys[steps[i]])
+        h = o.apply_galois(ct, elts[i], keys[steps[i]])
         assert (outs[i].download() == o.multiply_plain(h, pts[i])).all(), (setname, i)
-        differs += int((h != o.apply_galois(ct, elts[i], keys[steps[i]])).any())
-    assert differs == n  # and it really is a different algorithm than SEAL's sequence
+        differs += int((h != o.apply_galois_hoisted(ct, elts[i], keys[steps[i]])).any())
+    assert differs == n  # the flip term matters on every one of them
     plain = e.rotate_hoisted_batch(L, dct, elts, [dkeys[s] for s in steps])
     for i in range(n):
-        assert (plain[i].download() == o.apply_galois_hoisted(ct, elts[i], keys[steps[i]])).all(), (setname, i)
+        assert (plain[i].download() == o.apply_galois(ct, elts[i], keys[steps[i]])).all(), (setname, i)
+    assert e.ks_fallback_count() == before  # the hoisted kernels produced these, not the per-item fallback
     assert (dct.download() == ct).all()  # the shared source is never written
     if L > 2:
         ctl = o.uniform(L - 1, 2, 43)
         got = e.rotate_hoisted_batch(L - 1, e.to_device(ctl), elts[:4], [dkeys[s] for s in steps[:4]])
         for i in range(4):
-            assert (got[i].download() == o.apply_galois_hoisted(ctl, elts[i], keys[steps[i]])).all()
+            assert (got[i].download() == o.apply_galois(ctl, elts[i], keys[steps[i]])).all()
     with pytest.raises(ValueError):
         e.rotate_hoisted_batch(L, dct, elts[:1], [dkeys[steps[0]]], outs=[dct])  # output aliases the source
 
@@ -423,14 +427,16 @@ def test_hoisted_chunking_and_policies_bit_exact(c3):
         "import sys, numpy as np; sys.path.insert(0, %r)\n"
         "from oracle import oracle as O\n"
         "from seal_fyp_logistic_regression_amd import Engine\n"
-        "primes=%r; o=O.Oracle(16384, primes); e=Engine(16384, primes); L=5; n=11\n"
+        "primes=%r; o=O.Oracle(16384, primes); e=Engine(16384, primes); L=5; n=45\n"
         "keys=[o.uniform(o.k, 2*(o.k-1), 70+i).reshape(o.k-1,2,o.k,o.N) for i in range(3)]; dk=[e.to_device(k) for k in keys]\n"
         "ct=o.uniform(L,2,900); d=e.to_device(ct); pts=[o.uniform(L,1,950+i)[0] for i in range(n)]\n"
         "elts=[[3,9,27][i%%3] for i in range(n)]\n"
         "outs=e.rotate_hoisted_batch(L,d,elts,[dk[i%%3] for i in range(n)],[e.to_device(p) for p in pts])\n"
-        "ok=all((outs[i].download()==o.multiply_plain(o.apply_galois_hoisted(ct,elts[i],keys[i%%3]),pts[i])).all() for i in range(n))\n"
+        "ok=all((outs[i].download()==o.multiply_plain(o.apply_galois(ct,elts[i],keys[i%%3]),pts[i])).all() for i in range(n))\n"
         "print('PARITY', ok)\n") % (root, primes)
-    for env in ({}, {"HEFX_CHUNK": "4"}, {"HEFX_STREAMS": "0", "HEFX_CHUNK": "3"}, {"HEFX_NO_FP64": "1"}):
+    # 45 items: one hoisted chunk; chunks of 40 + 5 (hoisted kernels, then the latency path) on two streams; serial chunks
+    # of 36 + 9; the integer policies for every modulus; hoisting switched off
+    for env in ({}, {"HEFX_CHUNK": "40"}, {"HEFX_STREAMS": "0", "HEFX_CHUNK": "36"}, {"HEFX_NO_FP64": "1"}, {"HEFX_SHARE_SRC": "0"}):
         r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
                            timeout=600)
         assert "PARITY True" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])

@@ -21,6 +21,17 @@ C5 = (32768, [0xfffffffff840001, 0xffff940001, 0xffffb20001, 0xffffc40001, 0xfff
 SETS = {"C2": C2, "C3": C3, "C4": C4, "C5": C5}
 
 
+def _edge61(N=4096, count=4):
+    """the largest primes hefx_context_create admits (61 bits; SEAL's stop at 60): the 128-bit accumulator policy of the key MAC"""
+    from seal_fyp_logistic_regression_amd.seal import _is_prime
+    primes, v = [], (1 << 61) - 2 * N + 1
+    while len(primes) < count:
+        if _is_prime(v):
+            primes.append(v)
+        v -= 2 * N
+    return N, primes
+
+
 def _bench(extra_env, *flags, timeout=900):
     env = dict(os.environ, HEFX_BENCH_BACKEND="gloo", **extra_env)
     for v in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -269,7 +280,7 @@ def _plant_zero_coefficients(o, ct, L, rng, rows, count):
 
 @pytest.mark.parametrize("setname,L,n,nsrc,zeros", [
     ("C3", 5, 100, 3, None), ("C2", 3, 600, 1, None), ("C3", 2, 72, 18, None), ("C3", 2, 70, 35, None), ("C4", 8, 40, 2, None),
-    ("C5", 5, 36, 1, None), ("C4", 3, 64, 4, None),
+    ("C5", 5, 36, 1, None), ("C4", 3, 64, 4, None), ("E61", 3, 48, 2, None),
     ("C3", 5, 64, 2, "one"), ("C3", 5, 40, 1, "transparent"), ("C2", 3, 600, 2, "second_chunk"), ("C4", 8, 40, 2, "many")])
 def test_shared_source_decomposition_bit_exact(setname, L, n, nsrc, zeros):
     """Batches in which many items rotate the SAME ciphertext (the d-1 rotations of Linear_Transform_Plain, helper.h:252-257)
@@ -279,13 +290,13 @@ def test_shared_source_decomposition_bit_exact(setname, L, n, nsrc, zeros):
     elements (incl. conjugation 2N-1 and large ones), two keys, with and without the fused plaintext product, sources
     interleaved; every output (a sample at n = 600) against the oracle, which decomposes every item on its own.
     n = 600 at N = 8192: two chunks; nsrc = n/4: the boundary of the mode; nsrc = n/2: the same inputs through the
-    ordinary per-item decomposition; C5: N = 32768.
+    ordinary per-item decomposition; C5: N = 32768; E61: four 61-bit primes at N = 4096 (the 128-bit MAC policy).
     zeros: the one input class the hoisted identity does not cover -- a source whose INTT(c1) has a ZERO coefficient in some
     RNS row (a negated zero stays 0, not q_i).  The source decomposition detects it on the device and the chunk is redone
     by the per-item kernels: "one" plants a single zero in one row of one source, "many" 50 in every row, "transparent" is
     c1 = 0, "second_chunk" has the zero in a source only items of the second chunk rotate.  hefx_ks_fallback_count tells
     which path ran: 0 without zeros (the fast path really ran), >= 1 with."""
-    N, primes = SETS[setname]
+    N, primes = _edge61() if setname == "E61" else SETS[setname]
     o, e = _engine_and_oracle(N, primes)
     rng = np.random.default_rng(7 * n + nsrc)
     keys = [_key(o, 91 + i) for i in range(2)]

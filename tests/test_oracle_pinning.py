@@ -195,3 +195,36 @@ def test_transparent_detection(small):
     zero = np.zeros((L, o.N), dtype=np.uint64)
     assert o.is_transparent(o.multiply_plain(ct, zero))
     assert not o.is_transparent(ct)
+
+
+@pytest.mark.parametrize("n,bits,L", [(16, [24, 20, 25], 2), (2048, [50, 30, 30, 30, 50], 4), (2048, [50, 30, 30, 30, 50], 2),
+                                      (4096, [36, 36, 37], 2)])
+def test_exact_hoisting_identity_gives_the_regular_key_switch_bits(n, bits, L):
+    """The identity behind csrc/hefx_keyswitch.hip ks_mac_exact_kernel, on the CPU: decompose the UNROTATED c1 once, gather
+    the extended digits through the Galois table, and add (q_i mod m) * NTT_m(flip mask) per digit -- that accumulator is
+    SEAL's modulo every key modulus, so the output words are those of the regular sequence (rotate in the NTT domain,
+    then decompose the rotated polynomial: orc_apply_galois).  The round 1-3 hoisted statement (no flip term) is a valid
+    key switch with DIFFERENT words.  A zero coefficient in a digit breaks the identity (a negated 0 stays 0, not q_i):
+    the statement reports it and takes the regular sequence."""
+    primes = O.coeff_modulus_create(n, bits)
+    o = O.Oracle(n, primes)
+    k = len(primes)
+    rng = np.random.default_rng(n + L)
+    ct = o.uniform(L, 2, 21)
+    key = o.uniform(k, 2 * (k - 1), 22).reshape(k - 1, 2, k, n)
+    for elt in [3, 2 * n - 1, 5, int(2 * rng.integers(1, n) + 1)]:
+        want = o.apply_galois(ct, elt, key)
+        got, regular = o.apply_galois_hoisted_exact(ct, elt, key)
+        assert not regular and (got == want).all(), elt
+        assert not (o.apply_galois_hoisted(ct, elt, key) == want).all(), "the uncorrected hoisted form has other words"
+    # a zero coefficient in digit 0 of c1
+    z = ct.copy()
+    coef = o.ntt_inv(0, z[1, 0])
+    coef[int(rng.integers(n))] = 0
+    z[1, 0] = o.ntt_fwd(0, coef)
+    got, regular = o.apply_galois_hoisted_exact(z, 3, key)
+    assert regular and (got == o.apply_galois(z, 3, key)).all()
+    # ... and what the identity would have produced there is NOT the regular result when the zero sits on a negated position
+    z[1] = 0  # transparent c1: every coefficient zero
+    got, regular = o.apply_galois_hoisted_exact(z, 2 * n - 1, key)
+    assert regular and (got == o.apply_galois(z, 2 * n - 1, key)).all()
