@@ -149,10 +149,13 @@ class BoardSampler:
         pat = {"sclk_mhz": re.compile(r"GPU\[%d\].*sclk clock level.*\((\d+)Mhz\)" % self.idx),
                "package_power_w": re.compile(r"GPU\[%d\].*Power \(W\):\s*([0-9.]+)" % self.idx),
                "gpu_use_pct": re.compile(r"GPU\[%d\].*GPU use \(%%\):\s*([0-9.]+)" % self.idx)}
+        # the child must not carry a profiler's preloaded tool library: under `rocprofv3 --pmc` that library initialises the
+        # GPU in every process it is loaded into, and rocm-smi (an env -> python3 script) then re-executes itself
+        env = {k: v for k, v in os.environ.items() if k != "LD_PRELOAD" and not k.startswith(("ROCP", "ROCPROF"))}
         while not self._stop.is_set():
             try:
                 out = subprocess.run([exe, "--showclocks", "--showpower", "--showuse"], capture_output=True, text=True,
-                                     timeout=10).stdout
+                                     timeout=10, env=env).stdout
             except Exception:
                 return
             rec = {}

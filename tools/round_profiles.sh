@@ -33,6 +33,9 @@ json.dump({k: dict(launches=n[k], items_per_launch=per, **v) for k, v in agg.ite
 PY
   rm -rf $out/pf_$set $out/pw_$set $out/sq_$set
 done
+# the exactly hoisted linear transform (d = 512, a direct key per step): kernel stats and the timeline of the last call
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_lt_direct -o kt -- python3 tools/lt_direct_probe.py 512 10 > $out/lt_direct_probe.txt 2> $out/kt_lt_direct.err
+python tools/kernel_timeline.py $out/kt_lt_direct > $out/lt_direct_timeline.txt
 find $out -name "*_agent_info.csv" -delete; find $out -name "*kernel_trace.csv" -delete
 python tools/batch_sweep.py C3 > $out/batch_sweep_C3.json 2> $out/batch_sweep.err
 ls $out
