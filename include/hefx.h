@@ -276,7 +276,7 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
  *      pinned on the CPU in tests/test_oracle_pinning.py, and it excludes zero coefficients, which the device detects
  *      and redoes per item).  Rounds 1-3 shipped the uncorrected sum as a fast mode with other words.
  *      hefx_apply_galois_batch / hefx_rotate_multiply_plain_batch / hefx_apply_galois_add_batch take this path by
- *      themselves when a batch of more than 32 items rotates at most n/4 distinct ciphertexts, so this entry is now the
+ *      themselves when a batch of more than 32 items rotates at most n/3 distinct ciphertexts, so this entry is now the
  *      same computation with a stricter contract (one source, which no output may alias) -- kept for its callers.
  *      d_pts may be NULL (no fused multiply_plain). */
 int hefx_rotate_hoisted_batch(hefx_context *ctx, int L, const uint64_t *d_ct_in, int n, const uint32_t *galois_elts,

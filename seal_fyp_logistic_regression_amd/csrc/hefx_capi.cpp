@@ -1181,18 +1181,22 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     auto src = [&](int i) { return ord.empty() ? i : ord[(size_t)i]; };
     const int cmax = n < chunk ? n : chunk;
     const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
-    // EXACT HOISTING (ks_mac_exact_kernel): when at most a quarter as many DISTINCT source ciphertexts as items are rotated
+    // EXACT HOISTING (ks_mac_exact_kernel): when at most a third as many DISTINCT source ciphertexts as items are rotated
     // -- the d-1 rotations of a linear transform rotate ONE (helper.h:252-257) -- every distinct source is decomposed and
     // extended to the key moduli once per chunk and the items run the gathered key MAC with the flip-mask correction:
     // SEAL's bits at (L+1)(L+2) -> 2 + 2L transforms per item (profiles/r04/ab_exact_hoisting.txt).  Not for the
     // small-batch latency path (more launches), in-place rotations (their sources are per-item scratch copies), the
     // fused-transform path, relinearisations.  HEFX_SHARE_SRC=0 switches it off.
     static const bool share_ok = !(getenv("HEFX_SHARE_SRC") && atoi(getenv("HEFX_SHARE_SRC")) == 0);
+    // items per distinct source from which a chunk is hoisted: 3 (HEFX_SHARE_RATIO).  The direct-key transform has d - 1 per
+    // source; the levels of a NAF forest have 2..20, and there 2 and 3 measure 2-3 % under 4 (3.85 / 3.85-3.96 / 3.98-4.01 ms
+    // at C3, d = 512; 2.76-2.79 / 2.70-2.74 / 2.78-2.83 ms at N = 8192, d = 1000)
+    static const size_t share_ratio = getenv("HEFX_SHARE_RATIO") ? (size_t)std::max(1, atoi(getenv("HEFX_SHARE_RATIO"))) : 3;
     bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
     if (share) {
         std::unordered_set<const void *> distinct;
-        for (int i = 0; i < n && distinct.size() * 4 <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
-        share = distinct.size() * 4 <= (size_t)n;
+        for (int i = 0; i < n && distinct.size() * share_ratio <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
+        share = distinct.size() * share_ratio <= (size_t)n;
     }
     if (share)
         if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream)) return rc;
@@ -1240,9 +1244,9 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         int nsrc = 0;  // > 0: this chunk runs exactly hoisted over that many distinct sources
         std::unordered_map<const void *, uint32_t> src_of;
         if (share && cnt > ks_small_max()) {
-            for (int i = 0; i < cnt && src_of.size() * 4 <= (size_t)cnt; ++i)
+            for (int i = 0; i < cnt && src_of.size() * share_ratio <= (size_t)cnt; ++i)
                 src_of.emplace((const void *)ct_in[src(base + i)], (uint32_t)src_of.size());
-            if (src_of.size() * 4 <= (size_t)cnt && cnt + (int)src_of.size() <= KS_MAX_CHUNK) nsrc = (int)src_of.size();
+            if (src_of.size() * share_ratio <= (size_t)cnt && cnt + (int)src_of.size() <= KS_MAX_CHUNK) nsrc = (int)src_of.size();
         }
         for (int i = 0; i < cnt; ++i) {
             KsItem &it = hb[i];

@@ -1,6 +1,7 @@
 """Linear_Transform_Plain (helper.h:237-262) at C3 with a DIRECT Galois key per step (bench.py's
 `lt_sharded.direct_keys_d*` leg on its own, for rocprofv3 --kernel-trace and A/B runs):
-    python tools/lt_direct_probe.py [d=512] [reps=10]"""
+    python tools/lt_direct_probe.py [d=512] [reps=10]
+LT_NAF=1: the reference's default power-of-two keys instead (every rotation a NAF chain; the engine's shared-prefix forest)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -22,7 +23,8 @@ rng = np.random.default_rng(2000 + d)
 M, v = rng.uniform(-1, 1, (d, d)), rng.uniform(-1, 1, d)
 diags = encoder.encode_many(list(alg.get_all_diagonals(M)), 2.0 ** 40)
 ct = enc.encrypt(encoder.encode(v, 2.0 ** 40))
-gk = kg.galois_keys([-d] + list(range(1, d)))
+naf = os.environ.get("LT_NAF") == "1"
+gk = kg.galois_keys() if naf else kg.galois_keys([-d] + list(range(1, d)))
 r = alg.linear_transform_plain(ev, ct, diags, gk)
 eng.sync()
 ts, hs = [], []
@@ -35,5 +37,5 @@ for _ in range(reps):
     hs.append(t1 - t0)
 ms = sorted(ts)[len(ts) // 2] * 1e3
 ok = bool(np.allclose(encoder.decode(dec.decrypt(r))[:d].real, M @ v, atol=1e-3 * d))
-print(f"direct-key LT d={d}: {ms:.3f} ms per call (host submit {sorted(hs)[len(hs)//2]*1e3:.3f} ms), {d/(ms*1e-3):.0f} key switches/s, "
+print(f"{'NAF-key' if naf else 'direct-key'} LT d={d}: {ms:.3f} ms per call (host submit {sorted(hs)[len(hs)//2]*1e3:.3f} ms), {d/(ms*1e-3):.0f} key switches/s, "
       f"decrypts_to_Mv={ok}", flush=True)
