@@ -231,6 +231,37 @@ int main()
         CHECK(fabs(dec(r)[0] - 3.0) < 1e-5, "a recorded rotation is materialised by decrypt");
     }
 
+    // exact hoisting behind the unchanged loop of helper.h:252-257: d - 1 = 40 rotations of ONE ciphertext with a direct
+    // Galois key per step.  Recorded, they reach the engine as one batch, which it runs exactly hoisted (one decomposition
+    // of ct_new, the flip-mask term in the key MAC); executed call by call every rotation is a key switch of its own.  Same
+    // bits -- the hoisted kernels against the per-item kernels, inside one process.
+    {
+        const int d = 41;
+        vector<int> steps{-d};
+        for (int i = 1; i < d; i++) steps.push_back(i);
+        GaloisKeys gd = keygen.galois_keys(steps);
+        vector<Plaintext> diags(d);
+        for (int l = 0; l < d; l++) {
+            vector<double> dv(d);
+            for (int i = 0; i < d; i++) dv[i] = 0.01 * ((i * 7 + l * 3) % 11) - 0.05;
+            encoder.encode(dv, scale, diags[l]);
+        }
+        auto run = [&](bool lazy) {
+            context->engine()->live();
+            context->engine()->lazy = lazy;
+            Ciphertext out = lt_plain(ca, diags, gd, params);
+            auto bits = shim::download(out.buf);
+            context->engine()->lazy = true;
+            return bits;
+        };
+        uint64_t fb0 = 0, fb1 = 0;
+        hefx_ks_fallback_count(context->engine()->live(), &fb0);
+        const auto h = run(true), s1 = run(false);
+        hefx_ks_fallback_count(context->engine()->live(), &fb1);
+        CHECK(h == s1, "Linear_Transform_Plain, 40 direct-key rotations: recorded (exactly hoisted) == call by call, bit for bit");
+        CHECK(fb1 == fb0, "... and the hoisted kernels produced it (no chunk fell back)");
+    }
+
     // the recorder as a dependency graph: the LR loop of the reference (logistic_regression_ckks.cpp:217-229 calling
     // helper.h:432-476 per observation row) -- multiply, relinearize, rescale, rotate(-size), add, then size-1 times
     // rotate-by-1 + add_inplace, a plaintext mod_switch and a mask product per row, add_many at the end -- recorded for

@@ -120,6 +120,35 @@ def test_apply_galois_add_batch_bit_exact(setname, L, n):
             assert (dacc[i].download() == o.add(o.add(accs[i], t1), t2)).all(), ("in-place sum", i)
 
 
+@pytest.mark.parametrize("zero", [False, True])
+def test_apply_galois_add_batch_of_one_source_runs_hoisted_bit_exact(zero):
+    """The accumulate form on a batch the engine hoists (48 rotations of 2 ciphertexts, in-place sums): rotation and sum
+    word for word against rotate-then-add on the oracle; with a planted zero coefficient the chunk takes the per-item
+    fallback, whose epilogue accumulates just the same -- and exactly once (the hoisted epilogue is gated off)."""
+    N, primes = C3
+    o, e = _engine_and_oracle(N, primes)
+    L, n = 4, 48
+    rng = np.random.default_rng(48 + zero)
+    keys = [_key(o, 61 + i) for i in range(2)]
+    dkeys = [e.to_device(k) for k in keys]
+    srcs = [o.uniform(L, 2, 700 + i) for i in range(2)]
+    if zero:
+        srcs[0] = _plant_zero_coefficients(o, srcs[0], L, rng, [1], 2)
+    dsrcs = [e.to_device(c) for c in srcs]
+    accs = [o.uniform(L, 2, 800 + i) for i in range(n)]
+    dacc = [e.to_device(a) for a in accs]
+    si = [int(rng.integers(2)) for _ in range(n)]
+    elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
+    ki = [int(rng.integers(2)) for _ in range(n)]
+    before = e.ks_fallback_count()
+    outs, sums = e.apply_galois_add_batch(L, [dsrcs[s] for s in si], elts, [dkeys[k] for k in ki], dacc, acc_outs=dacc)
+    assert (e.ks_fallback_count() - before) == (1 if zero else 0)
+    for i in range(n):
+        rot = o.apply_galois(srcs[si[i]], elts[i], keys[ki[i]])
+        assert (outs[i].download() == rot).all(), ("rotation", i)
+        assert (dacc[i].download() == o.add(accs[i], rot)).all(), ("sum", i)
+
+
 def test_apply_galois_add_batch_refuses_overlapping_sums():
     N, primes = C2
     o, e = _engine_and_oracle(N, primes)
