@@ -27,6 +27,7 @@
 #include <initializer_list>
 #include <functional>
 #include <map>
+#include <unordered_map>
 #include <tuple>
 #include <memory>
 #include <mutex>
@@ -227,8 +228,26 @@ struct Engine {
         std::uint64_t stream_id = 0;
     };
     std::vector<Node> pend;
-    std::map<const Buf *, int> pend_dst;                                                        // result buffer -> node
-    std::map<std::tuple<const Buf *, std::uint32_t, const Buf *>, int> pend_cse;                // rotations
+    struct CseKey {
+        const Buf *a, *b;
+        std::uint32_t elt;
+        bool operator==(const CseKey &o) const { return a == o.a && b == o.b && elt == o.elt; }
+    };
+    struct CseHash {
+        std::size_t operator()(const CseKey &k) const
+        {
+            return (std::size_t)(((std::uintptr_t)k.a >> 4) * 0x9E3779B97F4A7C15ull ^ ((std::uintptr_t)k.b >> 4) * 0xC2B2AE3D27D4EB4Full ^
+                                 (std::uint64_t)k.elt * 0x165667B19E3779F9ull);
+        }
+    };
+    struct PtrHash {
+        std::size_t operator()(const Buf *p) const { return (std::size_t)(((std::uintptr_t)p >> 4) * 0x9E3779B97F4A7C15ull); }
+    };
+    // result buffer -> node: the index rides in the Buf itself (Buf::pend_idx, valid while Buf::pend_epoch == epoch_ of its
+    // engine) -- a hash-map insert and lookup per recorded call was a fifth of the recording time of a 1000-step transform
+    std::uint32_t epoch_ = 1;
+    inline int pend_index(const Buf *b) const;
+    std::unordered_map<CseKey, int, CseHash> pend_cse;               // rotations: (source, element, key) -> node
     std::size_t pend_bytes = 0, pend_budget = (std::size_t)8192 << 20, pend_check = (std::size_t)8192 << 20;
     std::string failed;  // a batched call of flush() failed: results recorded with it are garbage
     struct Stats {       // SEAL_SHIM_STATS=1 prints them when the process ends
@@ -369,19 +388,23 @@ struct Buf {
         return addr_;
     }
     bool allocated() const { return addr_ != nullptr; }
+    // the recorder's back-pointer: node index of the pending operation that produces this buffer (Engine::pend_index)
+    int pend_idx = -1;
+    std::uint32_t pend_epoch = 0;
 
 private:
     std::uint64_t *addr_ = nullptr;
 };
+inline int Engine::pend_index(const Buf *b) const { return b->eng.get() == this && b->pend_epoch == epoch_ ? b->pend_idx : -1; }
 inline BufPtr new_buf(const std::shared_ptr<Engine> &e, std::size_t words) { return std::make_shared<Buf>(e, words); }
 
-inline bool Engine::pending(const Buf *b) const { return pend_dst.count(b) != 0; }
+inline bool Engine::pending(const Buf *b) const { return pend_index(b) >= 0; }
 
 inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, std::uint32_t elt, int L, int size,
                              std::size_t out_words, const std::shared_ptr<Engine> &self, const Node *extra)
 {
     if (kind == Node::ROT) {  // the same rotation of the same buffer with the same key: computed once
-        auto hit = pend_cse.find(std::make_tuple((const Buf *)a.get(), elt, (const Buf *)b.get()));
+        auto hit = pend_cse.find(CseKey{a.get(), b.get(), elt});
         if (hit != pend_cse.end() && pend[hit->second].L == L) return pend[hit->second].dst;
     }
     Node nd{kind, a, b, new_buf(self, out_words), elt, L, size, 0, 0, -1};
@@ -394,9 +417,9 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     const int idx = (int)pend.size();
     auto link = [&](const BufPtr &in, bool ct_input) {
         if (!in) return;
-        auto p = pend_dst.find(in.get());
-        if (p == pend_dst.end()) return;
-        Node &src = pend[p->second];
+        const int pi = pend_index(in.get());
+        if (pi < 0) return;
+        Node &src = pend[pi];
         nd.depth = std::max(nd.depth, src.depth + 1);
         ++src.consumers;
         if (kind == Node::MULPT && ct_input) src.mulpt_consumer = idx;
@@ -407,11 +430,12 @@ inline BufPtr Engine::record(Node::Kind kind, const BufPtr &a, const BufPtr &b, 
     } else if (kind == Node::MULPT) {
         link(b, false);  // the plaintext may be a recorded encode
     }
-    pend.push_back(nd);
-    pend_dst[nd.dst.get()] = idx;
-    if (kind == Node::ROT) pend_cse[std::make_tuple((const Buf *)a.get(), elt, (const Buf *)b.get())] = idx;
-    pend_bytes += out_words * 8;
     BufPtr out = nd.dst;
+    pend.push_back(std::move(nd));
+    out->pend_idx = idx;
+    out->pend_epoch = epoch_;
+    if (kind == Node::ROT) pend_cse[CseKey{a.get(), b.get(), elt}] = idx;
+    pend_bytes += out_words * 8;
     // bounded memory: run what is recorded once the results it will STORE exceed the budget.  Result buffers take memory
     // only when a submission writes them (Buf is lazy), and the nodes a submission elides -- chain intermediates, rotations
     // inside fused products -- never do: the eight 2000-level gradient chains of the LR driver record 16 GB of results and
@@ -456,7 +480,8 @@ inline void Engine::flush()
 {
     std::vector<Node> K;
     K.swap(pend);
-    pend_dst.clear();
+    pend.reserve(std::min<std::size_t>(K.capacity(), (std::size_t)1 << 17));  // the next recording does not regrow from nothing
+    ++epoch_;  // nothing is pending any more
     pend_cse.clear();
     pend_bytes = 0;
     pend_check = pend_budget;
@@ -659,7 +684,8 @@ inline Engine::Fusion Engine::plan_fusion(const std::vector<Node> &K) const
         fz.unwritten[i] = 1;  // the rotation inside a fused product is never stored
     }
     if (!fuse_add) return fz;
-    std::map<const Buf *, int> producer;
+    std::unordered_map<const Buf *, int, PtrHash> producer;
+    producer.reserve((std::size_t)nk * 2);
     for (int i = 0; i < nk; ++i) producer[K[i].dst.get()] = i;
     // the depth at which a node's result EXISTS: its own, or -- for a sum fused into a rotation -- the rotation's
     std::vector<int> eff_depth(nk);
@@ -779,7 +805,8 @@ inline void Engine::flush_multi(std::vector<Node> &K, const Fusion &fz, int max_
     const int nk = (int)K.size();
     // connected sub-graphs of the recorded dependencies (shared EXTERNAL inputs -- keys, the weight ciphertext -- do not
     // connect: they are replicated)
-    std::map<const Buf *, int> producer;
+    std::unordered_map<const Buf *, int, PtrHash> producer;
+    producer.reserve((std::size_t)nk * 2);
     for (int i = 0; i < nk; ++i) producer[K[i].dst.get()] = i;
     std::vector<int> root(nk);
     for (int i = 0; i < nk; ++i) root[i] = i;
@@ -1000,22 +1027,35 @@ inline std::uint32_t galois_elt_from_step(int step, std::size_t n)
         if ((std::size_t)step >= n / 2) throw std::invalid_argument("step count too large");
         pos = (std::size_t)step;
     }
-    std::uint64_t e = 1;
-    for (std::size_t i = 0; i < pos; ++i) e = (e * 3) & (m - 1);
+    // 3^pos mod 2N by squaring (the loop over pos multiplications was the largest single cost of RECORDING a rotation:
+    // the negative terms of a NAF chain have pos ~ N/2, ~4 us each at N = 8192)
+    std::uint64_t e = 1, b = 3;
+    for (std::size_t x = pos; x; x >>= 1) {
+        if (x & 1) e = (e * b) & (m - 1);
+        b = (b * b) & (m - 1);
+    }
     return (std::uint32_t)e;
 }
 
-inline std::vector<int> naf(int value)
+// non-adjacent form, least significant term first; out holds at most 33 terms.  (No allocation: this runs once per
+// recorded rotate_vector.)
+inline int naf_terms(int value, int (&out)[34])
 {
-    std::vector<int> res;
+    int cnt = 0;
     const bool sign = value < 0;
     value = std::abs(value);
     for (int i = 0; value; ++i) {
         const int zi = (value & 1) ? 2 - (value & 3) : 0;
         value = (value - zi) >> 1;
-        if (zi) res.push_back((sign ? -zi : zi) * (1 << i));
+        if (zi) out[cnt++] = (sign ? -zi : zi) * (1 << i);
     }
-    return res;
+    return cnt;
+}
+inline std::vector<int> naf(int value)
+{
+    int t[34];
+    const int cnt = naf_terms(value, t);
+    return std::vector<int>(t, t + cnt);
 }
 
 inline std::uint32_t bitrev(std::uint32_t x, int bits)
@@ -2393,7 +2433,8 @@ public:
         check_ct(a);
         if (!ctx_->is_ckks()) throw std::logic_error("unsupported scheme");
         if (a.size() != 2) throw std::invalid_argument("encrypted size must be 2");
-        std::vector<std::uint32_t> plan;
+        static thread_local std::vector<std::uint32_t> plan;  // reused: no allocation per recorded rotation
+        plan.clear();
         rotation_plan(steps, gk, plan);
         shim::BufPtr cur = a.buf;
         for (std::uint32_t elt : plan) {
@@ -2465,11 +2506,12 @@ public:
             plan.push_back(elt);
             return;
         }
-        const std::vector<int> terms = shim::naf(steps);
-        if (terms.size() == 1) throw std::invalid_argument("Galois key not present");
-        for (int t : terms) {
-            if ((std::size_t)std::abs(t) == n / 2) continue;
-            rotation_plan(t, gk, plan);
+        int terms[34];
+        const int nt = shim::naf_terms(steps, terms);
+        if (nt == 1) throw std::invalid_argument("Galois key not present");
+        for (int i = 0; i < nt; ++i) {
+            if ((std::size_t)std::abs(terms[i]) == n / 2) continue;
+            rotation_plan(terms[i], gk, plan);
         }
     }
 
