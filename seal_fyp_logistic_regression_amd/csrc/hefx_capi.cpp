@@ -151,6 +151,7 @@ struct hefx_context {
     // elements per allocation; q_i mod q_m [k][k]; one gate word per descriptor-ring slot + the count of chunks redone
     std::unordered_map<uint32_t, u64 *> flipw;
     std::vector<void *> flipw_slabs;
+    size_t flipw_bytes = 0, flipw_cap = (size_t)8 << 30;  // tables are kept for the context's life: bounded (HEFX_FLIPW_MB)
     u64 *d_qmod = nullptr;
     uint32_t *d_gate = nullptr;
     uint32_t gate_seq = 0;
@@ -409,6 +410,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         if (e == hipSuccess) e = hipMemset(c->d_gate, 0, sizeof(uint32_t) * (KS_RING + 1));
     }
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
+    if (const char *fv = getenv("HEFX_FLIPW_MB")) c->flipw_cap = (size_t)strtoull(fv, nullptr, 10) << 20;
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
     if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "round") ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR;
@@ -981,20 +983,33 @@ static uint32_t inv_mod_2n(uint32_t elt, uint32_t n)
 // exact hoisting's per-element tables (ks_mac_exact_kernel: W_g[m] = NTT_m(F_g)), for every element of `elts` that has none
 // yet: one allocation, one mask launch, one transform launch for all of them, then a wait -- a cached table may be read
 // from any stream later.  First use only; a linear transform's d tables cost about what its d gather tables do.
-static int ensure_flipw(hefx_context *c, const uint32_t *elts, int n, hipStream_t s)
+// out[i] = the table of elts[i], resolved under the context's lock (the map may grow under another thread's call).
+static int ensure_flipw(hefx_context *c, const uint32_t *elts, int n, hipStream_t s, std::vector<const u64 *> &out)
 {
+    out.assign((size_t)n, nullptr);
     std::vector<uint32_t> miss;
+    auto resolve = [&] {  // caller holds c->mu
+        miss.clear();
+        for (int i = 0; i < n; ++i) {
+            auto it = c->flipw.find(elts[i] ? elts[i] : 1u);
+            if (it != c->flipw.end())
+                out[(size_t)i] = it->second;
+            else
+                miss.push_back(elts[i] ? elts[i] : 1u);
+        }
+    };
     {
         std::lock_guard<std::mutex> lk(c->mu);
-        for (int i = 0; i < n; ++i) {
-            const uint32_t e = elts[i] ? elts[i] : 1u;
-            if (!c->flipw.count(e) && std::find(miss.begin(), miss.end(), e) == miss.end()) miss.push_back(e);
-        }
+        resolve();
     }
     if (miss.empty()) return HEFX_OK;
     std::sort(miss.begin(), miss.end());
     miss.erase(std::unique(miss.begin(), miss.end()), miss.end());
     const size_t per = (size_t)c->k * c->n;
+    if (c->flipw_bytes + per * miss.size() * sizeof(u64) > c->flipw_cap) {  // over the budget: this batch runs unhoisted (same bits)
+        out.clear();
+        return HEFX_OK;
+    }
     std::vector<uint32_t> ginv(miss.size());
     for (size_t i = 0; i < miss.size(); ++i) ginv[i] = inv_mod_2n(miss[i], c->n);
     u64 *rows = nullptr;
@@ -1015,7 +1030,9 @@ static int ensure_flipw(hefx_context *c, const uint32_t *elts, int n, hipStream_
     }
     std::lock_guard<std::mutex> lk(c->mu);
     c->flipw_slabs.push_back(rows);
-    for (size_t i = 0; i < miss.size(); ++i) c->flipw[miss[i]] = rows + per * i;
+    c->flipw_bytes += per * miss.size() * sizeof(u64);
+    for (size_t i = 0; i < miss.size(); ++i) c->flipw.emplace(miss[i], rows + per * i);  // (keeps another thread's earlier table)
+    resolve();
     return HEFX_OK;
 }
 
@@ -1198,8 +1215,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         for (int i = 0; i < n && distinct.size() * share_ratio <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
         share = distinct.size() * share_ratio <= (size_t)n;
     }
-    if (share)
-        if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream)) return rc;
+    std::vector<const u64 *> flips;
+    if (share) {
+        if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream, flips)) return rc;
+        if (flips.empty()) share = false;  // the tables' memory budget is spent
+    }
     // (a hoisted chunk's fallback runs the digit transforms of all its items at once: x for the whole chunk)
     const size_t x_words = ks_x_words(c, L, fused || share || sub > cmax ? cmax : sub);
     const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
@@ -1264,7 +1284,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.flipw = nullptr;
             if (nsrc) {
                 it.dsrc = src_of[(const void *)ct_in[j]];
-                it.flipw = c->flipw.at(it.elt ? it.elt : 1u);
+                it.flipw = flips[(size_t)j];
             }
             if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
                 it.c_in = S.alias + (size_t)i * 2 * L * N;

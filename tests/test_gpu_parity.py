@@ -436,7 +436,8 @@ def test_hoisted_chunking_and_policies_bit_exact(c3):
         "print('PARITY', ok)\n") % (root, primes)
     # 45 items: one hoisted chunk; chunks of 40 + 5 (hoisted kernels, then the latency path) on two streams; serial chunks
     # of 36 + 9; the integer policies for every modulus; hoisting switched off
-    for env in ({}, {"HEFX_CHUNK": "40"}, {"HEFX_STREAMS": "0", "HEFX_CHUNK": "36"}, {"HEFX_NO_FP64": "1"}, {"HEFX_SHARE_SRC": "0"}):
+    for env in ({}, {"HEFX_CHUNK": "40"}, {"HEFX_STREAMS": "0", "HEFX_CHUNK": "36"}, {"HEFX_NO_FP64": "1"}, {"HEFX_SHARE_SRC": "0"},
+                {"HEFX_FLIPW_MB": "1"}):  # ... and with no room for the flip tables (the batch then runs unhoisted)
         r = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
                            timeout=600)
         assert "PARITY True" in r.stdout, (env, r.stdout[-500:], r.stderr[-1500:])
