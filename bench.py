@@ -351,6 +351,10 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         out[f"direct_keys_d{d}"] = {
             "serial_ms": ms, "key_switches": ks, "galois_keys": len(gk_direct.keys), "key_bytes": len(gk_direct.keys) * kb,
             "key_switches_per_s": ks / (ms * 1e-3), "key_GBps": ks * kb / (ms * 1e-3) / 1e9,
+            # every rotation reads its own key: the regime roofline.frac prices (8 N L (2L+7) algorithmic bytes per key switch)
+            "frac_of_8TBps_algorithmic": ks / (ms * 1e-3) * 8 * N * (len(primes) - 1) * (2 * (len(primes) - 1) + 7) / 8e12,
+            "note": "d-1 rotations of ONE ciphertext, a direct Galois key per step: run exactly hoisted (SEAL's bits; "
+                    "DESIGN.md 'Exact hoisting'), wall time per call incl. the host side",
             "decrypts_to_Mv": bool(np.allclose(encoder.decode(dec.decrypt(r))[:d].real, M @ v, atol=1e-3 * d))}
         del gk_direct
     return out
