@@ -47,6 +47,19 @@ def _worker(rank, world, port, q):
         sharded = par.linear_transform_plain_sharded(ev, ct, diags, gk)
         lt_same = bool((bits(serial) == bits(sharded)).all())
         lt_val = bool(np.allclose(encoder.decode(dec.decrypt(sharded))[:d].real, M @ v, atol=1e-4))
+        # d = 80 with a direct Galois key per step: each rank's share is ~40 rotations of ct_new in one batch, which the
+        # engine runs exactly hoisted -- as it does the serial form's 79; same bits, and no chunk fell back
+        d2 = 80
+        M2, v2 = rng.standard_normal((d2, d2)), rng.standard_normal(d2)
+        gk2 = kg.galois_keys([-d2] + list(range(1, d2)))
+        diags2 = encoder.encode_many(list(alg.get_all_diagonals(M2)), scale)
+        ct2 = enc.encrypt(encoder.encode(v2, scale))
+        fb0 = ctx.backend.engine.ks_fallback_count()
+        serial2 = alg.linear_transform_plain(ev, ct2, diags2, gk2)
+        sharded2 = par.linear_transform_plain_sharded(ev, ct2, diags2, gk2)
+        lt_same = lt_same and bool((bits(serial2) == bits(sharded2)).all()) and ctx.backend.engine.ks_fallback_count() == fb0
+        lt_val = lt_val and bool(np.allclose(encoder.decode(dec.decrypt(sharded2))[:d2].real, M2 @ v2, atol=1e-3))
+        del gk2, diags2
         X, w = rng.uniform(-1, 1, (5, 4)), rng.uniform(-0.5, 0.5, 4)
         feats = [enc.encrypt(encoder.encode(r, scale)) for r in X]
         cw = enc.encrypt(encoder.encode(w, scale))
