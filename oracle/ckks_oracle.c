@@ -533,10 +533,10 @@ static void moddown_into(const orc_ctx *c, int L, const uint64_t *S, uint64_t *c
 }
 
 /* tab == NULL: SEAL's key switch of `target` (App. A.8).
- * tab != NULL: the HOISTED variant (csrc/hefx_keyswitch.hip, ks_mac_hoisted_kernel): `target` is
- * the UNROTATED c1; its digits are extended to every modulus once and each extended row is read through the Galois
- * gather table, i.e. the automorphism is applied AFTER the decomposition.  Not SEAL's bits: where the automorphism
- * negates a coefficient, SEAL's digit is q_i - a (positive lift) and this one is -a. */
+ * tab != NULL: the HOISTED variant: `target` is the UNROTATED c1; its digits are extended to every
+ * modulus once and each extended row is read through the Galois gather table, i.e. the automorphism is applied AFTER
+ * the decomposition.  With flip == NULL this is the uncorrected sum (what rounds 1-3 shipped as a fast mode) -- other
+ * words than SEAL's: where the automorphism negates a coefficient, SEAL's digit is q_i - a (positive lift), this one -a. */
 /* flip != NULL (with tab): the EXACT hoisted form (csrc/hefx_keyswitch.hip, ks_mac_exact_kernel).  flip[a] = 1 where the
  * automorphism negates the coefficient that lands at position a.  SEAL's digit of the rotated polynomial is
  * sigma(T_i) + q_i * flip as an integer vector (T_i = the unrotated digit, sigma the signed permutation over Z) unless T_i

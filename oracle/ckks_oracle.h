@@ -106,7 +106,8 @@ void orc_encode(const orc_ctx *c, int L, const double *vals_ri, int nvals, doubl
 void orc_decode(const orc_ctx *c, int L, const uint64_t *pt, double scale, double *vals_ri);
 
 
-/* hoisted rotation (fast mode of csrc/hefx_keyswitch.hip; not SEAL's bits, see ckks_oracle.c) */
+/* the UNCORRECTED hoisted rotation (what rounds 1-3 shipped as a fast mode; other words than SEAL's, see ckks_oracle.c):
+ * kept as the counter-example of tests/test_oracle_pinning.py -- the engine runs orc_apply_galois_hoisted_exact's identity */
 void orc_apply_galois_hoisted(const orc_ctx *c, int L, const uint64_t *ct_in, uint64_t elt, const uint64_t *key,
                               uint64_t *ct_out);
 

@@ -220,7 +220,8 @@ class Oracle:
         return out
 
     def apply_galois_hoisted(self, ct, elt, key):
-        """hoisted-rotation fast mode (decompose, then permute): NOT SEAL's bits, see ckks_oracle.c"""
+        """the UNCORRECTED hoisted rotation (decompose, then permute; rounds 1-3's fast mode): other words than SEAL's --
+        the counter-example beside apply_galois_hoisted_exact"""
         out = np.zeros_like(ct)
         lib().orc_apply_galois_hoisted(self._h, ct.shape[1], np.ascontiguousarray(ct), elt, key, out)
         return out

@@ -119,10 +119,11 @@ def linear_transform_plain(ev: Evaluator, ct: Ciphertext, U_diagonals: Sequence[
     context.key_parms_id())), ct at the top data level; the products are accumulated over the extended basis and modded
     down once (hefx_linear_transform_plain_hoisted2) -- per rotation only a gathered key MAC remains.
 
-    hoisted=True is the fast mode of SURVEY 8f rank 3: the d-1 rotations of ct_new share one digit decomposition
-    (hefx_rotate_hoisted_batch).  It needs a direct Galois key per step (keygen.galois_keys(steps)) and is NOT
-    bit-identical to the reference's sequence (signed instead of positive digit lifts where the automorphism
-    negates a coefficient); it decrypts to the same values with the same noise bound."""
+    hoisted=True asks for SURVEY 8f rank 3 explicitly: the d-1 rotations of ct_new share one digit decomposition
+    (hefx_rotate_hoisted_batch); it needs a direct Galois key per step (keygen.galois_keys(steps)).  Since round 4 the
+    hoisted form is EXACT -- the engine adds the term by which SEAL's positive digit lifts differ from the signed ones
+    (DESIGN.md "Exact hoisting") -- so this is bit-identical to the reference's sequence with those keys, and the plain
+    call (hoisted=False) takes the same path by itself whenever more than 32 rotations share a source."""
     d = len(U_diagonals)
     if hoisted == 2:
         return _linear_transform_plain_hoisted2(ev, ct, U_diagonals, gal_keys)

@@ -377,7 +377,8 @@ class Engine:
         return buf
 
     def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None, outs=None, stream=None):
-        """n rotations of ONE ciphertext sharing its digit decomposition (fast mode, not bit-identical to rotate_vector)"""
+        """n rotations of ONE ciphertext sharing its digit decomposition -- exactly hoisted since round 4: the words of
+        apply_galois_batch (hefx.h: hefx_rotate_hoisted_batch); the one source may be no item's output"""
         n = len(elts)
         outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
         capi.check(capi.lib().hefx_rotate_hoisted_batch(

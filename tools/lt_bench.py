@@ -3,7 +3,7 @@
 timer at linear_transformation.cpp:540-542.  Three modes:
   naf      the reference's setup: default power-of-two Galois keys, NAF chains (bit-exact to the op-by-op sequence)
   direct   a direct Galois key per step (keygen.galois_keys(steps)): one key switch per rotation (bit-exact)
-  hoisted  direct keys + shared digit decomposition (fast mode, not SEAL's bits; same decryption)
+  hoisted  direct keys through the explicit hoisted entry (since round 4 the same computation and words as `direct`)
   hoisted2 double hoisting: additionally ONE mod-down for the whole transform (key-level diagonals)
   bsgs     baby-step/giant-step (algorithms.linear_transform_plain_bsgs): ~2*sqrt(d) keys and key switches, hoisted
            baby steps, inner sums through hefx_multiply_plain_sum"""
