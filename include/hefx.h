@@ -389,7 +389,9 @@ int hefx_event_elapsed_ms(hefx_context *ctx, void *event_start, void *event_stop
  * its launches; end returns the summed duration per launch kind (see hefx_profile_stage_name) and the
  * number of chunks, so average launch duration = stage_ms[k] / launches. */
 int hefx_profile_begin(hefx_context *ctx);
-int hefx_profile_end(hefx_context *ctx, double *stage_ms /* [6] */, uint64_t *launches);
+#define HEFX_PROFILE_STAGES 8 /* launch kinds hefx_profile_end reports; the last one: the (normally empty) fallback launches of
+                                 an exactly hoisted chunk */
+int hefx_profile_end(hefx_context *ctx, double *stage_ms /* [HEFX_PROFILE_STAGES] */, uint64_t *launches);
 const char *hefx_profile_stage_name(int k);
 
 #ifdef __cplusplus

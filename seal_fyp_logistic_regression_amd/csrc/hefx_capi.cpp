@@ -1859,7 +1859,8 @@ extern "C" const char *hefx_profile_stage_name(int k)
     static const char *names[KS_STAGES] = {"ks_alias_copy_kernel",   "ks_intt_digits_kernel",
                                            "ks_ntt_digits_kernel",   "ks_mac_kernel",
                                            "ks_moddown_intt_kernel", "ks_moddown_finish_kernel",
-                                           "ks_ntt_mac_kernel"};
+                                           "ks_ntt_mac_kernel",      "gated fallback launches"};
+    static_assert(KS_STAGES == HEFX_PROFILE_STAGES, "profile stage count");
     return (k >= 0 && k < KS_STAGES) ? names[k] : "";
 }
 

@@ -135,7 +135,7 @@ hipError_t launch_multiply(const DevTables &T, int L, const u64 *a, const u64 *b
 hipError_t launch_addsub_table(const DevTables &T, bool sub, int L, int size, const u64 *const *d_tab, int n,
                                hipStream_t s);
 // profiling: an event is recorded before every launch (tagged with its stage) and one after the last
-constexpr int KS_STAGES = 7;
+constexpr int KS_STAGES = 8;  // == HEFX_PROFILE_STAGES (hefx.h)
 struct KsProf {
     hipEvent_t *ev;  // capacity `cap`
     int *stage;      // stage[i] = launch kind that follows ev[i]; -1 terminates a chunk

@@ -1498,7 +1498,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
                            0, n * 2, hs);
         // the fallback: the ordinary five launches, which exit at once unless a source of this chunk held a zero coefficient
-        mark(0);
+        mark(7);
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, 0, 0,
                            n * L, fb);
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds_ntt, s, T, L, n * L, 0, 0,

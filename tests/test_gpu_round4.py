@@ -149,6 +149,29 @@ def test_apply_galois_add_batch_of_one_source_runs_hoisted_bit_exact(zero):
         assert (dacc[i].download() == o.add(accs[i], rot)).all(), ("sum", i)
 
 
+def test_profile_session_over_a_hoisted_batch():
+    """hefx_profile_begin/end around a batch the engine hoists: the per-launch-kind report has HEFX_PROFILE_STAGES entries,
+    the exact MAC is booked under the MAC stage, the (empty) fallback launches under their own, and the results are still
+    the oracle's (a profile session runs the chunks serially on the caller's stream)."""
+    N, primes = C3
+    o, e = _engine_and_oracle(N, primes)
+    L, n = 5, 64
+    key = _key(o, 77)
+    dk = e.to_device(key)
+    src = o.uniform(L, 2, 4242)
+    dsrc = e.to_device(src)
+    elts = [2 * i + 3 for i in range(n)]
+    e.apply_galois_batch(L, [dsrc] * n, elts, [dk] * n)  # first use: tables
+    e.profile_begin()
+    outs = e.apply_galois_batch(L, [dsrc] * n, elts, [dk] * n)
+    stages, chunks = e.profile_end()
+    assert chunks == 1 and len(stages) == 8 and "gated fallback launches" in stages
+    assert stages["ks_mac_kernel"] > 0 and stages["ks_moddown_finish_kernel"] > 0
+    assert 0 < stages["gated fallback launches"] < 0.5 * sum(stages.values()), stages  # five empty launches, not a second key switch
+    for i in (0, 17, 63):
+        assert (outs[i].download() == o.apply_galois(src, elts[i], key)).all()
+
+
 def test_apply_galois_add_batch_refuses_overlapping_sums():
     N, primes = C2
     o, e = _engine_and_oracle(N, primes)
