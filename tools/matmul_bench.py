@@ -4,7 +4,8 @@ encoded / encrypted, keys generated beforehand), median of 5 calls incl. the hos
           default power-of-two Galois keys (bit-exact to the op-by-op sequence)
   sparse  algorithms.cc_matrix_multiplication_sparse: the non-zero diagonals only (fast mode), the reference's keys
   sparse_direct  the same with a direct Galois key for every step it uses (one key switch per rotation)
-  sparse_hoisted direct keys + the sigma / tau rotations on a shared digit decomposition
+  sparse_hoisted direct keys + the sigma / tau rotations through the explicit hoisted entry (exact since round 4: same
+                 words as sparse_direct; above 32 rotations per source both run hoisted)
   sparse_hoisted2 the sigma / tau transforms double-hoisted (key-level diagonals, one mod-down each)
 usage: matmul_bench.py [C3|C5] n [dense|sparse|sparse_direct|sparse_hoisted|sparse_hoisted2 ...]"""
 import json, os, sys, time
