@@ -149,6 +149,36 @@ def test_apply_galois_add_batch_of_one_source_runs_hoisted_bit_exact(zero):
         assert (dacc[i].download() == o.add(accs[i], rot)).all(), ("sum", i)
 
 
+@pytest.mark.parametrize("setname,L,n,nsrc", [("C3", 5, 512, 1), ("C3", 3, 300, 7), ("C4", 8, 256, 2), ("C4", 5, 200, 50),
+                                              ("C5", 5, 160, 1), ("C2", 3, 1100, 3), ("C2", 1, 400, 1)])
+def test_hoisted_equals_per_item_on_the_device_every_output(setname, L, n, nsrc):
+    """Full-size cross-check without the oracle's cost: the same rotations once as ONE batch (hoisted: the engine decomposes
+    each source once per chunk) and once in slices of 32 items (the per-item kernels) -- every word of every output equal,
+    with the fused plaintext product, eight keys, random elements, at top and lower levels.  (The oracle-backed test above
+    pins both against SEAL's sequence on samples; this one compares all n outputs.)"""
+    N, primes = SETS[setname]
+    o, e = _engine_and_oracle(N, primes)
+    rng = np.random.default_rng(1000 * L + n)
+    dkeys = [e.sample("uniform", bytes([i] * 32), 1, 2 * (o.k - 1), o.k, 0) for i in range(8)]
+    dsrcs = [e.sample("uniform", bytes([100 + i] * 32), 2, 2, L, 0) for i in range(nsrc)]
+    dpts = [e.sample("uniform", bytes([200 + i] * 32), 3, 1, L, 0) for i in range(4)]
+    si = [int(rng.integers(nsrc)) for _ in range(n)]
+    elts = [int(2 * rng.integers(1, N) + 1) for _ in range(n)]
+    ki = [int(rng.integers(8)) for _ in range(n)]
+    args = lambda idx: (L, [dsrcs[si[i]] for i in idx], [elts[i] for i in idx], [dkeys[ki[i]] for i in idx])
+    before = e.ks_fallback_count()
+    one = e.rotate_multiply_plain_batch(*args(range(n)), [dpts[i % 4] for i in range(n)])
+    plain = e.apply_galois_batch(*args(range(n)))
+    assert e.ks_fallback_count() == before
+    for lo in range(0, n, 32):
+        idx = range(lo, min(n, lo + 32))
+        a = e.rotate_multiply_plain_batch(*args(idx), [dpts[i % 4] for i in idx])
+        b = e.apply_galois_batch(*args(idx))
+        for j, i in enumerate(idx):
+            assert (a[j].download() == one[i].download()).all(), ("fused", i)
+            assert (b[j].download() == plain[i].download()).all(), ("plain", i)
+
+
 def test_profile_session_over_a_hoisted_batch():
     """hefx_profile_begin/end around a batch the engine hoists: the per-launch-kind report has HEFX_PROFILE_STAGES entries,
     the exact MAC is booked under the MAC stage, the (empty) fallback launches under their own, and the results are still
