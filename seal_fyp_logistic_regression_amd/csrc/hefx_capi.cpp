@@ -392,7 +392,14 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, c->flag_cap * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, c->flag_cap * sizeof(int));
-    for (int s = 0; s < hefx_context::MAX_STREAMS && e == hipSuccess; ++s) {
+    if (const char *ev = getenv("HEFX_STREAMS")) {
+        const int v = atoi(ev);
+        c->use_streams = v != 0;
+        if (v >= 2 && v <= hefx_context::MAX_STREAMS) c->nstreams = v;
+    }
+    // only the internal streams that will be used (two unless HEFX_STREAMS asks for more): a stream is a hardware queue,
+    // 8-20 ms each to create -- a visible part of a short process like the reference's drivers
+    for (int s = 0; s < c->nstreams && e == hipSuccess; ++s) {
         e = hipStreamCreateWithFlags(&c->streams[s], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[s], hipEventDisableTiming);
     }
@@ -414,11 +421,6 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
     if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "round") ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR;
-    if (const char *ev = getenv("HEFX_STREAMS")) {
-        const int v = atoi(ev);
-        c->use_streams = v != 0;
-        if (v >= 2 && v <= hefx_context::MAX_STREAMS) c->nstreams = v;
-    }
     if (e != hipSuccess) {
         if (c->d_tables) (void)hipFree(c->d_tables);
         delete c;
