@@ -40,11 +40,31 @@ while time.time() < t_end:
         e.apply_galois_batch(L, dcts, elts, [dkeys[j] for j in ki], outs=dcts)
         for i in range(n):
             assert (dcts[i].download() == o.apply_galois(cts[i], elts[i], keys[ki[i]])).all(), ("inplace", N, bits, L, i)
-        # hoisted
+        # hoisted entry (exact since round 4: the regular words)
         src = e.to_device(cts[0])
         ho = e.rotate_hoisted_batch(L, src, elts, [dkeys[j] for j in ki])
         for i in range(n):
-            assert (ho[i].download() == o.apply_galois_hoisted(cts[0], elts[i], keys[ki[i]])).all(), ("hoist", N, bits, L, i)
+            assert (ho[i].download() == o.apply_galois(cts[0], elts[i], keys[ki[i]])).all(), ("hoist", N, bits, L, i)
+        # a batch the engine hoists by itself: 33..72 rotations of 1..3 sources, now and then with a zero coefficient planted
+        # in one source (the chunk then takes the on-device per-item fallback); a sample of the outputs against the oracle
+        nb, ns = int(rng.integers(33, 73)), int(rng.integers(1, 4))
+        srcs = [cts[i % n].copy() for i in range(ns)]
+        planted = rng.random() < 0.3
+        if planted:
+            row = int(rng.integers(L))
+            coef = o.ntt_inv(row, srcs[0][1, row])
+            coef[int(rng.integers(N))] = 0
+            srcs[0][1, row] = o.ntt_fwd(row, coef)
+        dsr = [e.to_device(x) for x in srcs]
+        sb = [int(rng.integers(ns)) for _ in range(nb)]
+        eb = [int(2 * rng.integers(1, N) + 1) for _ in range(nb)]
+        kb = [int(rng.integers(nkeys)) for _ in range(nb)]
+        fb0 = e.ks_fallback_count()
+        hb = e.apply_galois_batch(L, [dsr[x] for x in sb], eb, [dkeys[x] for x in kb])
+        assert (e.ks_fallback_count() > fb0) == (planted and 0 in sb), ("fallback count", N, bits, L, planted)
+        for i in sorted(set([0, nb - 1] + [int(x) for x in rng.integers(0, nb, 4)])):
+            assert (hb[i].download() == o.apply_galois(srcs[sb[i]], eb[i], keys[kb[i]])).all(), ("auto-hoist", N, bits, L, i)
+            checks += 1
         # multiply / relinearize / rescale
         a, b = cts[0], o.uniform(L, 2, seed + 999)
         m = o.multiply(a, b)
