@@ -248,7 +248,7 @@ def launch(args) -> int:
 # ------------------------------------------------------------------------------------------------------------------
 # the sharded linear transform (SURVEY 8d "Scaling runs", 8e-i)
 # ------------------------------------------------------------------------------------------------------------------
-def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int = 0):
+def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int = 0, use_pg: bool = False):
     """Linear_Transform_Plain at C3 with the reference's default (power-of-two, NAF-expanded) Galois keys: the serial
     one-call form on this rank, and -- with more than one rank -- the diagonal-sharded form with its one all-reduce.
     Same seeds on every rank => same keys, ciphertext and diagonals everywhere (what a broadcast at setup would give)."""
@@ -278,7 +278,7 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         def timed(fn):
             r = fn()  # warm-up (scratch growth, Galois tables, pool slabs)
             eng.sync()
-            if world > 1:
+            if use_pg:
                 dist.barrier()
             t0 = time.perf_counter()
             for _ in range(reps):
@@ -289,7 +289,19 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         serial, serial_ms = timed(lambda: alg.linear_transform_plain(ev, ct, diags, gk))
         ok = bool(np.allclose(encoder.decode(dec.decrypt(serial))[:d].real, M @ v, atol=1e-3 * d))
         rec = {"serial_ms": serial_ms, "decrypts_to_Mv": ok, "key_switches_serial": alg_key_switches(ev, d, gk)}
-        if world > 1:
+        # what the transform really executes with the reference's default keys (linear_transformation2.cpp:239): the engine's
+        # own counters around ONE more call -- key switches after prefix sharing of the NAF forest (the op-by-op loop runs
+        # `key_switches_serial`), how many ran exactly hoisted, launch sequences -- and the algorithmic-byte rate of the
+        # executed key switches, each pricing its own key read (8 N L (2L+7) bytes, the basis of roofline.frac)
+        s0 = eng.ks_stats()
+        alg.linear_transform_plain(ev, ct, diags, gk)
+        s1 = eng.ks_stats()
+        Lr = len(primes) - 1
+        ex = s1["key_switches"] - s0["key_switches"]
+        rec.update({"key_switches_executed": ex, "hoisted_items": s1["hoisted"] - s0["hoisted"],
+                    "launch_sequences": s1["chunks"] - s0["chunks"], "key_switches_per_s": ex / (serial_ms * 1e-3),
+                    "frac_of_8TBps_algorithmic": ex / (serial_ms * 1e-3) * 8 * N * Lr * (2 * Lr + 7) / 8e12})
+        if use_pg:
             par.ENGINE_COMM = "off"   # this leg: the exchange through torch.distributed (in place on the payload)
             sharded, sharded_ms = timed(lambda: par.linear_transform_plain_sharded(ev, ct, diags, gk))
             same = bool((bits(serial) == bits(sharded)).all())
@@ -365,6 +377,56 @@ def alg_key_switches(ev, d, gk) -> int:
     return sum(len(ev.rotation_plan(s, gk)) for s in [-d] + list(range(1, d)))
 
 
+def secondary_bench(name, Engine, local_rank, rank, world, timed, key32, seconds=1.0):
+    """the bench unit at parameter set `name`: value (whole job), ms_per_step, roofline.frac, verified"""
+    import hashlib
+    N, primes = SETS[name]
+    k = len(primes)
+    L = k - 1
+    B = {"C2": 9216, "C3": 4608, "C4": 2304, "C5": 2304}[name]
+    e2 = Engine(N, primes, device=local_rank)
+    big_ct = e2.sample("uniform", key32("ct:" + name), 1, 2 * B, L, 0)
+    big_pt = e2.sample("uniform", key32("pt:" + name), 2, B, L, 0)
+    big_out = e2.empty(B, 2, L, N)
+    key = e2.sample("uniform", hashlib.sha256(("hefx-bench:key:" + name).encode()).digest(), 3, 2 * L, k, 0).view(0, (L, 2, k, N))
+    cts = [big_ct.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
+    pts = [big_pt.view(i * L * N, (L, N)) for i in range(B)]
+    outs = [big_out.view(i * 2 * L * N, (2, L, N)) for i in range(B)]
+    elts, keys = [3] * B, [key] * B
+    fn = lambda: e2.rotate_multiply_plain_batch(L, cts, elts, keys, pts, outs)
+    one, _ = timed(fn, 2, 2, e2)
+    steps = max(3, int(seconds / max(one / 2, 1e-6)))
+    dt, gpu_ms = timed(fn, steps, 0, e2)
+    verified = None
+    if rank == 0:
+        try:
+            from oracle import oracle as O
+            o = O.Oracle(N, primes)
+            hk = key.download()
+            verified = all(bool((outs[i].download() == o.rotate_mulplain(cts[i].download(), 3, hk, pts[i].download())).all())
+                           for i in (0, B // 2 + 1, B - 1))
+        except Exception as ex:
+            verified = f"not checked: {ex!r}"
+    bytes_op = algorithmic_bytes_per_op(N, L)
+    achieved = B * bytes_op / (gpu_ms / steps * 1e-3) / 1e9
+    valu = valu_bound_ops_per_s(N, primes, L)
+    value = B * steps * world / dt
+    return {"workload": f"{name}: N={N}, coeff_modulus bits {[p.bit_length() for p in primes]}, L={L}; {B} independent "
+                        "rotate_vector(step=1, direct key)+multiply_plain per step and GPU",
+            "value": value, "unit": "rotate+multiply_plain ops/s", "steps": steps, "ms_per_step": dt / steps * 1e3,
+            "batch_per_gpu": B, "verified": verified,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "algorithmic_bytes_per_op": bytes_op,
+                         "valu_frac": value / world / valu["peak_ops_per_s"]}}
+
+
+def _hashes():
+    """(source hash, library hash) of the engine that runs: written into the line and compared with the hashes the
+    profile tools wrote into profiles/*_pmc_traffic.json / *_sq_counters.json -- counters of other kernels are stale"""
+    from seal_fyp_logistic_regression_amd import _build
+    return _build.source_sha16(), _build.library_sha16()
+
+
 # ------------------------------------------------------------------------------------------------------------------
 def main():
     ap = argparse.ArgumentParser()
@@ -380,9 +442,17 @@ def main():
                     "of keys at C3); 0 disables")
     ap.add_argument("--key-per-item", type=int, default=1024, help="items of the key-per-item pass (one Galois key each: "
                     "8 GB of keys at 1024, C3); 0 disables")
+    ap.add_argument("--sustain", type=float, default=2.5, help="seconds of the second, longer headline pass (0 disables)")
+    ap.add_argument("--secondary", default="C2,C4,C5", help="parameter sets of the `secondary` block (north_star: "
+                    "poly_modulus_degree in {8192, 16384}); '' disables")
     ap.add_argument("--lt-direct", type=int, default=512, help="dimension of the direct-key Linear_Transform_Plain leg "
                     "(one Galois key per step: 4 GB of keys at d = 512, C3); 0 disables")
+    ap.add_argument("--quick", action="store_true", help="headline only (A/B and profiler runs): no CPU baseline, variants, "
+                    "key-per-item, secondary sets, sustained pass or linear-transform legs")
     args = ap.parse_args()
+    if args.quick:
+        args.cpu_seconds, args.variant_keys, args.stream_keys, args.key_per_item = 0.0, 0, 0, 0
+        args.lt, args.lt_direct, args.secondary, args.sustain = "", 0, "", 0.0
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))  # nothing in this process has touched the GPU
@@ -414,8 +484,12 @@ def main():
     if backend != "nccl":
         local_rank %= max(ndev, 1)
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    # HEFX_BENCH_FORCE_PG=1 (test hook, tests/test_gpu_round5.py): create the process group and take every barrier /
+    # all-reduce / sharded branch even at world 1 -- the only way the one-GPU box can execute the torch "nccl" (RCCL) path
+    use_pg = world > 1 or os.environ.get("HEFX_BENCH_FORCE_PG") == "1"
+    if use_pg:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
@@ -453,24 +527,25 @@ def main():
         e.rotate_multiply_plain_batch(L, cts, elts, keys, pts, outs)
 
     def barrier():
-        if world > 1:
+        if use_pg:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(fn, steps, warmup):
+    def timed(fn, steps, warmup, eng=None):
+        eng = eng or e
         for _ in range(warmup):
             fn()
-        ev0, ev1 = e.event(), e.event()
+        ev0, ev1 = eng.event(), eng.event()
         barrier()
         t0 = time.perf_counter()
-        e.event_record(ev0)
+        eng.event_record(ev0)
         for _ in range(steps):
             fn()
-        e.event_record(ev1)
+        eng.event_record(ev1)
         barrier()
         dt = time.perf_counter() - t0
-        gpu_ms = e.event_elapsed_ms(ev0, ev1)  # HIP events on the stream the launches are issued on
-        if world > 1:
+        gpu_ms = eng.event_elapsed_ms(ev0, ev1)  # HIP events on the stream the launches are issued on
+        if use_pg:
             tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if backend == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
@@ -480,6 +555,15 @@ def main():
     if board:
         board.start()
     dt, gpu_ms = timed(step, args.steps, args.warmup)
+    # a second, longer self-timed pass of the SAME step: at least `--sustain` seconds whatever --steps
+    # is, so that the board sampler (and anybody watching from outside) sees the device busy more than once and the clock /
+    # power it settles at; reported next to the headline, never instead of it
+    sustained = None
+    if args.sustain > 0:
+        ssteps = max(args.steps, int(args.sustain / max(dt / args.steps, 1e-6)) + 1)
+        sdt_, sgpu_ = timed(step, ssteps, 0)
+        sustained = {"steps": ssteps, "seconds": sdt_, "value": B * ssteps * world / sdt_, "ms_per_step": sdt_ / ssteps * 1e3,
+                     "gpu_ms_per_step": sgpu_ / ssteps}
 
     # what was timed is checked: one item of EVERY chunk of the launch sequence (the engine cuts the batch into chunks of
     # at most 256 items on alternating internal streams) plus the last item, word for word against the CPU oracle (rank 0)
@@ -570,6 +654,16 @@ def main():
         except Exception as ex:  # e.g. not enough memory for the keys: reported, never fatal
             key_per_item = {"error": repr(ex)[:300]}
 
+    # `secondary` (north_star: "poly_modulus_degree in {8192, 16384}"): the same unit at the other
+    # parameter sets, each on its own engine context with its own device-drawn batch, timed like the headline (barrier +
+    # sync on both sides, max over ranks) for about a second, three outputs checked against the oracle on rank 0
+    secondary = {}
+    for name in [x for x in args.secondary.split(",") if x and x != args.set]:
+        try:
+            secondary[name] = secondary_bench(name, Engine, local_rank, rank, world, timed, key32)
+        except Exception as ex:  # reported, never fatal for the headline
+            secondary[name] = {"error": repr(ex)[:300]}
+
     board_rec = board.stop() if board else None
     line = None
     if rank == 0:
@@ -581,15 +675,19 @@ def main():
         achieved = B * bytes_op / (step_ms * 1e-3) / 1e9
         # HBM traffic: not measurable live; taken from the committed rocprofv3 --pmc passes of this same command
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
-        traffic, traffic_src = None, None
-        for rnd in ("r04", "r03", "r02", "r01"):
+        src16, lib16 = _hashes()
+        traffic, traffic_src, traffic_stale = None, None, None
+        for rnd in ("r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_bench_pmc_traffic.json")
             if args.set == "C3" and os.path.exists(pmc):
                 try:
-                    pb = json.load(open(pmc))["per_op_bytes"]
+                    pj = json.load(open(pmc))
+                    pb = pj["per_op_bytes"]
                     traffic = (pb["fetch_x2"] + pb["write"]) * B / 1e9  # GB per step, same unit basis as achieved*time
                     traffic_src = (f"profiles/{rnd}_bench_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, "
                                    "separate passes); GB per step")
+                    # the counters belong to the engine sources they were measured on (tools/pmc_traffic.py writes the hash)
+                    traffic_stale = pj.get("csrc_sha16") != src16
                     break
                 except Exception:
                     pass
@@ -597,16 +695,17 @@ def main():
         # engine clock sampled during this run that is cycles of wall time per instruction and SIMD -- against ~5 cycles
         # of issue cost for this mix (4 for 32-bit ops, 4.75 v_fma_f64, 5.7 v_mad_u64_u32: profiles/r01_valu_issue_rates.txt)
         issue = None
-        sqf = os.path.join(ROOT, "profiles", "r04_bench_sq_counters.json")
-        if not os.path.exists(sqf):
-            sqf = os.path.join(ROOT, "profiles", "r03_bench_sq_counters.json")
-        if args.set == "C3" and os.path.exists(sqf):
+        sqf = next((f for f in (os.path.join(ROOT, "profiles", f"{r}_bench_sq_counters.json") for r in ("r05", "r04", "r03"))
+                    if os.path.exists(f)), "")
+        if args.set == "C3" and sqf:
             try:
                 sq = json.load(open(sqf))
+                meta = sq.pop("_meta", {})
                 per_op = sum(v["SQ_INSTS_VALU"] / (v["launches"] * 256) for v in sq.values())  # 256 items per chunk launch
                 mhz = (board_rec or {}).get("sclk_mhz")
                 issue = {"valu_wave_instr_per_op": per_op,
                          "source": f"profiles/{os.path.basename(sqf)} (rocprofv3 --pmc SQ_INSTS_VALU of this command)",
+                         "stale": meta.get("csrc_sha16") != src16,
                          "sclk_mhz": mhz}
                 if mhz:
                     cyc = (dt / total_ops * world) * mhz * 1e6 * SIMDS / per_op
@@ -633,6 +732,11 @@ def main():
             "data": "synthetic",
             "verified": verified,
             "verified_items": verified_items,
+            "libhefx_sha16": lib16,      # sha256[:16] of the libhefx.so this run loaded
+            "csrc_sha16": src16,         # ... and of the engine sources (csrc/ + include/hefx.h) it was built from
+            "rescale_mode": "round" if e.rescale_rounded else "floor",  # the engine's default division
+            "sustained": sustained,
+            "secondary": secondary,
             "config": {
                 "workload": f"{args.set}: N={N}, coeff_modulus bits "
                             f"{[p.bit_length() for p in primes]}, level L={L} (k={k}); per step and per GPU "
@@ -650,6 +754,8 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                # True: the counter file was measured on other engine sources than the ones that ran (csrc hash differs)
+                "traffic_stale": traffic_stale,
                 # the honest number for the regime `frac` prices: one Galois key per item
                 "key_per_item": key_per_item,
                 "algorithmic_GB_per_step": B * bytes_op / 1e9,  # same basis as `traffic` (one step = one launch sequence)
@@ -719,14 +825,14 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            lt = lt_sharded_bench(local_rank, world, dims, reps=3, direct_d=args.lt_direct)
+            lt = lt_sharded_bench(local_rank, world, dims, reps=3, direct_d=args.lt_direct, use_pg=use_pg)
         except Exception as ex:
             lt = {"error": repr(ex)[:400]}
         dog.cancel()
         if rank == 0:
             line["lt_sharded"] = lt
     emit()
-    if world > 1:
+    if use_pg:
         dist.barrier()
         dist.destroy_process_group()
 

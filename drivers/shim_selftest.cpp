@@ -3,6 +3,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <iostream>
+#include <sstream>
 
 #include "seal/seal.h"
 
@@ -546,6 +547,115 @@ int main()
         bev.multiply(a, b, big);  // size 3 x size 3 -> size 5
         bdec.decrypt(big, back);
         CHECK(big.size() == 5 && back.to_string() == "1C54", "BFV 4(x^2+1)(x+1)^2 at x = 6 without relinearisation (1_bfv.cpp:130-132)");
+    }
+
+    // ---- save / load: SEAL 3.4.5's uncompressed stream layouts; "format unpinned" (shim_io.h)
+    {
+        auto hex = [](const array<uint8_t, 32> &d) {
+            static const char *H = "0123456789abcdef";
+            string o;
+            for (auto b : d) o += H[b >> 4], o += H[b & 15];
+            return o;
+        };
+        CHECK(hex(shim::sha3_256(nullptr, 0)) == "a7ffc6f8bf1ed76651c14756a061d662f580ff4de43b49fa82d80a4b80f8434a" &&
+                  hex(shim::sha3_256((const uint8_t *)"abc", 3)) == "3a985da74fe225b2045c172d6bd390bd855f086e3e9d525b46bfe24511431532",
+              "SHA3-256 known answers (FIPS 202): SEAL's parms_id is this hash of the parameter words");
+        vector<uint8_t> longmsg(200, 0xa3);  // one full block + a remainder (NIST's 1600-bit message of 0xa3 bytes)
+        CHECK(hex(shim::sha3_256(longmsg.data(), longmsg.size())) == "79f38adec5c20307a98ef76e8324afbfd46cfd81b22e3973c65fa1bd9de31787",
+              "SHA3-256 over more than one block");
+        EncryptionParameters sp(scheme_type::CKKS);
+        sp.set_poly_modulus_degree(8192);
+        sp.set_coeff_modulus(CoeffModulus::Create(8192, {60, 40, 40, 60}));
+        auto sctx = SEALContext::Create(sp);
+        CHECK(sctx->key_parms_id() == sp.parms_id() && sctx->first_parms_id() != sctx->key_parms_id() &&
+                  sctx->first_context_data()->parms().parms_id() == sctx->first_parms_id(),
+              "parms_id of every level is the SHA3-256 of that level's parameters");
+        stringstream ps;
+        EncryptionParameters::Save(sp, ps);
+        CHECK(ps.str().size() == 1 + 8 + 8 + 4 * 8 + 8 && (uint8_t)ps.str()[0] == 2, "EncryptionParameters::Save: 57 bytes for four primes, scheme byte 2 (CKKS)");
+        CHECK(EncryptionParameters::Load(ps) == sp, "EncryptionParameters::Load gives the parameters back");
+        KeyGenerator skg(sctx);
+        PublicKey spk = skg.public_key();
+        SecretKey ssk = skg.secret_key();
+        RelinKeys srk = skg.relin_keys();
+        GaloisKeys sgk = skg.galois_keys(vector<int>{1, -1, 4});
+        Encryptor senc(sctx, spk);
+        Decryptor sdec(sctx, ssk);
+        CKKSEncoder scod(sctx);
+        Evaluator sev(sctx);
+        vector<double> vals{1.5, -2.25, 3.0, 0.125};
+        Plaintext pt;
+        scod.encode(vals, pow(2.0, 40), pt);
+        Ciphertext ct;
+        senc.encrypt(pt, ct);
+        stringstream cs;
+        ct.save(cs);
+        const size_t words = 2 * 3 * 8192;
+        CHECK(cs.str().size() == 32 + 1 + 8 + 8 + 8 + 8 + 8 + words * 8, "Ciphertext::save: 73 header bytes + the words");
+        Ciphertext ct2, ct3;
+        ct2.load(sctx, cs);
+        cs.seekg(0);
+        ct3.unsafe_load(cs);  // the 3.4.x spelling: the context is found by the stream's parms_id
+        bool same = ct2.size() == 2 && ct2.parms_id() == ct.parms_id() && ct2.scale() == ct.scale() && ct2.is_ntt_form();
+        for (size_t i = 0; same && i < words; ++i) same = ct2.data()[i] == ct.data()[i] && ct3.data()[i] == ct.data()[i];
+        CHECK(same, "Ciphertext save -> load / unsafe_load: the same words, level and scale");
+        stringstream pss;
+        pt.save(pss);
+        Plaintext pt2;
+        pt2.load(sctx, pss);
+        vector<double> back;
+        scod.decode(pt2, back);
+        CHECK(pt2.parms_id() == pt.parms_id() && pt2.scale() == pt.scale() && fabs(back[1] + 2.25) < 1e-6 && fabs(back[3] - 0.125) < 1e-6,
+              "Plaintext save -> load decodes to the same values");
+        // keys through a stream, then the whole pipeline on the loaded ones: encrypt under the loaded public key, rotate with
+        // the loaded Galois keys, square + relinearise with the loaded relinearisation key, decrypt with the loaded secret key
+        stringstream k1, k2, k3, k4;
+        spk.save(k1);
+        ssk.save(k2);
+        srk.save(k3);
+        sgk.save(k4);
+        PublicKey lpk;
+        SecretKey lsk;
+        RelinKeys lrk;
+        GaloisKeys lgk;
+        lpk.load(sctx, k1);
+        lsk.load(sctx, k2);
+        lrk.load(sctx, k3);
+        lgk.load(sctx, k4);
+        CHECK(lgk.size() == 3 && lgk.has_key(shim::galois_elt_from_step(4, 8192)) && lrk.has_key(0u) && lsk.host == ssk.host,
+              "RelinKeys / GaloisKeys / SecretKey save -> load keep their entries");
+        Ciphertext r1, r2, q1, q2;
+        sev.rotate_vector(ct, 1, sgk, r1);
+        sev.rotate_vector(ct, 1, lgk, r2);
+        sev.square(ct, q1);
+        sev.relinearize_inplace(q1, srk);
+        sev.square(ct, q2);
+        sev.relinearize_inplace(q2, lrk);
+        same = true;
+        for (size_t i = 0; same && i < words; ++i) same = r1.data()[i] == r2.data()[i] && q1.data()[i] == q2.data()[i];
+        CHECK(same, "evaluation with the loaded keys gives the bits of the original keys");
+        Encryptor lenc(sctx, lpk);
+        Decryptor ldec(sctx, lsk);
+        Ciphertext lc;
+        lenc.encrypt(pt, lc);
+        sev.rotate_vector_inplace(lc, 1, lgk);
+        Plaintext lp;
+        ldec.decrypt(lc, lp);
+        scod.decode(lp, back);
+        CHECK(fabs(back[0] + 2.25) < 1e-4 && fabs(back[2] - 0.125) < 1e-4, "encrypt / rotate / decrypt entirely on loaded keys");
+        // a stream of another parameter set, and a damaged one, are refused
+        EncryptionParameters op(scheme_type::CKKS);
+        op.set_poly_modulus_degree(8192);
+        op.set_coeff_modulus(CoeffModulus::Create(8192, {50, 30, 50}));
+        auto octx = SEALContext::Create(op);
+        cs.clear();
+        cs.seekg(0);
+        Ciphertext bad;
+        CHECK(throws_invalid([&] { bad.load(octx, cs); }, "invalid"), "load refuses a ciphertext of other parameters");
+        string raw = cs.str();
+        raw[73 + 8 + 7] = (char)0xff;  // top byte of the first word: no longer a residue of the 60-bit prime
+        stringstream dm(raw);
+        CHECK(throws_invalid([&] { bad.load(sctx, dm); }, "invalid"), "load refuses a word that is not a residue (unsafe_load would take it)");
     }
 
     cout << (failures ? "SELFTEST FAILED" : "SELFTEST PASSED") << " (" << failures << " failures)" << endl;

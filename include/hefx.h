@@ -98,6 +98,12 @@ int hefx_device_memory(hefx_context *ctx, size_t *free_bytes, size_t *total_byte
  * the per-item sequence, same bits either way.  Waits for the device.  A diagnostic: tests assert 0 on random inputs
  * (the fast path ran) and > 0 on planted zeros (the fallback ran). */
 int hefx_ks_fallback_count(hefx_context *ctx, uint64_t *chunks);
+/* Host-side counters of the key-switch front door since the context was created (no device wait): out[0] key switches
+ * submitted (items of every batch, relinearisations included), out[1] of them run exactly hoisted (sharing their source's
+ * decomposition), out[2] launch sequences (chunks), out[3] batched calls.  What a caller needs to price a composite --
+ * e.g. how many key switches the NAF forest of one Linear_Transform_Plain with the reference's power-of-two keys
+ * (/root/reference/linear_transformation2.cpp:239) executes after prefix sharing. */
+int hefx_ks_stats(hefx_context *ctx, uint64_t out[4]);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
 int hefx_stream_sync(hefx_context *ctx, void *stream);
 

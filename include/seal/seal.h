@@ -38,6 +38,7 @@
 
 #include "../hefx.h"
 #include "shim_bfv.h"
+#include "shim_io.h"
 
 namespace seal {
 
@@ -59,6 +60,17 @@ public:
         return b;
     }
     bool is_zero() const { return value_ == 0; }
+    // SEAL 3.4.5 SmallModulus::save / load: the value, one uint64 (format notes: shim_io.h)
+    void save(std::ostream &stream) const
+    {
+        shim::StreamGuard g(stream);
+        shim::put_u64(stream, value_);
+    }
+    void load(std::istream &stream)
+    {
+        shim::StreamGuard g(stream);
+        value_ = shim::get_u64(stream);
+    }
     bool operator==(const SmallModulus &o) const { return value_ == o.value_; }
     bool operator!=(const SmallModulus &o) const { return value_ != o.value_; }
 
@@ -1140,6 +1152,45 @@ public:
     const std::vector<SmallModulus> &coeff_modulus() const { return q_; }
     const SmallModulus &plain_modulus() const { return t_; }
     scheme_type scheme() const { return scheme_; }
+    // SEAL's parms_id (EncryptionParameters::compute_parms_id): SHA3-256 over the uint64 words scheme,
+    // poly_modulus_degree, the coeff_modulus values and the plain_modulus value
+    parms_id_type parms_id() const
+    {
+        std::vector<std::uint64_t> w{(std::uint64_t)scheme_, (std::uint64_t)n_};
+        for (auto &q : q_) w.push_back(q.value());
+        w.push_back(t_.value());
+        return shim::sha3_words(w);
+    }
+    bool operator==(const EncryptionParameters &o) const { return scheme_ == o.scheme_ && n_ == o.n_ && q_ == o.q_ && t_ == o.t_; }
+    bool operator!=(const EncryptionParameters &o) const { return !(*this == o); }
+    // SEAL 3.4.5: static Save / Load -- scheme (one byte), poly_modulus_degree, coeff_mod_count, the coeff_modulus
+    // values, the plain_modulus value (saved for both schemes).  Members save / load: the >= 3.5 spelling, same bytes here.
+    static void Save(const EncryptionParameters &parms, std::ostream &stream)
+    {
+        shim::StreamGuard g(stream);
+        shim::put_u8(stream, (std::uint8_t)parms.scheme_);
+        shim::put_u64(stream, (std::uint64_t)parms.n_);
+        shim::put_u64(stream, (std::uint64_t)parms.q_.size());
+        for (auto &q : parms.q_) q.save(stream);
+        parms.t_.save(stream);
+    }
+    static EncryptionParameters Load(std::istream &stream)
+    {
+        shim::StreamGuard g(stream);
+        const std::uint8_t scheme = shim::get_u8(stream);
+        if (scheme != (std::uint8_t)scheme_type::bfv && scheme != (std::uint8_t)scheme_type::ckks)
+            throw std::invalid_argument("unsupported scheme");
+        EncryptionParameters p(scheme);
+        const std::uint64_t n = shim::get_u64(stream), cnt = shim::get_u64(stream);
+        if (n > 32768 || cnt > 62) throw std::invalid_argument("coeff_modulus is invalid");  // SEAL_COEFF_MOD_COUNT_MAX
+        p.n_ = (std::size_t)n;
+        p.q_.resize((std::size_t)cnt);
+        for (auto &q : p.q_) q.load(stream);
+        p.t_.load(stream);
+        return p;
+    }
+    void save(std::ostream &stream) const { Save(*this, stream); }
+    void load(std::istream &stream) { *this = Load(stream); }
 
 private:
     scheme_type scheme_;
@@ -1279,12 +1330,6 @@ private:
         if (k_ < 1) throw std::invalid_argument("coeff_modulus is not set");
         if (n_ < 1024 || (n_ & (n_ - 1))) throw std::invalid_argument("poly_modulus_degree is not valid");
         for (auto &q : parms.coeff_modulus()) primes_.push_back(q.value());
-        std::uint64_t h = 1469598103934665603ull;  // FNV-1a over (N, primes): identifies the parameter set
-        auto mix = [&](std::uint64_t v) {
-            for (int i = 0; i < 8; ++i) h = (h ^ ((v >> (8 * i)) & 0xff)) * 1099511628211ull;
-        };
-        mix(n_);
-        for (auto q : primes_) mix(q);
         levels_.resize(k_);
         for (int rows = 1; rows <= k_; ++rows) {
             auto cd = std::make_shared<ContextData>();
@@ -1293,7 +1338,7 @@ private:
             p.set_coeff_modulus(std::vector<SmallModulus>(parms.coeff_modulus().begin(), parms.coeff_modulus().begin() + rows));
             p.set_plain_modulus(parms.plain_modulus());
             cd->parms_ = p;
-            cd->id_ = {(std::uint64_t)rows, (std::uint64_t)n_, h, 0x5ea1c0deull};
+            cd->id_ = p.parms_id();  // SEAL's own value (SHA3-256 of the level's parameters): what save() writes
             // chain_index: key level = k-1 ... last data level = 0 (App. A.2)
             cd->chain_index_ = (std::size_t)(rows - 1);
             shim::u128 dummy = 0;
@@ -1309,7 +1354,35 @@ private:
             levels_[rows - 1] = cd;
         }
         for (int rows = 2; rows <= k_; ++rows) levels_[rows - 1]->next_ = levels_[rows - 2];
+        // every parameter set a context was built for is remembered: the context-free unsafe_load(stream) of SEAL 3.4.x
+        // finds the engine of a stream's parms_id here (known())
+        std::lock_guard<std::mutex> lk(known_mutex());
+        bool seen = false;
+        for (auto &c : known_list()) seen = seen || c->levels_.back()->id_ == levels_.back()->id_;
+        if (!seen) known_list().push_back(std::make_shared<SEALContext>(*this));
     }
+    static std::mutex &known_mutex()
+    {
+        static std::mutex m;
+        return m;
+    }
+    static std::vector<std::shared_ptr<SEALContext>> &known_list()
+    {
+        static auto *v = new std::vector<std::shared_ptr<SEALContext>>();
+        return *v;
+    }
+
+public:
+    // a context of this process one of whose levels carries `id` (nullptr: none was ever created)
+    static std::shared_ptr<SEALContext> known(const parms_id_type &id)
+    {
+        std::lock_guard<std::mutex> lk(known_mutex());
+        for (auto &c : known_list())
+            if (c->rows_of(id)) return c;
+        return nullptr;
+    }
+
+private:
 
     std::size_t n_ = 0;
     int k_ = 0;
@@ -1430,6 +1503,62 @@ public:
         }
         return out.empty() ? "0" : out;
     }
+    // ---- SEAL 3.4.5 Plaintext::save: parms_id (4 x uint64), scale (double), then the IntArray -- coefficient count and the
+    // words (CKKS: rows * N words in NTT form; BFV: coefficients modulo t under parms_id_zero).  Format notes: shim_io.h.
+    void save(std::ostream &stream) const
+    {
+        shim::StreamGuard g(stream);
+        shim::put_id(stream, id_);
+        shim::put_f64(stream, scale_);
+        const bool on_device = bfv.empty() && buf;
+        shim::put_words(stream, on_device ? data() : bfv.data(), on_device ? coeff_count() : bfv.size());
+    }
+    // unsafe_load: the stream's words as they are (structure checked only as far as the payload needs a home)
+    template <class Ctx>
+    void unsafe_load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        shim::StreamGuard g(stream);
+        const parms_id_type id = shim::get_id(stream);
+        const double scale = shim::get_f64(stream);
+        Plaintext p;
+        if (id == parms_id_zero) {  // BFV form
+            p.bfv = shim::get_words(stream, (std::uint64_t)ctx->n());
+            if (p.bfv.empty()) p.bfv.assign(1, 0);
+        } else {
+            const int rows = ctx->rows_of(id);
+            if (!rows) throw std::invalid_argument("plaintext data is invalid: parms_id is not of this context");
+            auto w = shim::get_words(stream, (std::uint64_t)rows * ctx->n());
+            if (w.size() != (std::size_t)rows * ctx->n()) throw std::invalid_argument("plaintext data is invalid");
+            p.zero_ = std::all_of(w.begin(), w.end(), [](std::uint64_t x) { return x == 0; });
+            p.buf = shim::upload(ctx->engine(), w);
+            p.rows = rows;
+        }
+        p.id_ = id;
+        p.scale_ = scale;
+        *this = std::move(p);
+    }
+    // load: unsafe_load + SEAL's is_valid_for (every word a residue of its row's prime / of the plain modulus)
+    template <class Ctx>
+    void load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Plaintext p;
+        p.unsafe_load(ctx, stream);
+        const std::uint64_t *w = p.data();
+        if (p.id_ == parms_id_zero) {
+            const std::uint64_t t = ctx->plain_modulus_value();
+            for (std::size_t i = 0; t && i < p.bfv.size(); ++i)
+                if (p.bfv[i] >= t) throw std::invalid_argument("plaintext data is invalid");
+        } else {
+            for (int j = 0; j < p.rows; ++j)
+                for (std::size_t i = 0; i < ctx->n(); ++i)
+                    if (w[(std::size_t)j * ctx->n() + i] >= ctx->primes()[j]) throw std::invalid_argument("plaintext data is invalid");
+        }
+        *this = std::move(p);
+    }
+    // SEAL 3.4.x spelling without a context: the parameter set is found among the contexts this process has created
+    inline void unsafe_load(std::istream &stream);
     // shim internals
     shim::BufPtr buf;                 // CKKS: [rows][N] NTT form on the device
     std::vector<std::uint64_t> bfv;   // BFV: N coefficients modulo the plain modulus, on the host
@@ -1467,6 +1596,58 @@ public:
         return mirror_->data();
     }
     const std::uint64_t *data(std::size_t poly) const { return data() + poly * (std::size_t)rows * poly_modulus_degree(); }
+    // ---- SEAL 3.4.5 Ciphertext::save: parms_id, is_ntt_form (one byte), size, poly_modulus_degree, coeff_mod_count (uint64
+    // each), scale (double), then the IntArray (count + words, [size][coeff_mod_count][N]).  Format notes: shim_io.h.
+    void save(std::ostream &stream) const
+    {
+        shim::StreamGuard g(stream);
+        shim::put_id(stream, id_);
+        shim::put_u8(stream, ntt_form_ ? 1 : 0);
+        shim::put_u64(stream, (std::uint64_t)size_);
+        shim::put_u64(stream, (std::uint64_t)poly_modulus_degree());
+        shim::put_u64(stream, (std::uint64_t)rows);
+        shim::put_f64(stream, scale_);
+        shim::put_words(stream, buf ? data() : nullptr, buf ? buf->words : 0);
+    }
+    template <class Ctx>
+    void unsafe_load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        shim::StreamGuard g(stream);
+        Ciphertext c;
+        c.id_ = shim::get_id(stream);
+        c.ntt_form_ = shim::get_u8(stream) != 0;
+        const std::uint64_t size = shim::get_u64(stream), n = shim::get_u64(stream), rows = shim::get_u64(stream);
+        c.scale_ = shim::get_f64(stream);
+        if (size > 16 || rows > (std::uint64_t)ctx->k() || (size && n != ctx->n()))
+            throw std::invalid_argument("ciphertext data is invalid");
+        auto w = shim::get_words(stream, size * rows * n);
+        if (w.size() != (std::size_t)(size * rows * n)) throw std::invalid_argument("ciphertext data is invalid");
+        c.size_ = (std::size_t)size;
+        c.rows = (int)rows;
+        if (!w.empty()) c.buf = shim::upload(ctx->engine(), w);
+        *this = std::move(c);
+    }
+    // load: unsafe_load + SEAL's is_valid_for (a level of this context, the size that level's payload has, the form the
+    // scheme keeps its ciphertexts in, every word a residue of its row's prime)
+    template <class Ctx>
+    void load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Ciphertext c;
+        c.unsafe_load(ctx, stream);
+        if (c.size_) {
+            if (ctx->rows_of(c.id_) != c.rows || c.size_ < 2 || c.ntt_form_ != ctx->is_ckks())
+                throw std::invalid_argument("ciphertext data is invalid");
+            const std::uint64_t *w = c.data();
+            for (std::size_t p = 0; p < c.size_; ++p)
+                for (int j = 0; j < c.rows; ++j)
+                    for (std::size_t i = 0; i < ctx->n(); ++i)
+                        if (w[(p * c.rows + j) * ctx->n() + i] >= ctx->primes()[j]) throw std::invalid_argument("ciphertext data is invalid");
+        }
+        *this = std::move(c);
+    }
+    inline void unsafe_load(std::istream &stream);  // SEAL 3.4.x spelling, see Plaintext::unsafe_load
     // shim internals
     shim::BufPtr buf;
     int rows = 0;
@@ -1492,6 +1673,42 @@ class SecretKey {
 public:
     std::vector<std::uint64_t> host;  // [k][N], NTT form
     shim::BufPtr buf;
+    parms_id_type &parms_id() { return id_; }
+    const parms_id_type &parms_id() const { return id_; }
+    // SEAL: a secret key is a key-level Plaintext in NTT form (scale 1)
+    void save(std::ostream &stream) const
+    {
+        shim::StreamGuard g(stream);
+        shim::put_id(stream, id_);
+        shim::put_f64(stream, 1.0);
+        shim::put_words(stream, host.data(), host.size());
+    }
+    template <class Ctx>
+    void unsafe_load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Plaintext p;
+        p.unsafe_load(ctx, stream);
+        adopt(*ctx, p);
+    }
+    template <class Ctx>
+    void load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Plaintext p;
+        p.load(ctx, stream);
+        adopt(*ctx, p);
+    }
+
+private:
+    void adopt(const SEALContext &ctx, const Plaintext &p)
+    {
+        if (p.parms_id() != ctx.key_parms_id() || !p.buf) throw std::invalid_argument("SecretKey data is invalid");
+        buf = p.buf;
+        host = shim::download(buf);
+        id_ = p.parms_id();
+    }
+    parms_id_type id_ = parms_id_zero;
 };
 class PublicKey {
 public:
@@ -1499,21 +1716,118 @@ public:
     // SEAL: a public key (and every component of a key-switching key) is a size-2 key-level ciphertext
     const Ciphertext &data() const
     {
-        if (!view_.buf || view_.buf != buf) view_.set(buf, 2, rows_, parms_id_zero, 1.0);
+        if (!view_.buf || view_.buf != buf) view_.set(buf, 2, rows_, id_, 1.0);
         return view_;
     }
     int rows_ = 0;
+    parms_id_type &parms_id() { return id_; }
+    const parms_id_type &parms_id() const { return id_; }
+    void save(std::ostream &stream) const { data().save(stream); }
+    template <class Ctx>
+    void unsafe_load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Ciphertext c;
+        c.unsafe_load(ctx, stream);
+        adopt(*ctx, c);
+    }
+    template <class Ctx>
+    void load(const Ctx &context, std::istream &stream)
+    {
+        auto ctx = shim::as_ptr(context);
+        Ciphertext c;
+        c.load(ctx, stream);
+        adopt(*ctx, c);
+    }
 
 private:
+    void adopt(const SEALContext &ctx, const Ciphertext &c)
+    {
+        if (c.size() != 2 || c.rows != ctx.k() || c.parms_id() != ctx.key_parms_id() || !c.buf)
+            throw std::invalid_argument("PublicKey data is invalid");
+        buf = c.buf;
+        rows_ = c.rows;
+        id_ = c.parms_id();
+    }
+    parms_id_type id_ = parms_id_zero;
     mutable Ciphertext view_;
 };
 class KSwitchKeys {
 public:
+    virtual ~KSwitchKeys() = default;
     bool has_key(std::uint32_t elt) const { return keys.count(elt) != 0; }
     std::map<std::uint32_t, shim::BufPtr> keys;  // Galois element -> [k-1][2][k][N]; relin key under element 0
     std::size_t size() const { return keys.size(); }
+    parms_id_type &parms_id() { return id_; }
+    const parms_id_type &parms_id() const { return id_; }
+    // ---- SEAL 3.4.5 KSwitchKeys::save: parms_id, the outer dimension, then per index its component count followed by that
+    // many PublicKeys (key-level size-2 ciphertexts: component i = digit i = [2][k][N]).  RelinKeys: index = key_power - 2
+    // (one index); GaloisKeys: index = (galois_elt - 1) / 2 over N indices, absent elements with zero components.
+    void save(std::ostream &stream) const
+    {
+        shim::StreamGuard g(stream);
+        shim::put_id(stream, id_);
+        const std::uint64_t dim1 = keys.empty() ? 0 : (galois_indexing() ? (std::uint64_t)keys.begin()->second->eng->n : 1);
+        shim::put_u64(stream, dim1);
+        for (std::uint64_t index = 0; index < dim1; ++index) {
+            const std::uint32_t elt = galois_indexing() ? (std::uint32_t)(2 * index + 1) : 0u;
+            if (!has_key(elt)) {
+                shim::put_u64(stream, 0);
+                continue;
+            }
+            const std::vector<PublicKey> &comps = components(elt);
+            shim::put_u64(stream, (std::uint64_t)comps.size());
+            for (const PublicKey &c : comps) {
+                Ciphertext view;
+                view.set(c.buf, 2, c.rows_, id_, 1.0);
+                view.save(stream);
+            }
+        }
+    }
+    template <class Ctx>
+    void unsafe_load(const Ctx &context, std::istream &stream)
+    {
+        load_impl(*shim::as_ptr(context), stream, false);
+    }
+    template <class Ctx>
+    void load(const Ctx &context, std::istream &stream)
+    {
+        load_impl(*shim::as_ptr(context), stream, true);
+    }
 
 protected:
+    virtual bool galois_indexing() const { return true; }  // how an index of SEAL's outer vector maps to an element
+    void load_impl(const SEALContext &ctx, std::istream &stream, bool validate)
+    {
+        shim::StreamGuard g(stream);
+        const parms_id_type id = shim::get_id(stream);
+        const std::uint64_t dim1 = shim::get_u64(stream);
+        const std::size_t n = ctx.n(), k = (std::size_t)ctx.k(), slice = 2 * k * n;
+        if (dim1 > (galois_indexing() ? (std::uint64_t)n : 1) || (validate && id != ctx.key_parms_id()))
+            throw std::invalid_argument("KSwitchKeys data is invalid");
+        std::map<std::uint32_t, shim::BufPtr> loaded;
+        auto ctxp = std::make_shared<SEALContext>(ctx);
+        for (std::uint64_t index = 0; index < dim1; ++index) {
+            const std::uint64_t dim2 = shim::get_u64(stream);
+            if (!dim2) continue;
+            if (dim2 != k - 1) throw std::invalid_argument("KSwitchKeys data is invalid");
+            std::vector<std::uint64_t> words(dim2 * slice);
+            for (std::uint64_t i = 0; i < dim2; ++i) {
+                Ciphertext c;
+                if (validate)
+                    c.load(ctxp, stream);
+                else
+                    c.unsafe_load(ctxp, stream);
+                if (c.size() != 2 || (std::size_t)c.rows != k || !c.buf) throw std::invalid_argument("KSwitchKeys data is invalid");
+                std::memcpy(words.data() + i * slice, c.data(), slice * 8);
+            }
+            loaded[galois_indexing() ? (std::uint32_t)(2 * index + 1) : 0u] = shim::upload(ctx.engine(), words);
+        }
+        keys = std::move(loaded);
+        views_.clear();
+        id_ = id;
+    }
+    parms_id_type id_ = parms_id_zero;
     // SEAL's view of one key: vector<PublicKey>, component i = digit i = [2][k][N] (a copy of that slice)
     const std::vector<PublicKey> &components(std::uint32_t elt) const
     {
@@ -1536,6 +1850,9 @@ protected:
     mutable std::map<std::uint32_t, std::vector<PublicKey>> views_;
 };
 class RelinKeys : public KSwitchKeys {
+protected:
+    bool galois_indexing() const override { return false; }
+
 public:
     static std::size_t get_index(std::size_t key_power) { return key_power - 2; }
     // shim-internal lookups use has_key(0u) (the relinearisation key is stored under element 0); SEAL's has_key(key_power)
@@ -1553,6 +1870,46 @@ public:
     const std::vector<PublicKey> &key(std::uint64_t galois_elt) const { return components((std::uint32_t)galois_elt); }
 };
 
+// SEAL 3.4.x's unsafe_load(stream) has no context argument; the payload still needs a device to live on, so the stream's
+// parms_id is looked up among the contexts this process has created (SEALContext::known).  The 16-byte look-ahead is
+// undone with seekg: these members need a seekable stream (files, stringstreams).
+inline void Plaintext::unsafe_load(std::istream &stream)
+{
+    const auto pos = stream.tellg();
+    parms_id_type id;
+    {
+        shim::StreamGuard g(stream);
+        id = shim::get_id(stream);
+        stream.seekg(pos);
+    }
+    std::shared_ptr<SEALContext> ctx = id == parms_id_zero ? nullptr : SEALContext::known(id);
+    if (id == parms_id_zero) {  // BFV form carries no parameters: any context's ring bounds it
+        Plaintext p;
+        shim::StreamGuard g(stream);
+        (void)shim::get_id(stream);
+        p.scale() = shim::get_f64(stream);
+        p.bfv = shim::get_words(stream, 32768);
+        if (p.bfv.empty()) p.bfv.assign(1, 0);
+        *this = std::move(p);
+        return;
+    }
+    if (!ctx) throw std::invalid_argument("no SEALContext of this process has the parameters of the stream (parms_id)");
+    unsafe_load(ctx, stream);
+}
+inline void Ciphertext::unsafe_load(std::istream &stream)
+{
+    const auto pos = stream.tellg();
+    parms_id_type id;
+    {
+        shim::StreamGuard g(stream);
+        id = shim::get_id(stream);
+        stream.seekg(pos);
+    }
+    auto ctx = SEALContext::known(id);
+    if (!ctx) throw std::invalid_argument("no SEALContext of this process has the parameters of the stream (parms_id)");
+    unsafe_load(ctx, stream);
+}
+
 // ------------------------------------------------------------------------------------------------
 // KeyGenerator (App. A.11): sampling (hefx_sample_*) and arithmetic on the GPU, key assembly on the host
 // ------------------------------------------------------------------------------------------------
@@ -1568,6 +1925,7 @@ public:
         shim::check(hefx_sample_ternary(e->ready({}), rnd_.key.data(), rnd_.stream(), 1, k, 0, sk_.buf->p, nullptr));
         shim::check(hefx_ntt_forward(e->ready({}), sk_.buf->p, 1, k, 0, nullptr));
         sk_.host = shim::download(sk_.buf);
+        sk_.parms_id() = ctx_->key_parms_id();
     }
 
     const SecretKey &secret_key() const { return sk_; }
@@ -1582,6 +1940,8 @@ public:
         std::copy(c0.begin(), c0.end(), h.begin());
         std::copy(z.second.begin(), z.second.end(), h.begin() + w);
         pk.buf = shim::upload(ctx_->engine(), h);
+        pk.rows_ = ctx_->k();
+        pk.parms_id() = ctx_->key_parms_id();
         return pk;
     }
     void create_public_key(PublicKey &pk) { pk = public_key(); }
@@ -1594,6 +1954,7 @@ public:
         auto s2 = shim::new_buf(e, (std::size_t)k * ctx_->n());
         shim::check(hefx_multiply_plain(e->ready({}), k, 1, 1, sk_.buf->p, sk_.buf->p, s2->p, nullptr));
         rk.keys[0] = kswitch_key(s2);
+        rk.parms_id() = ctx_->key_parms_id();
         return rk;
     }
     void create_relin_keys(RelinKeys &rk) { rk = relin_keys(); }
@@ -1632,6 +1993,7 @@ private:
             shim::check(hefx_galois_permute(e->ready({}), g, sk_.buf->p, k, sp->p, nullptr));
             gk.keys[g] = kswitch_key(sp);
         }
+        gk.parms_id() = ctx_->key_parms_id();
         return gk;
     }
 

@@ -12,6 +12,25 @@ HEADERS = ["hefx_internal.h", "hefx_modarith.cuh", "hefx_ntt.cuh", "hefx_ntt8.cu
 DEPS = SOURCES + HEADERS  # a change in any of them rebuilds the library (a header: every object; a source: its object)
 
 
+def source_sha16() -> str:
+    """sha256[:16] over the engine's sources (csrc/ + the public header), in the fixed order of DEPS: what bench.py writes
+    into its JSON line and the profile tools into profiles/*.json, so that counter files measured on other kernels are seen."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in sorted(DEPS):
+        h.update(d.encode())
+        h.update(open(os.path.join(CSRC, d), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def library_sha16() -> str:
+    """sha256[:16] of the built libhefx.so ("" when it does not exist)"""
+    import hashlib
+    if not os.path.exists(SO):
+        return ""
+    return hashlib.sha256(open(SO, "rb").read()).hexdigest()[:16]
+
+
 def hipcc() -> str:
     for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
         if cand and (os.path.sep not in cand or os.path.exists(cand)):
@@ -46,9 +65,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         jobs.append((src, subprocess.Popen(cmd)))  # the five translation units compile side by side
-    for src, p in jobs:
-        if p.wait() != 0:
-            raise subprocess.CalledProcessError(p.returncode, f"hipcc {src}")
+    failed = [(src, p.returncode) for src, p in jobs if p.wait() != 0]  # every job is waited for before anything is raised
+    if failed:
+        raise subprocess.CalledProcessError(failed[0][1], "hipcc " + ", ".join(src for src, _ in failed))
     cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", SO] + objs
     if verbose:
         print(" ".join(cmd))

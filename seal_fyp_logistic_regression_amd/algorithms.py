@@ -218,15 +218,18 @@ def _native_key_args(gal_keys: KSwitchKeys):
     """(elements, key payloads) of a key set in the form the native entry points take.  On the HIP engine the two C arrays
     are built once per key set and kept on it (512 keys: 0.1 ms of Python per call otherwise, with the GPU idle); the set
     is rebuilt when keys were added.  Other backends get plain lists."""
-    cache = getattr(gal_keys, "_native_args", None)
-    if cache is not None and cache[0] == len(gal_keys.keys):
-        return cache[1], cache[2]
     elts = sorted(gal_keys.keys)
     keys = [gal_keys.key(e) for e in elts]
     if not keys or not hasattr(keys[0], "ptr"):
         return elts, keys
+    # fingerprint: elements AND payload addresses -- a key replaced under an existing element, or one removed and another
+    # added, must not leave the native transform on the old payloads (0.03 ms at 512 keys against 0.1 ms for the C arrays)
+    mark = (tuple(elts), tuple(k.ptr for k in keys))
+    cache = getattr(gal_keys, "_native_args", None)
+    if cache is not None and cache[0] == mark:
+        return cache[1], cache[2]
     from . import capi
-    cache = (len(elts), capi.u32_array(elts), capi.ptr_array([k.ptr for k in keys]), keys)  # keys: kept alive
+    cache = (mark, capi.u32_array(elts), capi.ptr_array(list(mark[1])), keys)  # keys: kept alive
     gal_keys._native_args = cache
     return cache[1], cache[2]
 

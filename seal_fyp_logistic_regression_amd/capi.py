@@ -49,6 +49,7 @@ _SIGS = {
     "hefx_copy_peer_to": (_i, [_vp, _vp, _vp, _vp, _sz, _vp]),
     "hefx_device_memory": (_i, [_vp, C.POINTER(_sz), C.POINTER(_sz)]),
     "hefx_ks_fallback_count": (_i, [_vp, C.POINTER(C.c_uint64)]),
+    "hefx_ks_stats": (_i, [_vp, C.POINTER(C.c_uint64)]),
     "hefx_context_device": (_i, [_vp]),
     "hefx_memset_zero": (_i, [_vp, _vp, _sz, _vp]),
     "hefx_stream_sync": (_i, [_vp, _vp]),

@@ -221,6 +221,8 @@ struct hefx_context {
     // HEFX_FUSED=0/1 overrides the default.
     bool fused = false;
     std::vector<uint8_t> is_f64;  // per prime: FP64 policy in use (mirror of T.modsf[j].q != 0)
+    // hefx_ks_stats: key switches submitted / of them exactly hoisted / launch sequences / batched calls (host-side counts)
+    uint64_t stat_ks_items = 0, stat_ks_hoisted = 0, stat_ks_chunks = 0, stat_ks_calls = 0;
 };
 
 static int ensure_scratch(hefx_context *c, size_t words)
@@ -422,15 +424,13 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
     if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "round") ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR;
     if (e != hipSuccess) {
-        if (c->d_tables) (void)hipFree(c->d_tables);
-        delete c;
+        hefx_context_destroy(c);  // frees whatever exists so far (tables, flags, streams, events, ring, gate words)
         return hipfail(e, "context table upload");
     }
     // load every code object now (first-launch cost), not inside the caller's first timed operation
     if (warm_kernels(nullptr) != hipSuccess || warm_keyswitch(nullptr) != hipSuccess || warm_encode(nullptr) != hipSuccess ||
         warm_sample(nullptr) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
-        (void)hipFree(c->d_tables);
-        delete c;
+        hefx_context_destroy(c);
         return fail(HEFX_ERR_HIP, "kernel code objects failed to load");
     }
     unsigned char *base = static_cast<unsigned char *>(c->d_tables);
@@ -657,6 +657,13 @@ extern "C" int hefx_ks_fallback_count(hefx_context *c, uint64_t *chunks)
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(&v, c->d_gate + KS_RING, sizeof(v), hipMemcpyDeviceToHost));
     *chunks = v;
+    return HEFX_OK;
+}
+extern "C" int hefx_ks_stats(hefx_context *c, uint64_t out[4])
+{
+    CTXCHK(c);
+    if (!out) return fail(HEFX_ERR_INVALID, "null pointer");
+    out[0] = c->stat_ks_items, out[1] = c->stat_ks_hoisted, out[2] = c->stat_ks_chunks, out[3] = c->stat_ks_calls;
     return HEFX_OK;
 }
 extern "C" int hefx_memset_zero(hefx_context *c, void *d_dst, size_t bytes, void *stream)
@@ -1048,6 +1055,29 @@ static size_t ks_words_per_item(const hefx_context *c, int L)
 }
 static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t)c->n * sub * L * (L + 1); }
 
+// Workgroup shapes of a SMALL chunk (descriptors in the kernel arguments, one launch sequence; KS_Q_* mask).
+// Pair path (round 5, ks_pair_*): four launches with two transform phases instead of five with four -- taken while its
+// widest grid (4 L^2 quarter workgroups per item) still gets about two CUs' worth of room per workgroup pair, i.e. for what
+// the latency path is for: lone rotations of a NAF chain, the lockstep chains of a few dot products.  HEFX_PAIR=0/1
+// forces it off / on, HEFX_PAIR_MAX=<workgroups> moves the bound.
+// Otherwise per launch: quarter rows where the quarter grid (4 workgroups per row) still gets a CU per workgroup -- measured
+// with clock stamps over n = 1..8, L = 2..8 (profiles/r03/quarter_mask_sweep.txt) and end to end up to n = 32: the
+// inverse launches up to 256 / 192 quarter workgroups (256 of the mod-down inverse at n = 32 measured +27 us), the
+// digit transforms up to 256 (beyond that 2 split workgroups per row win: 14 us for 256 of them against 19 us for
+// 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none / all, HEFX_QMASK=<bits> any combination.
+static int ks_small_shape(int n, int L)
+{
+    static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
+    static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
+    static const int pair_force = getenv("HEFX_PAIR") ? atoi(getenv("HEFX_PAIR")) : -1;
+    static const int pair_max = getenv("HEFX_PAIR_MAX") ? atoi(getenv("HEFX_PAIR_MAX")) : 512;
+    if (qmask_force >= 0) return qmask_force & (KS_Q_ALL | KS_Q_PAIR);
+    if (pair_force > 0 || (pair_force < 0 && quarter_force < 0 && n * L * L * 4 <= pair_max)) return KS_Q_PAIR;
+    if (quarter_force >= 0) return quarter_force ? KS_Q_ALL : 0;
+    return (n * L * 4 <= 256 ? KS_Q_INTT : 0) | (n * L * L * 4 <= 256 ? KS_Q_NTT : 0) | (n * 2 * 4 <= 192 ? KS_Q_MDI : 0) |
+           (n * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
+}
+
 // Chunks of a batch alternate between two internal streams (each with its own scratch half) so that the
 // small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
 // the next; the caller's stream is forked before and joined after.
@@ -1124,7 +1154,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // submitted, on BYTE RANGES (callers hand out views of one allocation: big.view(...) slices): no two outputs may
     // overlap, and no input or plaintext may overlap another item's output -- nor its own, except the exact in-place
     // rotation c_in == c_out, which the kernels serve from a scratch copy.  O(n log n) on the host.
-    if (n > 1 || pts || acc_out) {
+    if (n > 1 || pts || acc_out || relin) {  // (a lone relinearisation too: its three input polys against its two output polys)
         const size_t row = (size_t)c->n * sizeof(u64);
         const size_t out_b = 2 * (size_t)L * row, in_b = (relin ? 3 : 2) * (size_t)L * row, pt_b = (size_t)L * row;
         std::vector<std::pair<uintptr_t, int>> outs((size_t)n);
@@ -1242,6 +1272,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         if (herr != hipSuccess) hwhat = #expr; \
     }
     int ci = 0;
+    ++c->stat_ks_calls;
     for (int base = 0; base < n && herr == hipSuccess; base += chunk, ++ci) {
         const int cnt = (n - base < chunk) ? n - base : chunk;
         const unsigned slot = c->ring_next++ % KS_RING;
@@ -1322,18 +1353,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         // digit transforms up to 256 (beyond that 2 split workgroups per row win: 14 us for 256 of them against 19 us for
         // 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none / all, HEFX_QMASK=<bits> any
         // combination (KS_Q_*)
-        static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
-        static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
-        int quarter = 0;
-        if (small && !fused && nchunks == 1) {
-            if (qmask_force >= 0)
-                quarter = qmask_force & KS_Q_ALL;
-            else if (quarter_force >= 0)
-                quarter = quarter_force ? KS_Q_ALL : 0;
-            else
-                quarter = (cnt * L * 4 <= 256 ? KS_Q_INTT : 0) | (cnt * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
-                          (cnt * 2 * 4 <= 192 ? KS_Q_MDI : 0) | (cnt * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
-        }
+        const int quarter = (small && !fused && nchunks == 1) ? ks_small_shape(cnt, L) : 0;
         for (const auto &so : src_of) {  // the distinct sources, behind the items: only c_in and elt are read (noperm)
             if (!nsrc) break;
             KsItem &sd = hb[cnt + (int)so.second];
@@ -1341,6 +1361,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             sd.c_in = (const u64 *)so.first;
             sd.elt = 1u;
         }
+        c->stat_ks_items += (uint64_t)cnt, c->stat_ks_hoisted += nsrc ? (uint64_t)cnt : 0, ++c->stat_ks_chunks;
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * (cnt + nsrc), hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, chunk_alias, small ? hb : nullptr,
                                       quarter, cs, prof, nsrc));
@@ -1421,6 +1442,7 @@ hipError_t chain_level(hefx_context *c, int L, int n, const uint64_t *const *in,
         it.dsrc = it.pad_ = 0;
         it.flipw = nullptr;
     }
+    c->stat_ks_items += (uint64_t)n, ++c->stat_ks_chunks;
     return launch_keyswitch_chunk(c->T, L, n, db, false, S, n, false, hb, quarter, s, nullptr);
 }
 }  // namespace
@@ -1436,6 +1458,25 @@ extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64
         return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, nullptr, ct_out, stream, false, acc_in, acc_out);
     if (int rc = check_ks_level(c, L)) return rc;
     if (n < 1 || !ct_in || !ct_out || !elts || !keys) return fail(HEFX_ERR_INVALID, "bad chain arguments");
+    // The levels after the first are launched without ks_run's checks, so what they write is checked HERE, before anything
+    // is submitted and whatever n is (the wide path's ks_run calls would refuse the same arguments, only later): every
+    // final rotation and every sum non-null and all 2n of them pairwise disjoint in bytes.  (ct_out[i] == ct_in[i] is
+    // fine: the inputs are read by level 1 only.)
+    {
+        const size_t out_b = 2 * (size_t)L * (size_t)c->n * sizeof(u64);
+        std::vector<uintptr_t> w;
+        w.reserve(2 * (size_t)n);
+        for (int i = 0; i < n; ++i) {
+            if (!ct_out[i] || !acc_out[i] || !acc_in[i] || !ct_in[i] || !keys[i])
+                return fail(HEFX_ERR_INVALID, "null pointer in a rotate-and-add chain");
+            w.push_back((uintptr_t)ct_out[i]);
+            w.push_back((uintptr_t)acc_out[i]);
+        }
+        std::sort(w.begin(), w.end());
+        for (size_t i = 1; i < w.size(); ++i)
+            if (w[i - 1] + out_b > w[i])
+                return fail(HEFX_ERR_INVALID, "rotate-and-add chain: final rotations and sums must not overlap one another");
+    }
     // the two intermediate buffer sets (pooled; parked again when the call returns -- later users are ordered behind
     // this call's work on the caller's stream, hefx_malloc's contract)
     const size_t ctw = 2 * (size_t)L * c->n;
@@ -1483,12 +1524,7 @@ extern "C" int hefx_rotate_add_chain(hefx_context *c, int L, int n, const uint64
     S.u = S.acc + (size_t)n * 2 * (L + 1) * N;
     S.x = S.u + (size_t)n * 2 * N;
     S.alias = S.x + ks_x_words(c, L, n);
-    static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
-    static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
-    const int quarter = qmask_force >= 0    ? (qmask_force & KS_Q_ALL)
-                        : quarter_force >= 0 ? (quarter_force ? KS_Q_ALL : 0)
-                                             : ((n * L * 4 <= 256 ? KS_Q_INTT : 0) | (n * L * L * 4 <= 256 ? KS_Q_NTT : 0) |
-                                                (n * 2 * 4 <= 192 ? KS_Q_MDI : 0) | (n * 2 * L * 4 <= 320 ? KS_Q_FIN : 0));
+    const int quarter = ks_small_shape(n, L);
     // the kernels after the first read the descriptors from device memory: a slot of their own per direction, so a
     // replayed level never finds another call's descriptors there
     if (!c->chain_items) HIPCHK(hipMalloc((void **)&c->chain_items, sizeof(KsItem) * 2 * 64));

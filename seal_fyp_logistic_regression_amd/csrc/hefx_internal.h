@@ -154,6 +154,8 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
 hipError_t launch_flip_rows(const DevTables &T, const uint32_t *d_ginv, int count, u64 *rows, hipStream_t s);
 // `quarter`: which of the four transform launches run on quarter-row workgroups
 constexpr int KS_Q_INTT = 1, KS_Q_NTT = 2, KS_Q_MDI = 4, KS_Q_FIN = 8, KS_Q_ALL = 15;
+// ... or the whole chunk on the pair path (ks_pair_*: four launches, two transform phases; overrides the mask above)
+constexpr int KS_Q_PAIR = 16;
 int ks_small_max();
 // double-hoisted linear transform (hefx_keyswitch.hip): see lt2_mac_kernel
 hipError_t launch_lt2_decompose(const DevTables &T, int L, const KsItem *src_item, const KsItem *rot_items, int nrot,

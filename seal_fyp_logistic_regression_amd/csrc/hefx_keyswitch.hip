@@ -1436,6 +1436,332 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kerne
     HEFX_STAMP_AT(15);
 }
 
+// ------------------------------------------------------------------------------------------------
+// PAIR path (round 5) -- the small-batch key switch in FOUR launches with TWO transform phases instead of five launches
+// with four: what one key switch at a time costs is its chain of DEPENDENT launches (each ~1 us of table fetches, ~2 us
+// until its rows have arrived, the radix-8 passes, the stores, the boundary), not work -- the chip is > 90 % idle.
+//
+// A quarter workgroup of an inverse transform ends with the coefficients of ONE residue class modulo 4 (4 g + part), and
+// every forward stage with gap >= 4 pairs coefficients of the same class: restricted to a class, stages 0 .. logN-3 of the
+// size-N forward transform ARE the size-N/4 negacyclic transform with root psi^4 -- table entries tw[1 .. N/4) of the same
+// table, prefix 1 (bitrev_logN(idx) = 4 bitrev_(logN-2)(idx) for idx < N/4).  So the workgroup that produced a class
+// carries it straight through those stages, registers to registers, and only the LAST TWO forward stages (gaps 2 and 1:
+// the four in-place positions 4g..4g+3, one from each class) need the other three quarters -- they move into the
+// element-wise kernel that follows anyway.  Symmetrically the FIRST two inverse stages of the special-prime row (gaps 1
+// and 2 on positions 4g..4g+3) run in the epilogue of the key MAC, which holds those four sums in registers.
+//
+//   (P1) ks_pair_digits   (b, i -> m, part): INTT_(q_i) quarter of perm_g(c1)[i]  ->  reduce mod m  ->  forward stages
+//                         0..logN-3 mod m  ->  xpre[b][i][m][part][.]        (the digit itself is never stored; every
+//                         target modulus recomputes the inverse quarter -- idle CUs, no extra latency)
+//   (P2) ks_pair_mac      (b, m, g): last two forward stages on the four planes of every digit, key MAC, and for m = P the
+//                         first two inverse stages  ->  acc[b][c][j]  (j < L),  upre[b][c][part][.]
+//   (P3) ks_pair_moddown  (b, c, j, part): rest of INTT_P on plane `part`, + P/2, reduce mod q_j, - (P/2 mod q_j), forward
+//                         stages 0..logN-3 mod q_j  ->  fpre[b][c][j][part][.]
+//   (P4) ks_pair_finish   (b, c, j, g): last two forward stages, then the mod-down epilogue of ks_moddown_finish (add-in
+//                         gathered from the source, optional plaintext product, optional accumulate)
+// Same integers as the five-launch sequence at every stored word -- the transforms are the same butterflies in another
+// order of WORKGROUPS, not of arithmetic -- hence the same bits (every small-batch parity test runs through here).
+// Scratch: xpre takes the place of x (same size), upre of u, fpre lives in x's storage (x is dead once P2 has run).
+// ------------------------------------------------------------------------------------------------
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_pair_digits_kernel(DevTables T, KsSmallItems small,
+                                                                   KsItem *__restrict__ items_out, int n, int L, int relin,
+                                                                   int rows, KsScratch S)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(0);
+    HEFX_STAMP_AT(0);
+    if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
+    // grid (8, 4 L, groups), dispatched x-fastest: the 4 L workgroups of digit g = (b, i) share an XCD (they all gather the
+    // same source row)
+    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    int jj = slot >> 2;
+    const int part = slot & 3;
+    if (g >= rows) return;
+    const int t = threadIdx.x;
+    const int b = g / L, i = g % L;
+    if (jj >= i) ++jj;  // skip the diagonal; jj == L is the special prime
+    const int m = jj < L ? jj : T.k - 1;
+    const KsItem it = small.it[b];
+    const u64 *__restrict__ src = it.c_in + ((size_t)(relin ? 2 * L : L) + i) * QC::N;
+    const uint32_t elt = relin ? 1u : item_elt(it);
+    u64 v[8];
+    quarter_inv<LOGN>(v, [src, elt](int j) { return gather_pair(src, (uint32_t)j, elt, LOGN); }, lds, ntt_tables(T, i),
+                      T.mods[i], T.modsf[i], t, part);
+    HEFX_STAMP_AT(15);
+    HEFX_STAMP_KERNEL(1);  // (stamp builds: the forward half reports as the old digit-NTT launch)
+    HEFX_STAMP_AT(0);
+    // v[r] = digit coefficient 4 idx_nat(t, r) + part, canonical modulo q_i: exactly the register layout the size-N/4
+    // forward core starts from, and its first pass writes the LDS words this thread's last inverse pass read (no barrier)
+    const ModConst mc = T.mods[m];
+    const ModConstF mf = T.modsf[m];
+    const InMode mode = {T.mods[i].q > mc.q, T.modsf[i].q == 0.0, false, 0};
+    u64 *__restrict__ xd = S.x + (((size_t)b * L + i) * (L + 1) + jj) * QC::N + (size_t)part * QC::Q;
+    const NttTables nt = ntt_tables(T, m);
+    fwd_policy_dispatch(mc, mf, [&](auto pol) {
+        using A = decltype(pol);
+        const typename A::Ctx cx = make_ctx(A{}, mc, mf);
+        typename A::V f[8];
+        fwd_inputs8<A>(f, v, mode, cx, mc);
+        ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), fwd_tw(A{}, nt), cx, t, 1);
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) gst16(xd + C::idx_out(t, r), make_ulonglong2(A::raw(f[r]), A::raw(f[r + 1])));
+    });
+    HEFX_STAMP_AT(15);
+}
+
+// the last two stages of a size-2^LOGN forward transform on in-place positions 4g..4g+3 (p0..p3): stage logN-2 pairs
+// (p0,p2), (p1,p3) with tw[N/4 + g]; stage logN-1 pairs (p0,p1) with tw[N/2 + 2g] and (p2,p3) with tw[N/2 + 2g + 1]
+template <int LOGN, class A>
+__device__ __forceinline__ void fwd_last_two(typename A::V &p0, typename A::V &p1, typename A::V &p2, typename A::V &p3,
+                                             const typename A::TW &wb, const typename A::TW &wa0,
+                                             const typename A::TW &wa1, const typename A::Ctx &cx)
+{
+    A::ct(p0, p2, wb, cx, LOGN - 2);
+    A::ct(p1, p3, wb, cx, LOGN - 2);
+    A::ct(p0, p1, wa0, cx, LOGN - 1);
+    A::ct(p2, p3, wa1, cx, LOGN - 1);
+}
+
+// unfinished forward values (p, q) -> the MAC policy's operand pair
+template <class AF, class P>
+__device__ __forceinline__ typename P::X pair_mac_operand(typename AF::V p, typename AF::V q, int slack,
+                                                          const typename AF::Ctx &fx, const typename P::Ctx &cx)
+{
+    if constexpr (AF::IS_F64) {
+        return make_double2(p, q);  // MacF multiplies the unfinished doubles as they are (|x| < 2^45)
+    } else {
+        ulonglong2 w;
+        if (slack == 1)
+            w = make_ulonglong2(AF::template mac_operand_lazy<1>(p, fx), AF::template mac_operand_lazy<1>(q, fx));
+        else if (slack >= 2)
+            w = make_ulonglong2(AF::template mac_operand_lazy<2>(p, fx), AF::template mac_operand_lazy<2>(q, fx));
+        else
+            w = make_ulonglong2(AF::mac_operand(p, fx), AF::mac_operand(q, fx));
+        return P::xin(w, false, cx);
+    }
+}
+
+template <int LOGN, class AF, class P>
+__device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &it, int L, int relin, int b, int jj, int m,
+                                              uint32_t g, const KsScratch &S)
+{
+    constexpr size_t N = (size_t)1 << LOGN, Q = N / 4;
+    const ModConst mc = T.mods[m];
+    const ModConstF mf = T.modsf[m];
+    const typename AF::Ctx fx = make_ctx(AF{}, mc, mf);
+    const typename P::Ctx cx = P::make(mc, mf);
+    const NttTables nt = ntt_tables(T, m);
+    const typename AF::TW *__restrict__ tw = fwd_tw(AF{}, nt);
+    const typename AF::TW wb = tw[Q + g], wa0 = tw[2 * Q + 2 * g], wa1 = tw[2 * Q + 2 * g + 1];
+    const int slack = mac_x_slack(mc, mf, L);
+    const size_t kpoly = (size_t)T.k * N;
+    P A0, A1;  // positions (4g, 4g+1) and (4g+2, 4g+3), both key polynomials each
+    auto mac_digit = [&](int i, const typename P::X &xa, const typename P::X &xb) {
+        const u64 *kb = it.key + ((size_t)i * 2 * T.k + m) * N + 4 * (size_t)g;
+        const ulonglong2 k0a = gld16(kb), k0b = gld16(kb + 2), k1a = gld16(kb + kpoly), k1b = gld16(kb + kpoly + 2);
+        A0.mac(xa, P::kin(k0a, k1a, cx), cx);
+        A1.mac(xb, P::kin(k0b, k1b, cx), cx);
+    };
+    if (jj < L) {  // the digit in NTT form modulo its own prime: the (rotated) input row itself, gathered
+        const u64 *__restrict__ own = it.c_in + ((size_t)(relin ? 2 * L : L) + jj) * N;
+        const uint32_t elt = relin ? 1u : item_elt(it);
+        const ulonglong2 xa = gather_pair(own, 2 * g, elt, LOGN), xb = gather_pair(own, 2 * g + 1, elt, LOGN);
+        mac_digit(jj, P::xin(xa, true, cx), P::xin(xb, true, cx));
+    }
+    for (int i = 0; i < L; ++i) {
+        if (i == jj) continue;
+        const u64 *__restrict__ xp = S.x + (((size_t)b * L + i) * (L + 1) + jj) * N + g;
+        typename AF::V p0 = AF::unraw(gld8(xp)), p1 = AF::unraw(gld8(xp + Q)), p2 = AF::unraw(gld8(xp + 2 * Q)),
+                       p3 = AF::unraw(gld8(xp + 3 * Q));
+        fwd_last_two<LOGN, AF>(p0, p1, p2, p3, wb, wa0, wa1, fx);
+        mac_digit(i, pair_mac_operand<AF, P>(p0, p1, slack, fx, cx), pair_mac_operand<AF, P>(p2, p3, slack, fx, cx));
+    }
+    ulonglong2 r0a, r1a, r0b, r1b;  // r<poly><pair>
+#ifdef HEFX_NO_LT2Q
+    A0.result(r0a, r1a, cx);
+    A1.result(r0b, r1b, cx);
+#else
+    A0.template result<true>(r0a, r1a, cx);
+    A1.template result<true>(r0b, r1b, cx);
+#endif
+    if (jj < L) {
+        u64 *a0 = S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * N + 4 * (size_t)g;
+        u64 *a1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * N + 4 * (size_t)g;
+        gst16(a0, r0a);
+        gst16(a0 + 2, r0b);
+        gst16(a1, r1a);
+        gst16(a1 + 2, r1b);
+        return;
+    }
+    // the special prime's rows: the first two stages of INTT_P here (the inverse policy of P; the MAC's words are below 2q
+    // or canonical, what its first stage takes), one plane per residue class for ks_pair_moddown
+    using AI = std::conditional_t<AF::IS_F64, ArithF64, ArithU64>;
+    const typename AI::Ctx ix = make_ctx(AI{}, mc, mf);
+    const typename AI::TW *__restrict__ itw = inv_tw(AI{}, nt);
+    const typename AI::TW va0 = itw[2 * Q + 2 * g], va1 = itw[2 * Q + 2 * g + 1], vb = itw[Q + g];
+    auto inverse_first_two = [&](const ulonglong2 &ra, const ulonglong2 &rb, u64 *__restrict__ up) {
+        const typename AI::V q0 = AI::from_u64(ra.x), q1 = AI::from_u64(ra.y), q2 = AI::from_u64(rb.x), q3 = AI::from_u64(rb.y);
+        const typename AI::V s01 = AI::gs_half_sum(q0, q1, ix), d01 = AI::gs_half_diff(q0, q1, va0, ix);
+        const typename AI::V s23 = AI::gs_half_sum(q2, q3, ix), d23 = AI::gs_half_diff(q2, q3, va1, ix);
+        gst8(up + g, AI::raw(AI::inv_add(s01, s23, ix)));                  // part 0: (sum, sum)
+        gst8(up + Q + g, AI::raw(AI::inv_add(d01, d23, ix)));              // part 1: (difference, sum)
+        gst8(up + 2 * Q + g, AI::raw(AI::inv_sub_mul(s01, s23, vb, ix)));  // part 2: (sum, twiddled difference)
+        gst8(up + 3 * Q + g, AI::raw(AI::inv_sub_mul(d01, d23, vb, ix)));  // part 3
+    };
+    inverse_first_two(r0a, r0b, S.u + ((size_t)b * 2 + 0) * N);
+    inverse_first_two(r1a, r1b, S.u + ((size_t)b * 2 + 1) * N);
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void ks_pair_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+                                                         KsScratch S)
+{
+    const int jj = blockIdx.y, b = blockIdx.z;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // positions 4g .. 4g+3
+    const int m = jj < L ? jj : T.k - 1;
+    const KsItem it = items[b];
+    const ModConst mc = T.mods[m];
+    if (T.modsf[m].q != 0.0)
+        pair_mac_body<LOGN, ArithF64, MacF>(T, it, L, relin, b, jj, m, g, S);
+    else
+        fwd_int_dispatch(mc, [&](auto pol) {
+            using AF = decltype(pol);
+            if (L <= 8 && (mc.q >> 60) == 0)  // (mac_dispatch's rule)
+                pair_mac_body<LOGN, AF, MacL>(T, it, L, relin, b, jj, m, g, S);
+            else
+                pair_mac_body<LOGN, AF, MacW>(T, it, L, relin, b, jj, m, g, S);
+        });
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_pair_moddown_kernel(DevTables T, int L, int rows, KsScratch S)
+{
+    using QC = QuarterCfg<LOGN>;
+    using C = typename QC::C;
+    extern __shared__ __align__(16) u64 lds[];
+    HEFX_STAMP_KERNEL(3);
+    HEFX_STAMP_AT(0);
+    // grid (8, 4 L, groups): g = remainder polynomial (b, c); every data prime j recomputes the quarter of INTT_P it needs
+    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    const int j = slot >> 2, part = slot & 3;
+    if (g >= rows) return;
+    const int t = threadIdx.x;
+    const int sp = T.k - 1;
+    const ModConst mcp = T.mods[sp];
+    const ModConstF mfp = T.modsf[sp];
+    const NttTables ntp = ntt_tables(T, sp);
+    const u64 *__restrict__ plane = S.u + (size_t)g * QC::N + (size_t)part * QC::Q;
+    u64 v[8];
+    if (mfp.q != 0.0)
+        quarter_inv_planes<LOGN, ArithF64>(v, plane, lds, ntp.itwf, ArithF64::make(mfp), t);
+    else
+        quarter_inv_planes<LOGN, ArithU64>(v, plane, lds, ntp.itw, ArithU64::make(mcp), t);
+    HEFX_STAMP_AT(15);
+    HEFX_STAMP_KERNEL(4);
+    HEFX_STAMP_AT(0);
+    const u64 half = mcp.q >> 1;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = csub(v[r] + half, mcp.q);  // (INTT_P(acc_P) + floor(P/2)) mod P
+    const ModConst mc = T.mods[j];
+    const ModConstF mf = T.modsf[j];
+    const InMode mode = {true, true, true, T.halfmod[(size_t)sp * T.k + j], true, mcp.q < 2 * mc.q};
+    u64 *__restrict__ fd = S.x + ((size_t)g * L + j) * QC::N + (size_t)part * QC::Q;
+    const NttTables nt = ntt_tables(T, j);
+    fwd_policy_dispatch(mc, mf, [&](auto pol) {
+        using A = decltype(pol);
+        const typename A::Ctx cx = make_ctx(A{}, mc, mf);
+        typename A::V f[8];
+        fwd_inputs8<A>(f, v, mode, cx, mc);
+        ntt8_fwd_core<LOGN - 2, A>(f, reinterpret_cast<typename A::V *>(lds), fwd_tw(A{}, nt), cx, t, 1);
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) gst16(fd + C::idx_out(t, r), make_ulonglong2(A::raw(f[r]), A::raw(f[r + 1])));
+    });
+    HEFX_STAMP_AT(15);
+}
+
+template <int LOGN, class A>
+__device__ __forceinline__ void pair_finish_body(const DevTables &T, const KsItem &it, int L, int relin, int b, int c, int j,
+                                                 uint32_t g, const KsScratch &S)
+{
+    constexpr size_t N = (size_t)1 << LOGN, Q = N / 4;
+    const int sp = T.k - 1;
+    const ModConst mc = T.mods[j];
+    const ModConstF mf = T.modsf[j];
+    const typename A::Ctx cx = make_ctx(A{}, mc, mf);
+    const auto pinv = md_pinv(A{}, T, sp, j);
+    const typename A::TW *__restrict__ tw = fwd_tw(A{}, ntt_tables(T, j));
+    const typename A::TW wb = tw[Q + g], wa0 = tw[2 * Q + 2 * g], wa1 = tw[2 * Q + 2 * g + 1];
+    const u64 *__restrict__ fp = S.x + (((size_t)b * 2 + c) * L + j) * N + g;
+    typename A::V p0 = A::unraw(gld8(fp)), p1 = A::unraw(gld8(fp + Q)), p2 = A::unraw(gld8(fp + 2 * Q)),
+                  p3 = A::unraw(gld8(fp + 3 * Q));
+    const size_t w4 = 4 * (size_t)g;
+    const u64 *__restrict__ acc = S.acc + (((size_t)b * 2 + c) * (L + 1) + j) * N + w4;
+    const ulonglong2 a01 = gld16(acc), a23 = gld16(acc + 2);
+    const u64 *__restrict__ addrow = it.c_in + ((size_t)(relin ? c : 0) * L + j) * N;
+    const bool has_add = relin || c == 0;
+    const uint32_t elt = relin ? 1u : item_elt(it);
+    const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * N + w4 : nullptr;
+    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * N + w4;
+    // specialised on (add-in?, plaintext?) by workgroup-uniform branches, like ks_moddown_finish: no conditional loads
+    auto epilogue = [&](auto has_add_c, auto has_pt_c) {
+        constexpr bool HA = decltype(has_add_c)::value, HP = decltype(has_pt_c)::value;
+        ulonglong2 s01 = make_ulonglong2(0, 0), s23 = s01, t01 = s01, t23 = s01;
+        if constexpr (HA) {
+            s01 = gather_pair(addrow, 2 * g, elt, LOGN);
+            s23 = gather_pair(addrow, 2 * g + 1, elt, LOGN);
+        }
+        if constexpr (HP) {
+            t01 = gld16(pt);
+            t23 = gld16(pt + 2);
+        }
+        fwd_last_two<LOGN, A>(p0, p1, p2, p3, wb, wa0, wa1, cx);
+        ulonglong2 o01, o23;
+        o01.x = md_epilogue(A{}, p0, a01.x, s01.x, t01.x, HP, cx, pinv, mc);
+        o01.y = md_epilogue(A{}, p1, a01.y, s01.y, t01.y, HP, cx, pinv, mc);
+        o23.x = md_epilogue(A{}, p2, a23.x, s23.x, t23.x, HP, cx, pinv, mc);
+        o23.y = md_epilogue(A{}, p3, a23.y, s23.y, t23.y, HP, cx, pinv, mc);
+        gst16(dst, o01);
+        gst16(dst + 2, o23);
+        if constexpr (!HP) {  // accumulate (hefx_apply_galois_add_batch): acc_out = acc_in + out
+            if (it.acc_out) {
+                const size_t arow = ((size_t)c * L + j) * N + w4;
+                const ulonglong2 i01 = gld16(it.acc_in + arow), i23 = gld16(it.acc_in + arow + 2);
+                gst16(it.acc_out + arow, make_ulonglong2(addmod(i01.x, o01.x, mc.q), addmod(i01.y, o01.y, mc.q)));
+                gst16(it.acc_out + arow + 2, make_ulonglong2(addmod(i23.x, o23.x, mc.q), addmod(i23.y, o23.y, mc.q)));
+            }
+        }
+    };
+    if (has_add) {
+        if (pt)
+            epilogue(std::true_type{}, std::true_type{});
+        else
+            epilogue(std::true_type{}, std::false_type{});
+    } else {
+        if (pt)
+            epilogue(std::false_type{}, std::true_type{});
+        else
+            epilogue(std::false_type{}, std::false_type{});
+    }
+}
+
+template <int LOGN>
+__global__ __launch_bounds__(256) void ks_pair_finish_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
+                                                            KsScratch S)
+{
+    const int row = blockIdx.y, b = blockIdx.z;  // row = c * L + j
+    const int c = row / L, j = row % L;
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    const KsItem it = items[b];
+    const ModConst mc = T.mods[j];
+    fwd_policy_dispatch(mc, T.modsf[j], [&](auto pol) {
+        using A = decltype(pol);
+        pair_finish_body<LOGN, A>(T, it, L, relin, b, c, j, g, S);
+    });
+}
+
 template <typename K>
 static void set_lds(K kernel, size_t bytes)
 {
@@ -1515,7 +1841,29 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     // `quarter` is a mask over the four transform launches (KS_Q_*): the scratch arrays have one layout, so each launch
     // picks its own workgroup shape -- ks_run gives quarter rows to the launches whose quarter grid still fits the chip in
     // one round (at n = 8, L = 5: the two inverse launches and not the 200 digit transforms).
-    if (small && quarter && sub >= n) {
+    if (small && (quarter & KS_Q_PAIR) && sub >= n) {  // the pair path: four launches, two transform phases (ks_pair_*)
+        static PerDeviceOnce attrp;
+        const size_t ldsq = QuarterCfg<LOGN>::LDS_BYTES;
+        if (attrp.first()) {
+            set_lds(ks_pair_digits_kernel<LOGN>, ldsq);
+            set_lds(ks_pair_moddown_kernel<LOGN>, ldsq);
+        }
+        constexpr int TQ = QuarterCfg<LOGN>::T;
+        mark(1);
+        hipLaunchKernelGGL((ks_pair_digits_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, *small,
+                           const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
+        mark(3);
+        hipLaunchKernelGGL((ks_pair_mac_kernel<LOGN>), dim3(SC::N / 4 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, rl, scr);
+        mark(4);
+        hipLaunchKernelGGL((ks_pair_moddown_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T, L, n * 2,
+                           scr);
+        mark(5);
+        hipLaunchKernelGGL((ks_pair_finish_kernel<LOGN>), dim3(SC::N / 4 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
+                           scr);
+        mark(-1);
+        return hipGetLastError();
+    }
+    if (small && (quarter & KS_Q_ALL) && sub >= n) {
         static PerDeviceOnce attrq;
         const size_t ldsq = QuarterCfg<LOGN>::LDS_BYTES;
         if (attrq.first()) {

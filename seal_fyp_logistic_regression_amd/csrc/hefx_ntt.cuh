@@ -223,6 +223,10 @@ struct ArithU64T {
         return shoup_lazy4(x + c.four_q - y, w.x, w.y, c.nq);
     }
     __device__ static __forceinline__ V from_u64(u64 x) { return x; }
+    // a working value as a 64-bit word for scratch memory, and back (the pair kernels hand UNFINISHED values from one launch
+    // to the next: hefx_keyswitch.hip, ks_pair_*)
+    __device__ static __forceinline__ u64 raw(V x) { return x; }
+    __device__ static __forceinline__ V unraw(u64 b) { return b; }
     static constexpr bool IS_F64 = false;
     __device__ static __forceinline__ bool fast_wide(const Ctx &) { return false; }
     // RED: 0 none, 1 Barrett (any 64-bit word), 3 the word is below 2q: one conditional subtraction -- or, when a constant
@@ -365,6 +369,8 @@ struct ArithF64 {
     {
         return __longlong_as_double((long long)(x | 0x4330000000000000ull)) - 4503599627370496.0;
     }
+    __device__ static __forceinline__ u64 raw(V x) { return (u64)__double_as_longlong(x); }
+    __device__ static __forceinline__ V unraw(u64 b) { return __longlong_as_double((long long)b); }
     // any 64-bit word -> an exact integer congruent to it mod q, in (-0.52q, 0.52q + 2^32): hi*(2^32 mod q) + lo with
     // two u32 -> f64 conversions and one FP64 modmul (9 instructions against ~28 slow integer ones for Barrett)
     __device__ static __forceinline__ V reduce_wide(u64 x, const Ctx &c)
@@ -424,6 +430,29 @@ struct ArithF64 {
     }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
 };
+
+// ---- policy plumbing for code that is templated on the arithmetic policy ------------------------------------------
+__device__ __forceinline__ ArithF64::Ctx make_ctx(ArithF64, const ModConst &, const ModConstF &mf) { return ArithF64::make(mf); }
+template <bool L16>
+__device__ __forceinline__ typename ArithU64T<L16>::Ctx make_ctx(ArithU64T<L16>, const ModConst &mc, const ModConstF &)
+{
+    return ArithU64T<L16>::make(mc);
+}
+__device__ __forceinline__ const double *fwd_tw(ArithF64, const NttTables &nt) { return nt.twf; }
+__device__ __forceinline__ const double *inv_tw(ArithF64, const NttTables &nt) { return nt.itwf; }
+template <bool L16>
+__device__ __forceinline__ const ulonglong2 *fwd_tw(ArithU64T<L16>, const NttTables &nt) { return nt.tw; }
+template <bool L16>
+__device__ __forceinline__ const ulonglong2 *inv_tw(ArithU64T<L16>, const NttTables &nt) { return nt.itw; }
+// f(policy tag) with the FORWARD policy of a modulus: FP64 below 2^41, else the integer policy the prime admits
+template <class F>
+__device__ __forceinline__ void fwd_policy_dispatch(const ModConst &mc, const ModConstF &mf, const F &f)
+{
+    if (mf.q != 0.0)
+        f(ArithF64{});
+    else
+        fwd_int_dispatch(mc, f);
+}
 
 // ---- twiddle prefetch ---------------------------------------------------------------------------
 // A radix-16 pass needs 1+2+4+8 = 15 twiddle records per thread (slot (1<<u)-1+k for stage u, k < 2^u); the

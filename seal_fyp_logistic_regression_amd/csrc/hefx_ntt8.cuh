@@ -435,6 +435,71 @@ __device__ __forceinline__ void quarter_inv_a(u64 (&v)[8], const LDP &ldp, u64 *
     for (int r = 0; r < 8; ++r) v[r] = A::inv_finish(f[r], cx);
 }
 
+// The REST of a quarter inverse transform whose first two stages (gaps 1 and 2) ran elsewhere -- in the epilogue of the
+// pair path's key MAC (ks_pair_mac_kernel), which holds the four values of positions 4j..4j+3 in registers anyway:
+// plane[j] = what stage B left for group j in this quarter's residue class, as a raw working value (A::raw: inverse lazy
+// range / unfinished double).  One 8-byte word per coefficient instead of the two 16-byte records and three twiddles of
+// quarter_inv_a.  On return v[r] = coefficient 4*idx_nat(t,r) + part, canonical.
+template <int LOGN, class A>
+__device__ __forceinline__ void quarter_inv_planes(u64 (&v)[8], const u64 *__restrict__ plane, u64 *lds,
+                                                   const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
+{
+    using C = Ntt8Cfg<LOGN - 2>;
+    typename A::V f[8];
+    typename A::TW w[7];
+    if constexpr (C::R == 0) {  // lane-adjacent words, transposed into the core's layout through LDS (as quarter_inv_a)
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[r] = A::unraw(gld8(plane + C::idx_nat(t, r)));
+    } else {  // G >= 2 adjacent words per lane: (r, r+1) are one 16-byte record
+#pragma unroll
+        for (int r = 0; r < 8; r += 2) {
+            const ulonglong2 p = gld16(plane + C::idx_out(t, r));
+            f[r] = A::unraw(p.x), f[r + 1] = A::unraw(p.y);
+        }
+    }
+    load_inv_first_tw8<LOGN - 2, A>(w, itw, t);
+    if constexpr (C::R == 0) {
+        typename A::V *lf = reinterpret_cast<typename A::V *>(lds);
+        const int pw = t + (t >> 3), pr = 9 * t;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) lf[pw + (C::T + C::T / 8) * r] = f[r];
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[r] = lf[pr + r];
+    }
+    ntt8_inv_core_w<LOGN - 2, A>(f, w, reinterpret_cast<typename A::V *>(lds), itw, cx, t);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = A::inv_finish(f[r], cx);
+}
+
+// Canonical (or merely 64-bit) words -> inputs of a forward core in policy A, eight at a time; the reduction the words
+// need is workgroup-uniform (InMode), so ONE branch selects the variant for all eight (as quarter_fwd_raw does)
+template <class A>
+__device__ __forceinline__ void fwd_inputs8(typename A::V (&f)[8], const u64 (&v)[8], const InMode &mode,
+                                            const typename A::Ctx &cx, const ModConst &mc)
+{
+    auto go = [&](auto red) {
+        constexpr int RED = decltype(red)::value;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[r] = A::template input<RED>(v[r], mode, cx, mc);
+    };
+    if constexpr (A::IS_F64) {
+        if (!mode.red_f64)
+            go(std::integral_constant<int, 0>{});
+        else if (mode.below_2_61 && A::fast_wide(cx))
+            go(std::integral_constant<int, 2>{});
+        else
+            go(std::integral_constant<int, 1>{});
+    } else {
+        if (!mode.red_int)
+            go(std::integral_constant<int, 0>{});
+        else if (mode.lt2q)
+            go(std::integral_constant<int, 3>{});
+        else
+            go(std::integral_constant<int, 1>{});
+    }
+}
+
 template <int LOGN, class LDP>
 __device__ __forceinline__ void quarter_inv(u64 (&v)[8], const LDP &ldp, u64 *lds, const NttTables &nt,
                                             const ModConst &mc, const ModConstF &mf, int t, int part)

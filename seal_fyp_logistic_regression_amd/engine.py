@@ -137,6 +137,14 @@ class Engine:
         capi.check(capi.lib().hefx_ks_fallback_count(self._h, ctypes.byref(v)))
         return int(v.value)
 
+    def ks_stats(self) -> dict:
+        """host-side counters of the key-switch front door (hefx_ks_stats): key switches submitted, of them exactly
+        hoisted, launch sequences, batched calls -- since the context was created"""
+        import ctypes
+        v = (ctypes.c_uint64 * 4)()
+        capi.check(capi.lib().hefx_ks_stats(self._h, v))
+        return {"key_switches": int(v[0]), "hoisted": int(v[1]), "chunks": int(v[2]), "calls": int(v[3])}
+
     def psi(self, j: int) -> int:
         return int(capi.lib().hefx_psi(self._h, j))
 

@@ -261,7 +261,7 @@ def test_composites_a2_a4_a5_a7_a8_at_n16384_c3_chain():
         assert np.allclose(decode(eg, un_g[i], 3), rows[i], atol=1e-4)
 
 
-def test_logistic_regression_step_at_n16384_c4_chain():
+def test_logistic_regression_step_at_n16384_c4_chain(rescale_mode):
     """rows a9-a11 at config 4's FULL parameter set (N=16384, {60,40x7,60}, L=8): Tree sigmoid, predict_cipher_weights
     over 3 rows x 4 weights (row-batched key switches at L=8 ... 4), update_weights raising where SEAL raises."""
     from seal_fyp_logistic_regression_amd import algorithms as alg

@@ -55,7 +55,7 @@ def test_bench_configuration_default_chunking_every_output_bit_exact():
     assert not bad, f"{len(bad)} of {n} outputs differ from the oracle, first: {bad[:8]}"
 
 
-def test_config4_pulsar_rows_eight_weights_bit_exact():
+def test_config4_pulsar_rows_eight_weights_bit_exact(rescale_mode):
     """BASELINE config 4's own shape (logistic_regression_ckks.cpp:208-266 with num_weights = 8): 16 observation rows of
     the pulsar data set -- raw values, as the reference encodes them (:590 encodes `features`, not the standardised copy)
     -- times 8 encrypted weights at the full parameter set (N=16384, {60,40x7,60}); the row-batched engine path against

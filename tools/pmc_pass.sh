@@ -2,7 +2,7 @@
 # One rocprofv3 counter pass over the bench command, summed per key-switch kernel (GPU box):
 #   tools/pmc_pass.sh outdir COUNTER [COUNTER ...]
 out=$1; shift; mkdir -p $out; export TMPDIR=/tmp
-rocprofv3 --pmc "$@" --output-format csv -d $out/p -o p -- python3 bench.py --steps 2 --warmup 0 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --lt= > /dev/null 2> $out/p.err
+rocprofv3 --pmc "$@" --output-format csv -d $out/p -o p -- python3 bench.py --steps 2 --warmup 0 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --key-per-item 0 --lt-direct 0 --secondary= --sustain 0 --lt= > /dev/null 2> $out/p.err
 python - $out <<'PY'
 import csv, collections, json, sys, glob, os
 out = sys.argv[1]

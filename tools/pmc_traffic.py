@@ -38,7 +38,11 @@ def main():
                      "WRITE_SIZE_KB": wr.get(k, [0, 0.0])[1]})
         tf += fe.get(k, [0, 0.0])[1]
         tw += wr.get(k, [0, 0.0])[1]
-    res = {"command": cmd, "ops": ops, "per_kernel": rows,
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from seal_fyp_logistic_regression_amd import _build
+    # the counters belong to the engine they were measured on: bench.py compares these hashes with the running library's
+    res = {"command": cmd, "ops": ops, "csrc_sha16": _build.source_sha16(), "libhefx_sha16": _build.library_sha16(),
+           "per_kernel": rows,
            "per_op_bytes": {"fetch_raw": tf * 1024 / ops, "fetch_x2": 2 * tf * 1024 / ops, "write": tw * 1024 / ops}}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res["per_op_bytes"]))
