@@ -1045,11 +1045,14 @@ __device__ __forceinline__ u64 md_epilogue(ArithF64, double f, u64 acc, u64 sadd
     return ArithF64::moddown(f, acc, sadd, pt, has_pt, cx, pinv.v);
 }
 
-template <int LOGN, class A>
+// SUM: the output goes into a running sum instead of the item's c_out (sum_dst: this workgroup's slice of the group's sum;
+// sum_first: nothing to add to yet) -- see KsScratch::sum
+template <int LOGN, class A, bool SUM = false>
 __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const KsItem &it, int L, int relin,
                                                     const KsScratch &S, u64 *lds,
                                                     const typename A::TW *__restrict__ tw, const typename A::Ctx &cx,
-                                                    const ModConst &mc, int b, int c, int j, int t, int h)
+                                                    const ModConst &mc, int b, int c, int j, int t, int h,
+                                                    u64 *__restrict__ sum_dst = nullptr, bool sum_first = false)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -1073,7 +1076,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const bool has_add = relin || c == 0;
     const uint32_t elt = relin ? 1u : item_elt(it);
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
-    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
+    u64 *__restrict__ dst = SUM ? sum_dst : it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
     u64 keep[16];  // the outputs, for the optional accumulate behind the epilogue (dead otherwise)
     {
@@ -1121,6 +1124,13 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                     ulonglong2 o;
                     o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], HP, cx, pinv, mc);
                     o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], HP, cx, pinv, mc);
+                    if constexpr (SUM) {  // (the running sum is this workgroup's own 64 KiB slice: an L1 / L2 hit, loaded at its use
+                        // -- as a fourth prefetched operand stream it cost 160 bytes per lane of scratch; unconditional: what
+                        // the first item of a group reads is never used)
+                        const ulonglong2 mv = gld16(dst + C::idx_io(t, GS * g + r));
+                        o.x = sum_first ? o.x : addmod(mv.x, o.x, q);
+                        o.y = sum_first ? o.y : addmod(mv.y, o.y, q);
+                    }
                     gst16(dst + C::idx_io(t, GS * g + r), o);
                     if constexpr (!HP) keep[GS * g + r] = o.x, keep[GS * g + r + 1] = o.y;
                 }
@@ -1140,7 +1150,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         }
         // accumulate (hefx_apply_galois_add_batch; never together with a fused plaintext product): acc_out = acc_in + out,
         // one workgroup-uniform branch behind the epilogue, all loads of the thread requested before the first is used
-        if (it.acc_out && !pt) {
+        if (!SUM && it.acc_out && !pt) {
             const size_t arow = ((size_t)c * L + j) * SC::N + off;
             const u64 *__restrict__ ain = it.acc_in + arow;
             u64 *__restrict__ aout = it.acc_out + arow;
@@ -1178,6 +1188,45 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
         // profiles/r03/ab_finish_l16.txt; one of five rows per polynomial is integer-policy)
         moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
     HEFX_STAMP_AT(15);
+}
+
+// (5s) the same with the products of sum_r consecutive items ADDED UP by the workgroup that computes them (KsScratch::sum):
+// Linear_Transform_Plain needs only the sum of its d - 1 rotate-and-multiply products (helper.h:252-259), and writing
+// every product to be read once more by add_many was 1.3 MB out and 1.3 MB in per rotation -- 0.15 ms of a 2.1 ms transform
+// at d = 512.  A workgroup owns (group, c, j, half) and walks the group's items; its slice of the running sum stays in
+// its own cache.  Modular addition of canonical residues is associative: the bits of add_many over the products.
+template <int LOGN>
+__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_moddown_finish_sum_kernel(DevTables T,
+                                                                                     const KsItem *__restrict__ items, int L,
+                                                                                     int n, int rows, KsScratch S)
+{
+    using SC = SplitCfg<LOGN>;
+    extern __shared__ __align__(16) u64 lds[];
+    int g, j, h;
+    group_decode(blockIdx.x, L, g, j, h);  // g = (group, c)
+    if (g >= rows || ks_gated_out(S)) return;
+    const int grp = g >> 1, c = g & 1;
+    const int b0 = grp * S.sum_r, b1 = b0 + S.sum_r < n ? b0 + S.sum_r : n;
+    for (int b = b0; b < b1; ++b) {
+        // Everything the body derives from (thread, row, half) is recomputed per item: laundered through empty asm so that
+        // loop-invariant code motion cannot stretch sixteen 64-bit addresses, the twiddle prefix and the row's constants
+        // across the whole transform (hoisted, they cost this kernel 370 bytes per lane of scratch under its 128-VGPR cap).
+        int tl = threadIdx.x, jl = j, hl = h, cl = c;
+        asm volatile("" : "+v"(tl), "+v"(jl), "+v"(hl), "+v"(cl));
+        jl = __builtin_amdgcn_readfirstlane(jl), hl = __builtin_amdgcn_readfirstlane(hl), cl = __builtin_amdgcn_readfirstlane(cl);
+        const ModConst mc = T.mods[jl];
+        const ModConstF mf = T.modsf[jl];
+        const NttTables nt = ntt_tables(T, jl);
+        u64 *__restrict__ dst = S.sum + (((size_t)grp * 2 + cl) * L + jl) * SC::N + (size_t)hl * SC::H;
+        const KsItem it = items[b];
+        if (mf.q != 0.0)
+            moddown_finish_body<LOGN, ArithF64, true>(T, it, L, 0, S, lds, nt.twf, ArithF64::make(mf), mc, b, cl, jl, tl, hl, dst,
+                                                      b == b0);
+        else
+            moddown_finish_body<LOGN, ArithU64, true>(T, it, L, 0, S, lds, nt.tw, ArithU64::make(mc), mc, b, cl, jl, tl, hl, dst,
+                                                      b == b0);
+        __syncthreads();  // the next item's first exchange reuses the LDS words this transform's last pass read
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1544,9 +1593,14 @@ __device__ __forceinline__ typename P::X pair_mac_operand(typename AF::V p, type
     }
 }
 
+// One thread = the four positions 4g..4g+3 of ONE key polynomial c (round 5, after the first stamps: with both polynomials
+// per thread the special-prime workgroups -- 60-bit butterflies, eight Barrett reductions, two inverse radix-4 -- ran
+// ~800 dependent instructions on one wave per SIMD, 5-6 us of a 44 us level).  The last two forward stages of every
+// digit are recomputed by the two threads of a group; the MAC policies keep their two-polynomial shape and are fed the
+// same key words in both slots -- the second slot's accumulators are never read and vanish as dead code.
 template <int LOGN, class AF, class P>
 __device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &it, int L, int relin, int b, int jj, int m,
-                                              uint32_t g, const KsScratch &S)
+                                              int c, uint32_t g, const KsScratch &S)
 {
     constexpr size_t N = (size_t)1 << LOGN, Q = N / 4;
     const ModConst mc = T.mods[m];
@@ -1558,12 +1612,12 @@ __device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &
     const typename AF::TW wb = tw[Q + g], wa0 = tw[2 * Q + 2 * g], wa1 = tw[2 * Q + 2 * g + 1];
     const int slack = mac_x_slack(mc, mf, L);
     const size_t kpoly = (size_t)T.k * N;
-    P A0, A1;  // positions (4g, 4g+1) and (4g+2, 4g+3), both key polynomials each
+    P A0, A1;  // positions (4g, 4g+1) and (4g+2, 4g+3)
     auto mac_digit = [&](int i, const typename P::X &xa, const typename P::X &xb) {
-        const u64 *kb = it.key + ((size_t)i * 2 * T.k + m) * N + 4 * (size_t)g;
-        const ulonglong2 k0a = gld16(kb), k0b = gld16(kb + 2), k1a = gld16(kb + kpoly), k1b = gld16(kb + kpoly + 2);
-        A0.mac(xa, P::kin(k0a, k1a, cx), cx);
-        A1.mac(xb, P::kin(k0b, k1b, cx), cx);
+        const u64 *kb = it.key + ((size_t)i * 2 * T.k + m) * N + (size_t)c * kpoly + 4 * (size_t)g;
+        const ulonglong2 ka = gld16(kb), kc = gld16(kb + 2);
+        A0.mac(xa, P::kin(ka, ka, cx), cx);
+        A1.mac(xb, P::kin(kc, kc, cx), cx);
     };
     if (jj < L) {  // the digit in NTT form modulo its own prime: the (rotated) input row itself, gathered
         const u64 *__restrict__ own = it.c_in + ((size_t)(relin ? 2 * L : L) + jj) * N;
@@ -1579,21 +1633,18 @@ __device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &
         fwd_last_two<LOGN, AF>(p0, p1, p2, p3, wb, wa0, wa1, fx);
         mac_digit(i, pair_mac_operand<AF, P>(p0, p1, slack, fx, cx), pair_mac_operand<AF, P>(p2, p3, slack, fx, cx));
     }
-    ulonglong2 r0a, r1a, r0b, r1b;  // r<poly><pair>
+    ulonglong2 ra, rb, dead_a, dead_b;  // (slot 0 of each accumulator set; slot 1 is dead)
 #ifdef HEFX_NO_LT2Q
-    A0.result(r0a, r1a, cx);
-    A1.result(r0b, r1b, cx);
+    A0.result(ra, dead_a, cx);
+    A1.result(rb, dead_b, cx);
 #else
-    A0.template result<true>(r0a, r1a, cx);
-    A1.template result<true>(r0b, r1b, cx);
+    A0.template result<true>(ra, dead_a, cx);
+    A1.template result<true>(rb, dead_b, cx);
 #endif
     if (jj < L) {
-        u64 *a0 = S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * N + 4 * (size_t)g;
-        u64 *a1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * N + 4 * (size_t)g;
-        gst16(a0, r0a);
-        gst16(a0 + 2, r0b);
-        gst16(a1, r1a);
-        gst16(a1 + 2, r1b);
+        u64 *a = S.acc + (((size_t)b * 2 + c) * (L + 1) + jj) * N + 4 * (size_t)g;
+        gst16(a, ra);
+        gst16(a + 2, rb);
         return;
     }
     // the special prime's rows: the first two stages of INTT_P here (the inverse policy of P; the MAC's words are below 2q
@@ -1602,38 +1653,43 @@ __device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &
     const typename AI::Ctx ix = make_ctx(AI{}, mc, mf);
     const typename AI::TW *__restrict__ itw = inv_tw(AI{}, nt);
     const typename AI::TW va0 = itw[2 * Q + 2 * g], va1 = itw[2 * Q + 2 * g + 1], vb = itw[Q + g];
-    auto inverse_first_two = [&](const ulonglong2 &ra, const ulonglong2 &rb, u64 *__restrict__ up) {
-        const typename AI::V q0 = AI::from_u64(ra.x), q1 = AI::from_u64(ra.y), q2 = AI::from_u64(rb.x), q3 = AI::from_u64(rb.y);
-        const typename AI::V s01 = AI::gs_half_sum(q0, q1, ix), d01 = AI::gs_half_diff(q0, q1, va0, ix);
-        const typename AI::V s23 = AI::gs_half_sum(q2, q3, ix), d23 = AI::gs_half_diff(q2, q3, va1, ix);
-        gst8(up + g, AI::raw(AI::inv_add(s01, s23, ix)));                  // part 0: (sum, sum)
-        gst8(up + Q + g, AI::raw(AI::inv_add(d01, d23, ix)));              // part 1: (difference, sum)
-        gst8(up + 2 * Q + g, AI::raw(AI::inv_sub_mul(s01, s23, vb, ix)));  // part 2: (sum, twiddled difference)
-        gst8(up + 3 * Q + g, AI::raw(AI::inv_sub_mul(d01, d23, vb, ix)));  // part 3
-    };
-    inverse_first_two(r0a, r0b, S.u + ((size_t)b * 2 + 0) * N);
-    inverse_first_two(r1a, r1b, S.u + ((size_t)b * 2 + 1) * N);
+    u64 *__restrict__ up = S.u + ((size_t)b * 2 + c) * N;
+    const typename AI::V q0 = AI::from_u64(ra.x), q1 = AI::from_u64(ra.y), q2 = AI::from_u64(rb.x), q3 = AI::from_u64(rb.y);
+    const typename AI::V s01 = AI::gs_half_sum(q0, q1, ix), d01 = AI::gs_half_diff(q0, q1, va0, ix);
+    const typename AI::V s23 = AI::gs_half_sum(q2, q3, ix), d23 = AI::gs_half_diff(q2, q3, va1, ix);
+    gst8(up + g, AI::raw(AI::inv_add(s01, s23, ix)));                  // part 0: (sum, sum)
+    gst8(up + Q + g, AI::raw(AI::inv_add(d01, d23, ix)));              // part 1: (difference, sum)
+    gst8(up + 2 * Q + g, AI::raw(AI::inv_sub_mul(s01, s23, vb, ix)));  // part 2: (sum, twiddled difference)
+    gst8(up + 3 * Q + g, AI::raw(AI::inv_sub_mul(d01, d23, vb, ix)));  // part 3
 }
 
 template <int LOGN>
 __global__ __launch_bounds__(256) void ks_pair_mac_kernel(DevTables T, const KsItem *__restrict__ items, int L, int relin,
                                                          KsScratch S)
 {
-    const int jj = blockIdx.y, b = blockIdx.z;
+    const int jj = blockIdx.y >> 1, c = blockIdx.y & 1, b = blockIdx.z;  // grid (N/4/256, 2 (L+1), n)
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;  // positions 4g .. 4g+3
     const int m = jj < L ? jj : T.k - 1;
+#ifdef HEFX_STAMP
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)2 * 1024 + wg) * 16] = wall_clock64();
+#endif
     const KsItem it = items[b];
     const ModConst mc = T.mods[m];
     if (T.modsf[m].q != 0.0)
-        pair_mac_body<LOGN, ArithF64, MacF>(T, it, L, relin, b, jj, m, g, S);
+        pair_mac_body<LOGN, ArithF64, MacF>(T, it, L, relin, b, jj, m, c, g, S);
     else
         fwd_int_dispatch(mc, [&](auto pol) {
             using AF = decltype(pol);
             if (L <= 8 && (mc.q >> 60) == 0)  // (mac_dispatch's rule)
-                pair_mac_body<LOGN, AF, MacL>(T, it, L, relin, b, jj, m, g, S);
+                pair_mac_body<LOGN, AF, MacL>(T, it, L, relin, b, jj, m, c, g, S);
             else
-                pair_mac_body<LOGN, AF, MacW>(T, it, L, relin, b, jj, m, g, S);
+                pair_mac_body<LOGN, AF, MacW>(T, it, L, relin, b, jj, m, c, g, S);
         });
+#ifdef HEFX_STAMP
+    if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)2 * 1024 + wg) * 16 + 15] = wall_clock64();
+#endif
 }
 
 template <int LOGN>
@@ -1754,12 +1810,20 @@ __global__ __launch_bounds__(256) void ks_pair_finish_kernel(DevTables T, const 
     const int row = blockIdx.y, b = blockIdx.z;  // row = c * L + j
     const int c = row / L, j = row % L;
     const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+#ifdef HEFX_STAMP
+    const int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)5 * 1024 + wg) * 16] = wall_clock64();
+#endif
     const KsItem it = items[b];
     const ModConst mc = T.mods[j];
     fwd_policy_dispatch(mc, T.modsf[j], [&](auto pol) {
         using A = decltype(pol);
         pair_finish_body<LOGN, A>(T, it, L, relin, b, c, j, g, S);
     });
+#ifdef HEFX_STAMP
+    if (HEFX_STAMP > 1) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    if (threadIdx.x == 0 && wg < 1024) hefx_stamp_buf[((size_t)5 * 1024 + wg) * 16 + 15] = wall_clock64();
+#endif
 }
 
 template <typename K>
@@ -1772,7 +1836,8 @@ static void set_lds(K kernel, size_t bytes)
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, int sub, bool alias,
-                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc)
+                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc,
+                                           const KsStage2 *st2)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -1806,6 +1871,19 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             prof->stage[prof->used++] = stage;
         }
     };
+    // the last launch of a chunk of split-2 workgroups: every item its own output, or sums of sum_r items (KsScratch::sum)
+    auto launch_finish = [&](const KsScratch &ks) {
+        if (ks.sum) {
+            static PerDeviceOnce sum_once;
+            if (sum_once.first()) set_lds(ks_moddown_finish_sum_kernel<LOGN>, lds_fin);
+            const int groups = (n + ks.sum_r - 1) / ks.sum_r;
+            hipLaunchKernelGGL((ks_moddown_finish_sum_kernel<LOGN>), dim3(group_grid(groups * 2, L)), dim3(SC::T), lds_fin, s, T,
+                               batch, L, n, groups * 2, ks);
+        } else {
+            hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                               rl, n * 2, ks);
+        }
+    };
     if (nsrc > 0) {  // exact hoisting: sources batch[n .. n + nsrc), see ks_mac_exact_kernel
         KsScratch hs = scr, fb = scr;
         hs.gate_mode = 1;
@@ -1817,12 +1895,24 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(nsrc * L, L)), dim3(SC::T), lds_ntt, s, T, L, nsrc * L,
                            0, 0, hs);
         mark(3);
-        hipLaunchKernelGGL(ks_mac_exact_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, hs);
+        // HEFX_MACX_LDS=<bytes>: a dynamic-LDS request as an occupancy cap (workgroups per CU = 160 KiB / request), so that the
+        // neighbouring chunk's mod-down finds wave slots while this HBM-bound kernel streams the keys (experiment knob)
+        static const size_t macx_lds = getenv("HEFX_MACX_LDS") ? (size_t)atol(getenv("HEFX_MACX_LDS")) : 0;
+        static PerDeviceOnce macx_once;
+        if (macx_lds > 65536 && macx_once.first()) set_lds(ks_mac_exact_kernel, macx_lds);
+        hipLaunchKernelGGL(ks_mac_exact_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), macx_lds, s, T, batch, L, hs);
+        // two-stage pipeline (st2): everything behind the key MAC -- VALU-bound transforms -- goes to a second, higher-priority
+        // stream, so that it runs UNDER the next chunk's HBM-bound MAC instead of behind it
+        if (st2) {
+            hipError_t e = hipEventRecord(st2->mac_done, s);
+            if (e == hipSuccess) e = hipStreamWaitEvent(st2->stream, st2->mac_done, 0);
+            if (e != hipSuccess) return e;
+            s = st2->stream;
+        }
         mark(4);
         hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, hs);
         mark(5);
-        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
-                           0, n * 2, hs);
+        launch_finish(hs);
         // the fallback: the ordinary five launches, which exit at once unless a source of this chunk held a zero coefficient
         mark(7);
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, 0, 0,
@@ -1832,8 +1922,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, 0, 0, n,
                            0, fb);
         hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, fb);
-        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
-                           0, n * 2, fb);
+        launch_finish(fb);
         mark(-1);
         return hipGetLastError();
     }
@@ -1853,7 +1942,8 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_pair_digits_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
         mark(3);
-        hipLaunchKernelGGL((ks_pair_mac_kernel<LOGN>), dim3(SC::N / 4 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, rl, scr);
+        hipLaunchKernelGGL((ks_pair_mac_kernel<LOGN>), dim3(SC::N / 4 / 256, 2 * (L + 1), n), dim3(256), 0, s, T, batch, L, rl,
+                           scr);
         mark(4);
         hipLaunchKernelGGL((ks_pair_moddown_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T, L, n * 2,
                            scr);
@@ -1968,8 +2058,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, scr);
     mark(5);
-    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
-                       rl, n * 2, scr);
+    launch_finish(scr);
     mark(-1);
     return hipGetLastError();
 }
@@ -2072,7 +2161,7 @@ int lt2_chunk() { return LT2_CHUNK; }
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool alias, const KsItem *small_items,
-                                  int quarter, hipStream_t s, KsProf *prof, int nsrc)
+                                  int quarter, hipStream_t s, KsProf *prof, int nsrc, const KsStage2 *st2)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
@@ -2082,7 +2171,7 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
         small = &sm;
     }
     if (T.logn < 12) quarter = 0;  // quarter rows of N = 2048 would be half-wave workgroups
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, alias, small, quarter, s, prof, nsrc)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, alias, small, quarter, s, prof, nsrc, st2)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }

@@ -14,7 +14,7 @@ from typing import Dict, List
 import numpy as np
 
 MAGIC = b"HEFXKAT1"
-KIND_CT, KIND_PT, KIND_KEY = 1, 2, 3
+KIND_CT, KIND_PT, KIND_KEY, KIND_STREAM = 1, 2, 3, 4
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "seal")
 
 
@@ -53,6 +53,12 @@ class VectorFile:
                 assert r.size == self.k - 1 and r.rows == self.k, "key layout is not [k-1][2][k][N]"
                 return r.words.reshape(self.k - 1, 2, self.k, self.N)
         raise KeyError((tag, elt))
+
+    def stream(self, tag) -> bytes:
+        """the bytes a save() member wrote (record kind 4; aux = byte count)"""
+        r = self.get(tag)
+        assert r.kind == KIND_STREAM
+        return np.ascontiguousarray(r.words, dtype="<u8").tobytes()[:r.aux]
 
     @property
     def from_real_seal(self) -> bool:
@@ -178,3 +184,63 @@ def check(vec: VectorFile, impl) -> Dict[str, object]:
         res["modsw"] = eq(low, vec.ct("modsw"))
         res["rot1_low"] = eq(impl.apply_galois(vec.ct("modsw"), e1, vec.key("gk", e1)), vec.ct("rot1_low"))
     return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SEAL 3.4.5's uncompressed stream layouts as include/seal/seal.h writes them (shim_io.h: "format unpinned" until a file
+# from REAL SEAL has passed check_streams) -- restated here independently of the C++ so that the same check pins both
+# ------------------------------------------------------------------------------------------------------------------
+def seal_parms_id(N: int, primes, scheme: int = 2, plain_modulus: int = 0):
+    """EncryptionParameters::compute_parms_id: SHA3-256 over the uint64 words (scheme, N, primes..., plain modulus)"""
+    import hashlib
+    d = hashlib.sha3_256(struct.pack(f"<{3 + len(primes)}Q", scheme, N, *primes, plain_modulus)).digest()
+    return struct.unpack("<4Q", d)
+
+
+def parse_ciphertext_stream(b: bytes, off: int = 0):
+    """Ciphertext::save -> (fields, words, next offset)"""
+    pid = struct.unpack_from("<4Q", b, off)
+    ntt = b[off + 32]
+    size, n, rows = struct.unpack_from("<3Q", b, off + 33)
+    scale, count = struct.unpack_from("<dQ", b, off + 57)
+    words = np.frombuffer(b, dtype="<u8", count=count, offset=off + 73).astype(np.uint64)
+    return dict(parms_id=pid, is_ntt_form=ntt, size=size, poly_modulus_degree=n, coeff_mod_count=rows, scale=scale), words, off + 73 + 8 * count
+
+
+def check_streams(vec: VectorFile) -> Dict[str, bool]:
+    """The three stream records of a vector file against the layouts the shim writes: parameters, a ciphertext (its words
+    must be the file's own `ct` record) and a Galois-key set holding the key of step 1."""
+    out = {}
+    N, k = vec.N, vec.k
+    key_id = seal_parms_id(N, vec.primes)
+    first_id = seal_parms_id(N, vec.primes[:-1]) if k > 1 else key_id
+    p = vec.stream("parms_stream")
+    want = struct.pack("<BQQ", 2, N, k) + struct.pack(f"<{k}Q", *vec.primes) + struct.pack("<Q", 0)
+    out["parms_stream"] = p == want
+    f, words, end = parse_ciphertext_stream(vec.stream("ct_stream"))
+    ct = vec.get("ct")
+    out["ct_stream"] = (f["parms_id"] == first_id and f["is_ntt_form"] == 1 and f["size"] == ct.size and
+                        f["poly_modulus_degree"] == N and f["coeff_mod_count"] == ct.rows and f["scale"] == ct.scale and
+                        end == len(vec.stream("ct_stream")) and bool((words == ct.words).all()))
+    g = vec.stream("gk1_stream")
+    pid = struct.unpack_from("<4Q", g, 0)
+    (dim1,) = struct.unpack_from("<Q", g, 32)
+    off, ok, found = 40, pid == key_id and dim1 == N, {}
+    for index in range(dim1 if ok else 0):
+        (dim2,) = struct.unpack_from("<Q", g, off)
+        off += 8
+        comps = []
+        for _ in range(dim2):
+            cf, cw, off = parse_ciphertext_stream(g, off)
+            ok = ok and cf["parms_id"] == key_id and cf["size"] == 2 and cf["coeff_mod_count"] == k and cf["is_ntt_form"] == 1
+            comps.append(cw)
+        if dim2:
+            ok = ok and dim2 == k - 1
+            found[2 * index + 1] = np.concatenate(comps)
+    e1 = elt_from_step(1, N)
+    ok = ok and off == len(g) and list(found) == [e1]
+    if ok and vec.has("gk"):  # the generator's default key set and this one-key set come from the same KeyGenerator: same
+        # secret key, fresh randomness -- the WORDS differ, the layout must match the `gk` record's
+        ok = found[e1].size == vec.key("gk", e1).size
+    out["gk1_stream"] = bool(ok)
+    return out

@@ -88,6 +88,9 @@ def test_hip_engine_against_real_seal_vectors(path):
     mode = res.pop("rescale_mode")
     print(f"{os.path.basename(path)} ({vec.producer}): rescale division = {mode}")
     assert all(res.values()), (path, vec.producer, {k_: v for k_, v in res.items() if not v})
+    if vec.has("ct_stream"):  # a file from REAL SEAL pins the serialisation format of include/seal/seal.h as well
+        st = SV.check_streams(vec)
+        assert all(st.values()), (path, vec.producer, st)
 
 
 @pytest.mark.gpu
@@ -124,3 +127,7 @@ def test_generator_built_against_the_shim_roundtrips_through_the_format(tmp_path
             res = SV.check(vec, impl)
             assert res.pop("rescale_mode") == "floor"      # the engine's default division
             assert all(res.values()), (name, type(impl).__name__, {k_: v for k_, v in res.items() if not v})
+        # the save() streams the shim wrote, against the layouts restated in tests/seal_vectors.py (SEAL 3.4.5's, "format
+        # unpinned"): parms_id = SHA3-256 of the parameter words, header fields, the words of `ct`, the key-set framing
+        st = SV.check_streams(vec)
+        assert all(st.values()), (name, st)

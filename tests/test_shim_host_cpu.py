@@ -27,3 +27,25 @@ def test_recording_the_unchanged_linear_transform_loop_is_cheap():
     # medians, with a wide margin for a loaded container (measured here: ~700 and ~400 us)
     assert rec[3] < 3000, f"recording 1000 rotations + products: {rec} us"
     assert sub[3] < 3000, f"planning and submitting them: {sub} us"
+
+
+def test_sha3_parms_id_and_parameter_stream_against_hashlib(tmp_path):
+    """include/seal/shim_io.h without a GPU: drivers/serial_host_probe.cpp (plain g++, no libhefx -- nothing in it touches an
+    engine) prints SHA3-256 of its argument, the SEAL-style parms_id of config 2's parameter set and the bytes of
+    EncryptionParameters::Save; Python's hashlib and struct say what they must be."""
+    import hashlib
+    import struct
+    exe = str(tmp_path / "serial_host_probe")
+    r = subprocess.run(["g++", "-O1", "-std=c++17", "-w", "-I" + os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "drivers", "serial_host_probe.cpp"), "-o", exe], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    primes = [0xffffffffffe8001, 0xfffff4c001, 0xfffffdc001, 0xfffffffffffc001]
+    for msg in ("", "abc", "x" * 135, "y" * 136, "z" * 500):   # empty, short, one byte under / exactly / several times the rate
+        out = subprocess.run([exe, msg], capture_output=True, text=True, timeout=60).stdout.split("\n")
+        assert out[0] == "sha3 " + hashlib.sha3_256(msg.encode()).hexdigest()
+    words = [2, 8192] + primes + [0]
+    want_id = struct.unpack("<4Q", hashlib.sha3_256(struct.pack("<7Q", *words)).digest())
+    _, a, b, c, d, stream = out[1].split()
+    assert tuple(int(x, 16) for x in (a, b, c, d)) == want_id
+    assert bytes.fromhex(stream) == struct.pack("<BQQ", 2, 8192, 4) + struct.pack("<4Q", *primes) + struct.pack("<Q", 0)
+    assert out[2] == "roundtrip 1"

@@ -25,6 +25,10 @@
 //     plaintext  : size = 1, rows x N words (CKKS plaintexts are in NTT form)
 //     key        : size = decomposition count (k-1), rows = k; words = [digit][component 0/1][row][N]
 //                  = the concatenation of PublicKey::data() of KSwitchKeys::data()[index]; aux = Galois element (0 = relin)
+//     stream (kind 4): the bytes a save() member wrote, padded with zeros to whole words; aux = byte count.  Pins the
+//                  SERIALISATION format (include/seal/shim_io.h is "format unpinned" until a real SEAL has written these):
+//                  tags parms_stream (EncryptionParameters::Save of the key-level parameters), ct_stream (ct.save),
+//                  gk1_stream (a GaloisKeys holding only the key of step 1, .save)
 //   tags: inputs  ct, ct_b, pt, gk (one per element, aux = element), rk
 //         outputs rot1 = rotate_vector(ct, 1)            rot1_mulpt = multiply_plain(rot1, pt)
 //                 rotm1 = rotate_vector(ct, -1)          rot3_naf = rotate_vector(ct, 3) with power-of-two keys only
@@ -36,6 +40,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -139,6 +144,14 @@ void put_key(Writer &w, const std::string &tag, const std::vector<PublicKey> &ke
     w.record(tag, 3, (std::uint32_t)key.size(), (std::uint32_t)rows, elt, 1.0, all.data(), all.size());
 }
 
+// the bytes of a save() call as a record of kind 4 (aux = byte count)
+void put_stream(Writer &w, const std::string &tag, const std::string &bytes)
+{
+    std::vector<std::uint64_t> words((bytes.size() + 7) / 8, 0);
+    std::memcpy(words.data(), bytes.data(), bytes.size());
+    w.record(tag, 4, 1, 0, (std::uint32_t)bytes.size(), 1.0, words.data(), words.size());
+}
+
 std::uint32_t elt_from_step(int step, std::size_t n)
 {
     const std::uint64_t m = 2 * n;
@@ -225,6 +238,26 @@ void generate(const std::string &dir, const Set &s)
                         econj = (std::uint32_t)(2 * n - 1);
     for (std::uint32_t e : {e1, em1, e4, econj}) put_key(w, "gk", gk.key(e), e);
     put_key(w, "rk", rk.key(2), 0);
+
+    // ---- serialised forms (SEAL >= 3.5 prefixes a SEALHeader and may compress: compr_mode_type::none keeps the body plain)
+    {
+        std::ostringstream ps, cs, gs;
+#ifdef SEAL_API_36
+        key_parms.save(ps, compr_mode_type::none);
+        ct.save(cs, compr_mode_type::none);
+        GaloisKeys gk1;
+        keygen.create_galois_keys(std::vector<int>{1}, gk1);
+        gk1.save(gs, compr_mode_type::none);
+#else
+        EncryptionParameters::Save(key_parms, ps);
+        ct.save(cs);
+        GaloisKeys gk1 = keygen.galois_keys(std::vector<int>{1});
+        gk1.save(gs);
+#endif
+        put_stream(w, "parms_stream", ps.str());
+        put_stream(w, "ct_stream", cs.str());
+        put_stream(w, "gk1_stream", gs.str());
+    }
 
     // ---- known answers
     Ciphertext rot1, rotm1, rot3, conj, mulpt, add, mul, sq, relin, rescale, rescale3, modsw, rot1_low, rot1_mulpt, addpl;

@@ -25,7 +25,9 @@ lib.hefx_debug_stamps.argtypes = [ctypes.c_void_p, ctypes.c_int]
 words = lib.hefx_debug_stamps(None, 0)
 assert words > 0
 buf = np.zeros(words, dtype=np.uint64)
-names = ["intt_digits", "ntt_digits", "mac", "moddown_intt", "moddown_finish"]
+# stamp slots: on the five-launch path one launch each; on the pair path (HEFX_PAIR, default for small batches) slots 0 + 1
+# are the inverse / forward halves of ks_pair_digits, 3 + 4 those of ks_pair_moddown, 5 is ks_pair_finish
+names = ["intt_digits", "ntt_digits", "mac", "moddown_intt", "moddown_finish", "pair_finish"]
 rows = []
 for rep in range(8):
     for _ in range(3):
@@ -37,7 +39,7 @@ for rep in range(8):
     assert lib.hefx_debug_stamps(buf.ctypes.data, 0) == words
     rows.append(buf.reshape(8, 1024, 16).astype(np.int64).copy())
 # the repetition with the median end-to-end time
-span = [int(max(r[k][:, 15].max() for k in range(5)) - r[0][:, 0][r[0][:, 0] > 0].min()) for r in rows]
+span = [int(max(r[k][:, 15].max() for k in range(6)) - r[0][:, 0][r[0][:, 0] > 0].min()) for r in rows]
 r = rows[int(np.argsort(span)[len(span) // 2])]
 t0 = r[0][:, 0][r[0][:, 0] > 0].min()
 us = lambda v: (v - t0) / 100.0
@@ -47,6 +49,8 @@ prev_end = None
 for kid, name in enumerate(names):
     s = r[kid]
     live = s[:, 15] > 0
+    if not live.any():
+        continue
     first, last = s[live, 0].min(), s[live, 15].max()
     crit = int(np.argmax(np.where(live, s[:, 15], 0)))
     gap = "" if prev_end is None else f"  gap after previous kernel {(first - prev_end) / 100.0:5.2f} us"
