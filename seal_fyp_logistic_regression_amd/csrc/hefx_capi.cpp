@@ -167,11 +167,6 @@ struct hefx_context {
     static constexpr int MAX_STREAMS = 4;
     hipStream_t streams[MAX_STREAMS] = {};  // internal streams for chunk pipelining
     hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {};
-    // exactly hoisted batches run as a two-stage pipeline: key MACs (HBM-bound) back to back on streams[0], everything
-    // behind them (VALU-bound) on this higher-priority stream, created on first use (a hardware queue: 8-20 ms)
-    hipStream_t hi_stream = nullptr;
-    hipEvent_t ev_join_hi = nullptr, mac_ev[KS_RING] = {};
-    bool hi_failed = false;
     int nstreams = 2;
     bool use_streams = true;
     // CKKS encode: tables built on first use, value staging buffer
@@ -474,12 +469,8 @@ extern "C" void hefx_context_destroy(hefx_context *c)
         if (c->ev_join[s]) (void)hipEventDestroy(c->ev_join[s]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->hi_stream) (void)hipStreamDestroy(c->hi_stream);
-    if (c->ev_join_hi) (void)hipEventDestroy(c->ev_join_hi);
-    for (int s = 0; s < KS_RING; ++s) {
+    for (int s = 0; s < KS_RING; ++s)
         if (c->ring_ev[s]) (void)hipEventDestroy(c->ring_ev[s]);
-        if (c->mac_ev[s]) (void)hipEventDestroy(c->mac_ev[s]);
-    }
     if (c->h_items) (void)hipHostFree(c->h_items);
     if (c->d_items) (void)hipFree(c->d_items);
     if (c->chain_items) (void)hipFree(c->chain_items);
@@ -1091,15 +1082,10 @@ static int ks_small_shape(int n, int L)
 // small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
 // the next; the caller's stream is forked before and joined after.
 // acc_in / acc_out (both or neither; rotations without a fused plaintext only): acc_out[i] = acc_in[i] + ct_out[i]
-// sum_base / sum_r / sum_list (engine-internal, hefx_linear_transform_plain: every item has a plaintext, the caller wants only
-// the SUM of the products): chunks of split-2 workgroups add up sum_r consecutive products each and write only those sums --
-// ciphertext-sized buffers from sum_base on, n / sum_r + n / 32 + 2 of them at most -- instead of the items' ct_out; chunks
-// on the small-batch path write their ct_out as ever.  sum_list receives the buffers whose sum is the batch's sum.
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
                   uint64_t *const *ct_out, void *stream, bool hoist = false, const uint64_t *const *acc_in = nullptr,
-                  uint64_t *const *acc_out = nullptr, uint64_t *sum_base = nullptr, int sum_r = 0,
-                  std::vector<const uint64_t *> *sum_list = nullptr)
+                  uint64_t *const *acc_out = nullptr)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
@@ -1119,8 +1105,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
         chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
     }
-    int nchunks = (n + chunk - 1) / chunk;
-    bool two = nchunks > 1 && c->use_streams && !c->profiling;
+    const int nchunks = (n + chunk - 1) / chunk;
+    const bool two = nchunks > 1 && c->use_streams && !c->profiling;
     int sub = c->sub;
     // HEFX_SUB > 0 restricts the digit x modulus scratch to `sub` items at a time (K2 + MAC per sub-chunk).
     // Measured neutral on MI355X (the scratch traffic is not what binds), so the default is one sub-chunk.
@@ -1242,8 +1228,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
     }
     auto src = [&](int i) { return ord.empty() ? i : ord[(size_t)i]; };
-    int cmax = n < chunk ? n : chunk;
-    int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
+    const int cmax = n < chunk ? n : chunk;
+    const int ns = two ? (nchunks < c->nstreams ? nchunks : c->nstreams) : 1;
     // EXACT HOISTING (ks_mac_exact_kernel): when at most a third as many DISTINCT source ciphertexts as items are rotated
     // -- the d-1 rotations of a linear transform rotate ONE (helper.h:252-257) -- every distinct source is decomposed and
     // extended to the key moduli once per chunk and the items run the gathered key MAC with the flip-mask correction:
@@ -1266,41 +1252,6 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         if (int rc = ensure_flipw(c, elts, n, (hipStream_t)stream, flips)) return rc;
         if (flips.empty()) share = false;  // the tables' memory budget is spent
     }
-    // TWO-STAGE PIPELINE of a hoisted batch (round 5).  Its key MAC streams every item's key from HBM (7.9 MB each at C3)
-    // while everything behind it is VALU-bound transforms; with whole chunks alternating between two equal streams the
-    // second chunk's MAC filled every wave slot and the first chunk's mod-down ran only when it was over (measured: MAC,
-    // MAC, then both mod-downs: profiles/r04_lt_direct_d512_timeline.txt).  Now all MACs run back to back on ONE stream and
-    // the launches behind them on a second stream of HIGHER PRIORITY, whose workgroups the dispatcher places first as the
-    // MAC's short workgroups retire -- and the chunks are smaller (128 items: HEFX_HOIST_CHUNK), so the part that cannot be
-    // hidden, the last chunk's mod-down, is half as long.
-    // MEASURED AND NOT ADOPTED (profiles/EXPERIMENTS.md, round 5): 2.35 against 2.11 ms per direct-key transform at d = 512.  The
-    // priority does place the second stage's workgroups, but a 512-thread, 68 KiB-LDS transform workgroup only fits a CU once
-    // two of the MAC's four waves per SIMD have drained, so ks_moddown_finish runs at a third of its speed beside the MAC
-    // (390 us per 128 items against 136 alone) and the period per chunk is 474 us where the MAC alone takes 285.
-    // Opt-in: HEFX_HOIST_PIPE=1.
-    static const bool pipe_ok = getenv("HEFX_HOIST_PIPE") && atoi(getenv("HEFX_HOIST_PIPE")) != 0;
-    static const int hoist_chunk = getenv("HEFX_HOIST_CHUNK") ? std::max(ks_small_max() + 1, atoi(getenv("HEFX_HOIST_CHUNK"))) : 128;
-    bool pipe = share && pipe_ok && c->use_streams && !c->profiling && !c->hi_failed && n > hoist_chunk && c->chunk <= 0;
-    if (pipe && !c->hi_stream) {
-        int least = 0, greatest = 0;
-        hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
-        if (e == hipSuccess) e = hipStreamCreateWithPriority(&c->hi_stream, hipStreamNonBlocking, greatest);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join_hi, hipEventDisableTiming);
-        for (int i = 0; i < KS_RING && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&c->mac_ev[i], hipEventDisableTiming);
-        if (e != hipSuccess) {  // no second queue: the alternating scheme still works
-            (void)hipGetLastError();
-            c->hi_failed = true;
-            pipe = false;
-        }
-    }
-    if (pipe) {
-        chunk = std::min(chunk, hoist_chunk);
-        nchunks = (n + chunk - 1) / chunk;
-        cmax = n < chunk ? n : chunk;
-        two = true;
-        ns = std::min(std::min(nchunks, 2), c->nstreams);  // scratch sets: a chunk's stage 2 runs under the next chunk's MAC
-        if (sub > cmax || sub <= 0) sub = cmax;
-    }
     // (a hoisted chunk's fallback runs the digit transforms of all its items at once: x for the whole chunk)
     const size_t x_words = ks_x_words(c, L, fused || share || sub > cmax ? cmax : sub);
     const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
@@ -1309,11 +1260,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     if (two) {
         HIPCHK(hipEventRecord(c->ev_fork, user));
         for (int s = 0; s < ns; ++s) HIPCHK(hipStreamWaitEvent(c->streams[s], c->ev_fork, 0));
-        if (pipe) HIPCHK(hipStreamWaitEvent(c->hi_stream, c->ev_fork, 0));
     }
-    // who used a scratch set last: a chunk that takes it over on ANOTHER stream waits for that chunk's last launch
-    hipStream_t set_stream[hefx_context::MAX_STREAMS] = {};
-    int set_slot[hefx_context::MAX_STREAMS] = {-1, -1, -1, -1};
     const size_t N = c->n;
     // from here on only HIP runtime failures can occur; they stop the submission, and the internal streams are still
     // joined to the caller's stream below so that whatever was launched stays ordered before the caller's next work
@@ -1324,7 +1271,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         herr = (expr);                     \
         if (herr != hipSuccess) hwhat = #expr; \
     }
-    int ci = 0, sum_next = 0;
+    int ci = 0;
     ++c->stat_ks_calls;
     for (int base = 0; base < n && herr == hipSuccess; base += chunk, ++ci) {
         const int cnt = (n - base < chunk) ? n - base : chunk;
@@ -1394,16 +1341,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             prof = &c->prof;
             ++c->prof_chunks;
         }
-        // pipeline: every hoisted chunk's first stage on streams[0], its second on the high-priority stream (a chunk that is
-        // not hoisted -- a short tail -- runs whole on streams[1 mod ns])
-        const bool staged = pipe && nsrc > 0;
-        hipStream_t cs = !two ? user : staged ? c->streams[0] : c->streams[pipe ? (ns > 1 ? 1 : 0) : ci % ns];
-        hipStream_t last = staged ? c->hi_stream : cs;  // where the chunk's last launch goes
-        const int set = two ? ci % ns : 0;
-        if (set_slot[set] >= 0 && set_stream[set] != cs) KS_TRY(hipStreamWaitEvent(cs, c->ring_ev[set_slot[set]], 0));
-        set_stream[set] = last;
-        set_slot[set] = (int)slot;
-        const KsStage2 st2{c->hi_stream, c->mac_ev[slot]};
+        hipStream_t cs = two ? c->streams[ci % ns] : user;
         // small chunks carry their descriptors in the first launch's kernel arguments (HEFX_SMALL=0 restores the copy)
         static const bool small_ok = !(getenv("HEFX_SMALL") && atoi(getenv("HEFX_SMALL")) == 0);
         const bool small = small_ok && cnt <= ks_small_max() && !nsrc && !chunk_alias;
@@ -1423,23 +1361,11 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             sd.c_in = (const u64 *)so.first;
             sd.elt = 1u;
         }
-        if (sum_list) {
-            if (sum_base && sum_r > 0 && pts && !small) {
-                const int groups = (cnt + sum_r - 1) / sum_r;
-                uint64_t *first = sum_base + (size_t)sum_next * 2 * L * N;
-                S.sum = (u64 *)first;
-                S.sum_r = sum_r;
-                for (int g = 0; g < groups; ++g) sum_list->push_back(first + (size_t)g * 2 * L * N);
-                sum_next += groups;
-            } else {
-                for (int i = 0; i < cnt; ++i) sum_list->push_back(ct_out[src(base + i)]);
-            }
-        }
         c->stat_ks_items += (uint64_t)cnt, c->stat_ks_hoisted += nsrc ? (uint64_t)cnt : 0, ++c->stat_ks_chunks;
         if (!small) KS_TRY(hipMemcpyAsync(db, hb, sizeof(KsItem) * (cnt + nsrc), hipMemcpyHostToDevice, cs));
         KS_TRY(launch_keyswitch_chunk(c->T, L, cnt, db, relin, S, fused ? -1 - fused_code : sub, chunk_alias, small ? hb : nullptr,
-                                      quarter, cs, prof, nsrc, staged ? &st2 : nullptr));
-        if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], last) == hipSuccess) c->ring_busy[slot] = true;
+                                      quarter, cs, prof, nsrc));
+        if (herr == hipSuccess && hipEventRecord(c->ring_ev[slot], cs) == hipSuccess) c->ring_busy[slot] = true;
     }
 #undef KS_TRY
     if (two) {
@@ -1447,11 +1373,6 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             hipError_t e = hipEventRecord(c->ev_join[s], c->streams[s]);
             if (e == hipSuccess) e = hipStreamWaitEvent(user, c->ev_join[s], 0);
             if (e != hipSuccess && herr == hipSuccess) herr = e, hwhat = "join of the internal streams";
-        }
-        if (pipe) {
-            hipError_t e = hipEventRecord(c->ev_join_hi, c->hi_stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(user, c->ev_join_hi, 0);
-            if (e != hipSuccess && herr == hipSuccess) herr = e, hwhat = "join of the second-stage stream";
         }
     }
     if (herr != hipSuccess) return hipfail(herr, hwhat);
@@ -2322,12 +2243,8 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         }
         leaf[l] = cur;
     }
-    // ---- workspace, part 2: one ciphertext per node, then the group sums of the fused rotate-and-multiply products
-    // (ks_moddown_finish_sum_kernel adds up LT_SUM_R products at a time; HEFX_LT_SUM=0: every product written, one add_many)
-    constexpr int LT_SUM_R = 8;
-    static const bool lt_sum_ok = !(getenv("HEFX_LT_SUM") && atoi(getenv("HEFX_LT_SUM")) == 0);
-    const size_t sum_cap = lt_sum_ok ? (size_t)d / LT_SUM_R + (size_t)d / 32 + 2 * (size_t)max_depth + 4 : 0;
-    const size_t need = ctw * (nodes.size() + sum_cap);
+    // ---- workspace, part 2: one ciphertext per node
+    const size_t need = ctw * nodes.size();
     if (c->lt_cap < need) {
         HIPCHK(hipDeviceSynchronize());
         if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
@@ -2337,11 +2254,6 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         c->lt_cap = need;
     }
     uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
-    uint64_t *sum0 = node0 + ctw * nodes.size();
-    size_t sums_used = 0;
-    std::vector<const uint64_t *> res;  // what add_many adds up: product 0, group sums, products of small batches
-    res.reserve((size_t)d);
-    res.push_back(prod0);
     auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
     // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth   (helper.h:252-257)
     std::vector<const uint64_t *> in, kk, pp;
@@ -2360,24 +2272,15 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
                 if (fused) pp.push_back(diag_pts[nd.fused]);
             }
             if (in.empty()) continue;
-            if (!fused) {
-                if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr, nullptr, oo.data(), stream,
-                                    hoisted))
-                    return rc;
-                continue;
-            }
-            // the fused nodes are the leaves: their products only ever meet in the final sum (helper.h:252-259)
-            const size_t before = res.size();
-            if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr, pp.data(), oo.data(), stream,
-                                hoisted, nullptr, nullptr, sum_cap ? sum0 + sums_used * ctw : nullptr, LT_SUM_R, &res))
+            if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
+                                fused ? pp.data() : nullptr, oo.data(), stream, hoisted))
                 return rc;
-            for (size_t i = before; i < res.size(); ++i)
-                if (res[i] >= sum0 && res[i] < sum0 + sum_cap * ctw) ++sums_used;
-            if (sums_used > sum_cap) return fail(HEFX_ERR_HIP, "linear transform: group-sum workspace exceeded (internal)");
         }
     // ---- out = add_many(res)               (helper.h:259)
-    (void)leaf;
-    return hefx_add_many(c, L, 2, (int)res.size(), res.data(), out, stream);
+    std::vector<const uint64_t *> res(d);
+    res[0] = prod0;
+    for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
+    return hefx_add_many(c, L, 2, d, res.data(), out, stream);
 }
 
 extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,

@@ -106,11 +106,6 @@ struct KsScratch {
     const u64 *qmod;
     uint32_t *gate, *gate_hits;  // gate_hits: chunks redone by the fallback so far (hefx_ks_fallback_count)
     uint32_t gate_tag, gate_mode;
-    // SUM mode of the mod-down finish (ks_moddown_finish_sum_kernel; every item carries a fused plaintext): the products of
-    // sum_r consecutive items are added up by the workgroup that computes them and only the sums are written --
-    // sum[g][2][L][N] for group g = item / sum_r; the items' c_out are not touched.  null: every item writes its own output.
-    u64 *sum;
-    int sum_r, pad_;
 };
 
 constexpr int ADD_MANY_GROUP = 48;
@@ -151,14 +146,9 @@ struct KsProf {
 // quarter: additionally run the chunk on quarter-row workgroups (four per row, eight coefficients per thread)
 // nsrc > 0: exact hoisting (ks_mac_exact_kernel) -- d_items[n .. n + nsrc) describe the chunk's distinct source
 // ciphertexts; they are decomposed and extended once (scr.d / scr.x hold SOURCE rows), every item runs the gathered MAC
-// st2 (exactly hoisted chunks only): the launches behind the key MAC go to st2->stream, ordered behind the MAC by st2->mac_done
-struct KsStage2 {
-    hipStream_t stream;
-    hipEvent_t mac_done;
-};
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *d_items, bool relin,
                                   const KsScratch &scr, int sub, bool alias, const KsItem *small_items,
-                                  int quarter, hipStream_t s, KsProf *prof, int nsrc = 0, const KsStage2 *st2 = nullptr);
+                                  int quarter, hipStream_t s, KsProf *prof, int nsrc = 0);
 // tables of exact hoisting: rows[e][m][.] = the flip mask (coefficient order) of the Galois element whose inverse mod 2N is
 // d_ginv[e], once per modulus row m = 0..k-1; the caller transforms the rows
 hipError_t launch_flip_rows(const DevTables &T, const uint32_t *d_ginv, int count, u64 *rows, hipStream_t s);

@@ -1045,14 +1045,11 @@ __device__ __forceinline__ u64 md_epilogue(ArithF64, double f, u64 acc, u64 sadd
     return ArithF64::moddown(f, acc, sadd, pt, has_pt, cx, pinv.v);
 }
 
-// SUM: the output goes into a running sum instead of the item's c_out (sum_dst: this workgroup's slice of the group's sum;
-// sum_first: nothing to add to yet) -- see KsScratch::sum
-template <int LOGN, class A, bool SUM = false>
+template <int LOGN, class A>
 __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const KsItem &it, int L, int relin,
                                                     const KsScratch &S, u64 *lds,
                                                     const typename A::TW *__restrict__ tw, const typename A::Ctx &cx,
-                                                    const ModConst &mc, int b, int c, int j, int t, int h,
-                                                    u64 *__restrict__ sum_dst = nullptr, bool sum_first = false)
+                                                    const ModConst &mc, int b, int c, int j, int t, int h)
 {
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
@@ -1076,7 +1073,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
     const bool has_add = relin || c == 0;
     const uint32_t elt = relin ? 1u : item_elt(it);
     const u64 *__restrict__ pt = it.pt ? it.pt + (size_t)j * SC::N + off : nullptr;
-    u64 *__restrict__ dst = SUM ? sum_dst : it.c_out + ((size_t)c * L + j) * SC::N + off;
+    u64 *__restrict__ dst = it.c_out + ((size_t)c * L + j) * SC::N + off;
     typename A::V f[16];
     u64 keep[16];  // the outputs, for the optional accumulate behind the epilogue (dead otherwise)
     {
@@ -1124,13 +1121,6 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
                     ulonglong2 o;
                     o.x = md_epilogue(A{}, f[GS * g + r], a[cur][r], sadd[cur][r], pp[cur][r], HP, cx, pinv, mc);
                     o.y = md_epilogue(A{}, f[GS * g + r + 1], a[cur][r + 1], sadd[cur][r + 1], pp[cur][r + 1], HP, cx, pinv, mc);
-                    if constexpr (SUM) {  // (the running sum is this workgroup's own 64 KiB slice: an L1 / L2 hit, loaded at its use
-                        // -- as a fourth prefetched operand stream it cost 160 bytes per lane of scratch; unconditional: what
-                        // the first item of a group reads is never used)
-                        const ulonglong2 mv = gld16(dst + C::idx_io(t, GS * g + r));
-                        o.x = sum_first ? o.x : addmod(mv.x, o.x, q);
-                        o.y = sum_first ? o.y : addmod(mv.y, o.y, q);
-                    }
                     gst16(dst + C::idx_io(t, GS * g + r), o);
                     if constexpr (!HP) keep[GS * g + r] = o.x, keep[GS * g + r + 1] = o.y;
                 }
@@ -1150,7 +1140,7 @@ __device__ __forceinline__ void moddown_finish_body(const DevTables &T, const Ks
         }
         // accumulate (hefx_apply_galois_add_batch; never together with a fused plaintext product): acc_out = acc_in + out,
         // one workgroup-uniform branch behind the epilogue, all loads of the thread requested before the first is used
-        if (!SUM && it.acc_out && !pt) {
+        if (it.acc_out && !pt) {
             const size_t arow = ((size_t)c * L + j) * SC::N + off;
             const u64 *__restrict__ ain = it.acc_in + arow;
             u64 *__restrict__ aout = it.acc_out + arow;
@@ -1188,45 +1178,6 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_modd
         // profiles/r03/ab_finish_l16.txt; one of five rows per polynomial is integer-policy)
         moddown_finish_body<LOGN, ArithU64>(T, it, L, relin, S, lds, nt.tw, ArithU64::make(mc), mc, b, c, j, t, h);
     HEFX_STAMP_AT(15);
-}
-
-// (5s) the same with the products of sum_r consecutive items ADDED UP by the workgroup that computes them (KsScratch::sum):
-// Linear_Transform_Plain needs only the sum of its d - 1 rotate-and-multiply products (helper.h:252-259), and writing
-// every product to be read once more by add_many was 1.3 MB out and 1.3 MB in per rotation -- 0.15 ms of a 2.1 ms transform
-// at d = 512.  A workgroup owns (group, c, j, half) and walks the group's items; its slice of the running sum stays in
-// its own cache.  Modular addition of canonical residues is associative: the bits of add_many over the products.
-template <int LOGN>
-__global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::FWD) void ks_moddown_finish_sum_kernel(DevTables T,
-                                                                                     const KsItem *__restrict__ items, int L,
-                                                                                     int n, int rows, KsScratch S)
-{
-    using SC = SplitCfg<LOGN>;
-    extern __shared__ __align__(16) u64 lds[];
-    int g, j, h;
-    group_decode(blockIdx.x, L, g, j, h);  // g = (group, c)
-    if (g >= rows || ks_gated_out(S)) return;
-    const int grp = g >> 1, c = g & 1;
-    const int b0 = grp * S.sum_r, b1 = b0 + S.sum_r < n ? b0 + S.sum_r : n;
-    for (int b = b0; b < b1; ++b) {
-        // Everything the body derives from (thread, row, half) is recomputed per item: laundered through empty asm so that
-        // loop-invariant code motion cannot stretch sixteen 64-bit addresses, the twiddle prefix and the row's constants
-        // across the whole transform (hoisted, they cost this kernel 370 bytes per lane of scratch under its 128-VGPR cap).
-        int tl = threadIdx.x, jl = j, hl = h, cl = c;
-        asm volatile("" : "+v"(tl), "+v"(jl), "+v"(hl), "+v"(cl));
-        jl = __builtin_amdgcn_readfirstlane(jl), hl = __builtin_amdgcn_readfirstlane(hl), cl = __builtin_amdgcn_readfirstlane(cl);
-        const ModConst mc = T.mods[jl];
-        const ModConstF mf = T.modsf[jl];
-        const NttTables nt = ntt_tables(T, jl);
-        u64 *__restrict__ dst = S.sum + (((size_t)grp * 2 + cl) * L + jl) * SC::N + (size_t)hl * SC::H;
-        const KsItem it = items[b];
-        if (mf.q != 0.0)
-            moddown_finish_body<LOGN, ArithF64, true>(T, it, L, 0, S, lds, nt.twf, ArithF64::make(mf), mc, b, cl, jl, tl, hl, dst,
-                                                      b == b0);
-        else
-            moddown_finish_body<LOGN, ArithU64, true>(T, it, L, 0, S, lds, nt.tw, ArithU64::make(mc), mc, b, cl, jl, tl, hl, dst,
-                                                      b == b0);
-        __syncthreads();  // the next item's first exchange reuses the LDS words this transform's last pass read
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1836,8 +1787,7 @@ static void set_lds(K kernel, size_t bytes)
 template <int LOGN>
 static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                            const KsScratch &scr, int sub, bool alias,
-                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc,
-                                           const KsStage2 *st2)
+                                           const KsSmallItems *small, int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     using SC = SplitCfg<LOGN>;
     const size_t lds = SC::LDS_BYTES;
@@ -1871,19 +1821,6 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
             prof->stage[prof->used++] = stage;
         }
     };
-    // the last launch of a chunk of split-2 workgroups: every item its own output, or sums of sum_r items (KsScratch::sum)
-    auto launch_finish = [&](const KsScratch &ks) {
-        if (ks.sum) {
-            static PerDeviceOnce sum_once;
-            if (sum_once.first()) set_lds(ks_moddown_finish_sum_kernel<LOGN>, lds_fin);
-            const int groups = (n + ks.sum_r - 1) / ks.sum_r;
-            hipLaunchKernelGGL((ks_moddown_finish_sum_kernel<LOGN>), dim3(group_grid(groups * 2, L)), dim3(SC::T), lds_fin, s, T,
-                               batch, L, n, groups * 2, ks);
-        } else {
-            hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
-                               rl, n * 2, ks);
-        }
-    };
     if (nsrc > 0) {  // exact hoisting: sources batch[n .. n + nsrc), see ks_mac_exact_kernel
         KsScratch hs = scr, fb = scr;
         hs.gate_mode = 1;
@@ -1895,24 +1832,12 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(nsrc * L, L)), dim3(SC::T), lds_ntt, s, T, L, nsrc * L,
                            0, 0, hs);
         mark(3);
-        // HEFX_MACX_LDS=<bytes>: a dynamic-LDS request as an occupancy cap (workgroups per CU = 160 KiB / request), so that the
-        // neighbouring chunk's mod-down finds wave slots while this HBM-bound kernel streams the keys (experiment knob)
-        static const size_t macx_lds = getenv("HEFX_MACX_LDS") ? (size_t)atol(getenv("HEFX_MACX_LDS")) : 0;
-        static PerDeviceOnce macx_once;
-        if (macx_lds > 65536 && macx_once.first()) set_lds(ks_mac_exact_kernel, macx_lds);
-        hipLaunchKernelGGL(ks_mac_exact_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), macx_lds, s, T, batch, L, hs);
-        // two-stage pipeline (st2): everything behind the key MAC -- VALU-bound transforms -- goes to a second, higher-priority
-        // stream, so that it runs UNDER the next chunk's HBM-bound MAC instead of behind it
-        if (st2) {
-            hipError_t e = hipEventRecord(st2->mac_done, s);
-            if (e == hipSuccess) e = hipStreamWaitEvent(st2->stream, st2->mac_done, 0);
-            if (e != hipSuccess) return e;
-            s = st2->stream;
-        }
+        hipLaunchKernelGGL(ks_mac_exact_kernel, dim3(SC::N / 2 / 256, L + 1, n), dim3(256), 0, s, T, batch, L, hs);
         mark(4);
         hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, hs);
         mark(5);
-        launch_finish(hs);
+        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                           0, n * 2, hs);
         // the fallback: the ordinary five launches, which exit at once unless a source of this chunk held a zero coefficient
         mark(7);
         hipLaunchKernelGGL((ks_intt_digits_kernel<LOGN>), dim3(split_grid(n * L)), dim3(SC::T), lds_intt, s, T, batch, L, 0, 0,
@@ -1922,7 +1847,8 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, 0, 0, n,
                            0, fb);
         hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, fb);
-        launch_finish(fb);
+        hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                           0, n * 2, fb);
         mark(-1);
         return hipGetLastError();
     }
@@ -2058,7 +1984,8 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
     mark(4);
     hipLaunchKernelGGL((ks_moddown_intt_kernel<LOGN>), dim3(split_grid(n * 2)), dim3(SC::T), lds_mdi, s, T, L, n * 2, scr);
     mark(5);
-    launch_finish(scr);
+    hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T, batch, L,
+                       rl, n * 2, scr);
     mark(-1);
     return hipGetLastError();
 }
@@ -2161,7 +2088,7 @@ int lt2_chunk() { return LT2_CHUNK; }
 int ks_small_max() { return KS_SMALL_MAX; }
 hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem *batch, bool relin,
                                   const KsScratch &scr, int sub, bool alias, const KsItem *small_items,
-                                  int quarter, hipStream_t s, KsProf *prof, int nsrc, const KsStage2 *st2)
+                                  int quarter, hipStream_t s, KsProf *prof, int nsrc)
 {
     KsSmallItems sm;
     const KsSmallItems *small = nullptr;
@@ -2171,7 +2098,7 @@ hipError_t launch_keyswitch_chunk(const DevTables &T, int L, int n, const KsItem
         small = &sm;
     }
     if (T.logn < 12) quarter = 0;  // quarter rows of N = 2048 would be half-wave workgroups
-#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, alias, small, quarter, s, prof, nsrc, st2)
+#define CALL(LN) launch_keyswitch_chunk_t<LN>(T, L, n, batch, relin, scr, sub, alias, small, quarter, s, prof, nsrc)
     HEFX_DISPATCH_SPLIT(T.logn, CALL)
 #undef CALL
 }
