@@ -279,6 +279,16 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         if (hipGetDevice(&cur) != hipSuccess || cur != device) return fail(HEFX_ERR_HIP, "hipSetDevice failed");
     }
 
+    // HEFX_DEBUG=1: where context creation spends its time (stderr), for tools/first_call_costs2.py
+    const bool dbg = getenv("HEFX_DEBUG") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hefx] context_create: %-44s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - t_last).count());
+        t_last = now;
+    };
+    lap("device selection (HIP runtime start-up)");
     hefx_context *c = new hefx_context();
     c->device = device;
     c->n = poly_degree;
@@ -390,8 +400,10 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
                 c->noise.t[i] = (u64)((long double)cdf * 18446744073709551616.0L);
         }
     }
+    lap("twiddle / constant tables on the host");
     hipError_t e = hipMalloc(&c->d_tables, total);
     if (e == hipSuccess) e = hipMemcpy(c->d_tables, host.data(), total, hipMemcpyHostToDevice);
+    lap("first hipMalloc + table upload");
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_flag, c->flag_cap * sizeof(int));
     if (e == hipSuccess) e = hipMemset(c->d_flag, 0, c->flag_cap * sizeof(int));
     if (const char *ev = getenv("HEFX_STREAMS")) {
@@ -406,6 +418,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join[s], hipEventDisableTiming);
     }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    lap("internal streams + events");
     if (e == hipSuccess) e = hipHostMalloc((void **)&c->h_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK, hipHostMallocDefault);
     if (e == hipSuccess) e = hipMalloc((void **)&c->d_items, sizeof(KsItem) * KS_RING * KS_MAX_CHUNK);
     for (int s = 0; s < KS_RING && e == hipSuccess; ++s) e = hipEventCreateWithFlags(&c->ring_ev[s], hipEventDisableTiming);
@@ -418,6 +431,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         if (e == hipSuccess) e = hipMalloc((void **)&c->d_gate, sizeof(uint32_t) * (KS_RING + 1));
         if (e == hipSuccess) e = hipMemset(c->d_gate, 0, sizeof(uint32_t) * (KS_RING + 1));
     }
+    lap("descriptor ring (pinned + device), gate words");
     if (const char *sv = getenv("HEFX_SUB")) c->sub = atoi(sv);
     if (const char *fv = getenv("HEFX_FLIPW_MB")) c->flipw_cap = (size_t)strtoull(fv, nullptr, 10) << 20;
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
@@ -433,6 +447,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
         hefx_context_destroy(c);
         return fail(HEFX_ERR_HIP, "kernel code objects failed to load");
     }
+    lap("code objects of the four kernel files (warm launches)");
     unsigned char *base = static_cast<unsigned char *>(c->d_tables);
     c->T.tw = reinterpret_cast<const ulonglong2 *>(base);
     c->T.itw = reinterpret_cast<const ulonglong2 *>(base + tw_bytes);
@@ -2175,6 +2190,14 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
     for (int i = 0; i < d; ++i)
         if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
     LtKeys K;
     for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
@@ -2190,6 +2213,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         if (hoisted && plans[(size_t)l].size() != 1)
             return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
     }
+    lap("key map + rotation plans");
     // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
     if (c->lt_head_cap < 4 * ctw) {
         HIPCHK(hipDeviceSynchronize());
@@ -2212,6 +2236,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
     // ---- res[0] = ct_new * diag[0]         (helper.h:250)
     if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
+    lap("head submitted (rotate -d, add, product 0)");
     // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
     struct Node {
         int parent;  // -1: ct_new
@@ -2243,6 +2268,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         }
         leaf[l] = cur;
     }
+    lap("forest");
     // ---- workspace, part 2: one ciphertext per node
     const size_t need = ctw * nodes.size();
     if (c->lt_cap < need) {
@@ -2276,11 +2302,14 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
                                 fused ? pp.data() : nullptr, oo.data(), stream, hoisted))
                 return rc;
         }
+    lap("key-switch batches submitted");
     // ---- out = add_many(res)               (helper.h:259)
     std::vector<const uint64_t *> res(d);
     res[0] = prod0;
     for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
-    return hefx_add_many(c, L, 2, d, res.data(), out, stream);
+    const int rc = hefx_add_many(c, L, 2, d, res.data(), out, stream);
+    lap("add_many submitted");
+    return rc;
 }
 
 extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,
@@ -2315,6 +2344,14 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
         return fail(HEFX_ERR_INVALID, "baby-step/giant-step transform: dimension too large for the slot count");
     for (int i = 0; i < d; ++i)
         if (!shifted_diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
     LtKeys K;
     for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
@@ -2404,6 +2441,14 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
         return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
     for (int i = 0; i < nterms; ++i)
         if (!diag_pts_keylevel[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
     LtKeys K;
     for (int i = 0; i < nkeys; ++i)
         if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");

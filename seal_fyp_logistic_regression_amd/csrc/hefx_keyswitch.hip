@@ -220,8 +220,9 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 // Small batches (a lone rotation of a NAF chain, the lockstep chains of a few dot products): the descriptors travel in
 // the KERNEL ARGUMENTS of this first launch -- no host-to-device descriptor copy ahead of the sequence (a ~4 us blit
 // plus its dependency gap on a ~90 us operation) -- and block 0 leaves them in device memory for the launches after it.
-// 32 descriptors = 1.5 KB of kernel arguments.  (8 until round 3: a batch of 9..32 items then paid the descriptor copy
-// and lost the quarter-row inverse launches -- 57 us at n = 8 against 80 us at n = 12 at L = 2; now 59 us.)
+// 32 descriptors of 80 bytes = 2.5 KB of kernel arguments (the segment holds 4 KiB: static_assert below).  (8 until round 3:
+// a batch of 9..32 items then paid the descriptor copy and lost the quarter-row inverse launches -- 57 us at n = 8 against
+// 80 us at n = 12 at L = 2; now 59 us.)
 #ifndef HEFX_SMALL_MAX
 #define HEFX_SMALL_MAX 32
 #endif
@@ -229,6 +230,9 @@ constexpr int KS_SMALL_MAX = HEFX_SMALL_MAX;
 struct KsSmallItems {
     KsItem it[KS_SMALL_MAX];
 };
+// the widest argument list that carries the descriptors: (DevTables, KsSmallItems, KsItem *, 5 ints, KsScratch)
+static_assert(sizeof(KsSmallItems) + sizeof(DevTables) + sizeof(KsScratch) + sizeof(void *) + 8 * sizeof(int) <= 4096,
+              "small-batch descriptors no longer fit the 4 KiB kernel-argument segment: lower HEFX_SMALL_MAX");
 template <int LOGN>
 __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt_digits_small_kernel(DevTables T, KsSmallItems small,
                                                                                     KsItem *__restrict__ items_out, int n,
