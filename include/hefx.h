@@ -205,13 +205,19 @@ int hefx_apply_galois_add_batch(hefx_context *ctx, int L, int n, const uint64_t 
  *      ct_out = t_steps, acc_out = a_steps; the inputs are not written.  Level by level the same key switches as `steps`
  *      calls of hefx_apply_galois_add_batch (same bits); the intermediate rotations live in two engine-owned buffer sets,
  *      so the levels are two alternating launch sequences issued from one loop -- no per-level validation, allocation
- *      or host bookkeeping.  HEFX_CHAIN_GRAPH=1 replays them as a captured two-level HIP graph instead (measured
- *      slower on MI355X / ROCm 7.2: 60 against 54 us per level at n = 8, L = 2). */
+ *      or host bookkeeping.  What the unvalidated levels write is checked up front, for every n: a null pointer, or any
+ *      two of the 2n buffers d_ct_out[i] / d_acc_out[i] overlapping in bytes, is HEFX_ERR_INVALID before anything is
+ *      submitted (d_ct_out[i] == d_ct_in[i] is fine: the inputs are read by the first level only).  Up to 32 chains run
+ *      on the small-batch path (four launches per level, 38-44 us at N = 16384, L = 2), sixteen or more of them dealt
+ *      over the caller's stream and the internal ones, eight per stream (HEFX_CHAIN_LANES=<k> forces k streams).
+ *      HEFX_CHAIN_GRAPH=1 replays the levels as a captured two-level HIP graph instead (measured slower on MI355X /
+ *      ROCm 7.2: 60 against 54 us per level at n = 8, L = 2, round 4). */
 int hefx_rotate_add_chain(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in, const uint32_t *galois_elts,
                           const uint64_t *const *d_keys, const uint64_t *const *d_acc_in, uint64_t *const *d_acc_out,
                           uint64_t *const *d_ct_out, int steps, void *stream);
 
 /* ---- Evaluator::relinearize_inplace (helper.h:440,541; polynomial.cpp:92,187): size 3 -> 2. */
+/* (input and output must not overlap in bytes -- three polynomials in, two out; checked for n = 1 as for a batch) */
 int hefx_relinearize(hefx_context *ctx, int L, const uint64_t *d_ct3, const uint64_t *d_relin_key,
                      uint64_t *d_ct2, void *stream);
 int hefx_relinearize_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct3,

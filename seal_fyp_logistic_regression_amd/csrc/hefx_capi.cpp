@@ -1097,10 +1097,13 @@ static int ks_small_shape(int n, int L)
 // small tail launches of one chunk (2 workgroups per item in the mod-down INTT) overlap the wide launches of
 // the next; the caller's stream is forked before and joined after.
 // acc_in / acc_out (both or neither; rotations without a fused plaintext only): acc_out[i] = acc_in[i] + ct_out[i]
+// trusted (engine-internal callers whose inputs and outputs are engine-owned workspace, disjoint by construction --
+// hefx_linear_transform_plain's node buffers): the O(n log n) byte-range independence check is skipped (40 us of host time
+// in front of the first launch of a 511-rotation batch)
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
                   uint64_t *const *ct_out, void *stream, bool hoist = false, const uint64_t *const *acc_in = nullptr,
-                  uint64_t *const *acc_out = nullptr)
+                  uint64_t *const *acc_out = nullptr, bool trusted = false)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
@@ -1169,7 +1172,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // submitted, on BYTE RANGES (callers hand out views of one allocation: big.view(...) slices): no two outputs may
     // overlap, and no input or plaintext may overlap another item's output -- nor its own, except the exact in-place
     // rotation c_in == c_out, which the kernels serve from a scratch copy.  O(n log n) on the host.
-    if (n > 1 || pts || acc_out || relin) {  // (a lone relinearisation too: its three input polys against its two output polys)
+    if (!trusted && (n > 1 || pts || acc_out || relin)) {  // (a lone relinearisation too: its three input polys against its two output polys)
         const size_t row = (size_t)c->n * sizeof(u64);
         const size_t out_b = 2 * (size_t)L * row, in_b = (relin ? 3 : 2) * (size_t)L * row, pt_b = (size_t)L * row;
         std::vector<std::pair<uintptr_t, int>> outs((size_t)n);
@@ -1257,7 +1260,9 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // at C3, d = 512; 2.76-2.79 / 2.70-2.74 / 2.78-2.83 ms at N = 8192, d = 1000)
     static const size_t share_ratio = getenv("HEFX_SHARE_RATIO") ? (size_t)std::max(1, atoi(getenv("HEFX_SHARE_RATIO"))) : 3;
     bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
-    if (share) {
+    bool one_source = share;  // the common case -- a linear transform's rotations of ct_new -- needs no hash set
+    for (int i = 1; i < n && one_source; ++i) one_source = ct_in[i] == ct_in[0];
+    if (share && !one_source) {
         std::unordered_set<const void *> distinct;
         for (int i = 0; i < n && distinct.size() * share_ratio <= (size_t)n; ++i) distinct.insert((const void *)ct_in[i]);
         share = distinct.size() * share_ratio <= (size_t)n;
@@ -1311,7 +1316,10 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         bool chunk_alias = false;
         int nsrc = 0;  // > 0: this chunk runs exactly hoisted over that many distinct sources
         std::unordered_map<const void *, uint32_t> src_of;
-        if (share && cnt > ks_small_max()) {
+        if (share && cnt > ks_small_max() && one_source) {
+            src_of.emplace((const void *)ct_in[0], 0u);
+            nsrc = 1;
+        } else if (share && cnt > ks_small_max()) {
             for (int i = 0; i < cnt && src_of.size() * share_ratio <= (size_t)cnt; ++i)
                 src_of.emplace((const void *)ct_in[src(base + i)], (uint32_t)src_of.size());
             if (src_of.size() * share_ratio <= (size_t)cnt && cnt + (int)src_of.size() <= KS_MAX_CHUNK) nsrc = (int)src_of.size();
@@ -1331,7 +1339,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             it.dsrc = it.pad_ = 0;
             it.flipw = nullptr;
             if (nsrc) {
-                it.dsrc = src_of[(const void *)ct_in[j]];
+                it.dsrc = one_source ? 0u : src_of[(const void *)ct_in[j]];
                 it.flipw = flips[(size_t)j];
             }
             if (!relin && it.c_in == it.c_out) {  // in place: the kernels read a scratch copy (ks_alias_copy_kernel)
@@ -2298,8 +2306,10 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
                 if (fused) pp.push_back(diag_pts[nd.fused]);
             }
             if (in.empty()) continue;
+            // (node buffers are this context's workspace, disjoint by construction; the diagonals are the caller's and
+            // cannot reach into it: the batch is trusted)
             if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
-                                fused ? pp.data() : nullptr, oo.data(), stream, hoisted))
+                                fused ? pp.data() : nullptr, oo.data(), stream, hoisted, nullptr, nullptr, true))
                 return rc;
         }
     lap("key-switch batches submitted");

@@ -508,14 +508,17 @@ def test_primes_at_the_top_of_the_admissible_range_bit_exact(N):
             assert (e.rescale_to_next(L, 2, e.to_device(r), rounded=rounded).download() == o.rescale(r, rounded=rounded)).all()
 
 
-@pytest.mark.parametrize("knob", ["HEFX_QUARTER=0", "HEFX_QUARTER=1", "auto", "HEFX_QMASK=5", "HEFX_QMASK=10"])
+@pytest.mark.parametrize("knob", ["HEFX_QUARTER=0", "HEFX_QUARTER=1", "auto", "HEFX_QMASK=5", "HEFX_QMASK=10", "HEFX_PAIR=1", "HEFX_PAIR=0"])
 def test_small_batch_quarter_row_path_bit_exact(knob):
     """The small-batch key switch (quarter-row workgroups with eight coefficients per thread, descriptors in the kernel
     arguments) gives the oracle's bits for rotations, fused rotate+multiply_plain and relinearisation at every ring size it
     is built for (N = 4096 .. 32768: every radix-8 pass / remainder combination of the 8-coefficient cores), top and lower
     levels, 1..19 items, distinct keys / elements.  Each of the four transform launches picks quarter rows or split-2
     workgroups on its own (the scratch layouts are shared): forced off, forced on, the engine's own per-launch rule, and the
-    two complementary mixes (inverse launches on quarter rows with forward ones on split-2 workgroups, and the reverse)."""
+    two complementary mixes (inverse launches on quarter rows with forward ones on split-2 workgroups, and the reverse).
+    Round 5: "auto" takes the PAIR path (four launches, two transform phases: ks_pair_*) wherever 4 L^2 n <= 512 workgroups;
+    HEFX_PAIR=1 forces it for every small batch -- also the ones whose 1900 quarter workgroups are not co-resident -- and
+    HEFX_PAIR=0 keeps it off."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = r"""
@@ -558,7 +561,7 @@ for name in ("C2", "C3", "C4", "C5", "toy4096", "toy2048"):
         ok &= bool((dd.download() == o.apply_galois(ct, 3, keys[0])).all())
 print("PARITY", ok)
 """ % (root, root)
-    env = {k: v for k, v in os.environ.items() if k not in ("HEFX_QUARTER", "HEFX_QMASK")}
+    env = {k: v for k, v in os.environ.items() if k not in ("HEFX_QUARTER", "HEFX_QMASK", "HEFX_PAIR", "HEFX_PAIR_MAX")}
     if knob != "auto":
         env[knob.split("=")[0]] = knob.split("=")[1]
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)

@@ -223,12 +223,14 @@ def test_apply_galois_add_batch_refuses_overlapping_sums():
 
 @pytest.mark.parametrize("setname,L,n,steps", [("C3", 2, 8, 1), ("C3", 2, 8, 2), ("C3", 2, 8, 3), ("C3", 2, 8, 12),
                                                ("C3", 2, 8, 13), ("C3", 5, 1, 11), ("C2", 3, 3, 10), ("C3", 2, 40, 4),
-                                               ("C4", 7, 8, 5), ("C5", 5, 2, 4)])
+                                               ("C4", 7, 8, 5), ("C5", 5, 2, 4), ("C3", 2, 17, 4), ("C3", 2, 24, 5),
+                                               ("C2", 2, 32, 3)])
 def test_rotate_add_chain_bit_exact(setname, L, n, steps):
     """hefx_rotate_add_chain = the loop of helper.h:472-476 (rotate_vector_inplace(dup, step); add_inplace(mult, dup)) for
     n pairs in lockstep, against the oracle's loop: final rotation and final sum word for word, inputs untouched.  12 / 13
     steps at n = 8, L = 2 is the shape of the LR gradient's chains (logistic_regression_ckks.cpp:295-300), an even and an odd
-    count of middle levels; 1-3 steps the degenerate plans; n = 40 the wide path."""
+    count of middle levels; 1-3 steps the degenerate plans; n = 40 the wide path; n = 17 / 24 / 32: two / three / three LANES
+    (round 5: one lane per 8 chains, each on its own stream with its own scratch slice and descriptor slots)."""
     N, primes = SETS[setname]
     o, e = _engine_and_oracle(N, primes)
     keys = [_key(o, 61 + i) for i in range(2)]
@@ -240,7 +242,7 @@ def test_rotate_add_chain_bit_exact(setname, L, n, steps):
     dct, dacc = [e.to_device(c) for c in cts], [e.to_device(a) for a in accs]
     outs, sums = e.rotate_add_chain(L, dct, elts, [dkeys[i % 2] for i in range(n)], dacc, steps)
     e.sync()
-    for i in (range(n) if n <= 8 else (0, 1, 17, 39)):
+    for i in (range(n) if n <= 8 else sorted({0, 1, n // 3, n // 2, (2 * n) // 3, n - 2, n - 1})):
         t, a = cts[i], accs[i]
         for _ in range(steps):
             t = o.apply_galois(t, elts[i], keys[i % 2])
