@@ -1072,9 +1072,11 @@ static size_t ks_x_words(const hefx_context *c, int L, int sub) { return (size_t
 
 // Workgroup shapes of a SMALL chunk (descriptors in the kernel arguments, one launch sequence; KS_Q_* mask).
 // Pair path (round 5, ks_pair_*): four launches with two transform phases instead of five with four -- taken while its
-// widest grid (4 L^2 quarter workgroups per item) still gets about two CUs' worth of room per workgroup pair, i.e. for what
-// the latency path is for: lone rotations of a NAF chain, the lockstep chains of a few dot products.  HEFX_PAIR=0/1
-// forces it off / on, HEFX_PAIR_MAX=<workgroups> moves the bound.
+// widest grid (4 L^2 quarter workgroups per item) still gets a CU per workgroup (ks_pair_digits runs at 190 VGPRs: one
+// 512-thread workgroup per CU), i.e. for what the latency path is for: lone rotations of a NAF chain, the lockstep chains
+// of a few dot products.  Measured over n = 1..32, L = 2..8 (profiles/r05/small_batch_pair_sweep.txt): it wins by 8-11 us up
+// to 256 workgroups (n = 16 at L = 2, 4 at L = 4, 1 at L = 8) and loses beyond (n = 24, L = 2: 82.8 against 75.2 us).
+// HEFX_PAIR=0/1 forces it off / on, HEFX_PAIR_MAX=<workgroups> moves the bound.
 // Otherwise per launch: quarter rows where the quarter grid (4 workgroups per row) still gets a CU per workgroup -- measured
 // with clock stamps over n = 1..8, L = 2..8 (profiles/r03/quarter_mask_sweep.txt) and end to end up to n = 32: the
 // inverse launches up to 256 / 192 quarter workgroups (256 of the mod-down inverse at n = 32 measured +27 us), the
@@ -1085,7 +1087,7 @@ static int ks_small_shape(int n, int L)
     static const int quarter_force = getenv("HEFX_QUARTER") ? atoi(getenv("HEFX_QUARTER")) : -1;
     static const int qmask_force = getenv("HEFX_QMASK") ? atoi(getenv("HEFX_QMASK")) : -1;
     static const int pair_force = getenv("HEFX_PAIR") ? atoi(getenv("HEFX_PAIR")) : -1;
-    static const int pair_max = getenv("HEFX_PAIR_MAX") ? atoi(getenv("HEFX_PAIR_MAX")) : 512;
+    static const int pair_max = getenv("HEFX_PAIR_MAX") ? atoi(getenv("HEFX_PAIR_MAX")) : 256;
     if (qmask_force >= 0) return qmask_force & (KS_Q_ALL | KS_Q_PAIR);
     if (pair_force > 0 || (pair_force < 0 && quarter_force < 0 && n * L * L * 4 <= pair_max)) return KS_Q_PAIR;
     if (quarter_force >= 0) return quarter_force ? KS_Q_ALL : 0;
@@ -2293,23 +2295,30 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     std::vector<const uint64_t *> in, kk, pp;
     std::vector<uint64_t *> oo;
     std::vector<uint32_t> ee;
+    // One batch per depth: the nodes that end in a diagonal product (leaves) and the ones that only feed deeper nodes are
+    // independent of one another, so they go out together -- larger batches, i.e. more two-chunk submissions whose phases
+    // overlap on the two internal streams, and half the latency-bound calls at the shallow depths (round 5; until then two
+    // batches per depth.  HEFX_LT_MERGE=0 restores that).  A null entry of `pp` = no fused product for that item.
+    static const bool merge = !(getenv("HEFX_LT_MERGE") && atoi(getenv("HEFX_LT_MERGE")) == 0);
     for (int depth = 0; depth < max_depth; ++depth)
-        for (int fused = 0; fused < 2; ++fused) {
+        for (int pass = 0; pass < (merge ? 1 : 2); ++pass) {
             in.clear(), kk.clear(), pp.clear(), oo.clear(), ee.clear();
+            bool any_pt = false;
             for (size_t i = 0; i < nodes.size(); ++i) {
                 const Node &nd = nodes[i];
-                if (nd.depth != depth || (nd.fused >= 0) != (fused != 0)) continue;
+                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0))) continue;
                 in.push_back(node_ptr(nd.parent));
                 ee.push_back(nd.elt);
                 kk.push_back(K.at(nd.elt));
                 oo.push_back(node_ptr((int)i));
-                if (fused) pp.push_back(diag_pts[nd.fused]);
+                pp.push_back(nd.fused >= 0 ? diag_pts[nd.fused] : nullptr);
+                any_pt = any_pt || nd.fused >= 0;
             }
             if (in.empty()) continue;
             // (node buffers are this context's workspace, disjoint by construction; the diagonals are the caller's and
             // cannot reach into it: the batch is trusted)
             if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
-                                fused ? pp.data() : nullptr, oo.data(), stream, hoisted, nullptr, nullptr, true))
+                                any_pt ? pp.data() : nullptr, oo.data(), stream, hoisted, nullptr, nullptr, true))
                 return rc;
         }
     lap("key-switch batches submitted");
