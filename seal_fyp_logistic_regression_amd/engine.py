@@ -318,6 +318,19 @@ class Engine:
             capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 
+    def prepare_rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs):
+        """The C argument arrays of rotate_multiply_plain_batch built ONCE, for callers that submit the same batch repeatedly
+        (bench.py: 9216 items per step are ~5 ms of Python list building around ~10 ms of GPU work at N = 8192, which a C or
+        C++ caller of the ABI never pays).  Returns an opaque tuple for rotate_multiply_plain_prepared; the buffers stay
+        referenced by it."""
+        n = len(cts)
+        return (L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts), capi.ptr_array([k.ptr for k in keys]),
+                capi.ptr_array([p.ptr for p in pts]), capi.ptr_array([o.ptr for o in outs]), (cts, keys, pts, outs))
+
+    def rotate_multiply_plain_prepared(self, prep, stream=None):
+        L, n, a_ct, a_elt, a_key, a_pt, a_out, _ = prep
+        capi.check(capi.lib().hefx_rotate_multiply_plain_batch(self._h, L, n, a_ct, a_elt, a_key, a_pt, a_out, stream))
+
     def relinearize(self, L, ct3, key, out=None, stream=None):
         out = out if out is not None else DeviceArray(self, (2, L, self.N))
         capi.check(capi.lib().hefx_relinearize(self._h, L, ct3.ptr, key.ptr, out.ptr, stream))
