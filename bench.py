@@ -665,8 +665,9 @@ def main():
     # `secondary` (north_star: "poly_modulus_degree in {8192, 16384}"): the same unit at the other
     # parameter sets, each on its own engine context with its own device-drawn batch, timed like the headline (barrier +
     # sync on both sides, max over ranks) for about a second, three outputs checked against the oracle on rank 0
+    # (single-rank runs only: a leg that fails on ONE rank of a multi-rank run would leave its peers in the leg's barriers)
     secondary = {}
-    for name in [x for x in args.secondary.split(",") if x and x != args.set]:
+    for name in [x for x in args.secondary.split(",") if x and x != args.set and world == 1]:
         try:
             secondary[name] = secondary_bench(name, Engine, local_rank, rank, world, timed, key32)
         except Exception as ex:  # reported, never fatal for the headline

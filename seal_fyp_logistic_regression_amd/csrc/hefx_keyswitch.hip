@@ -348,6 +348,10 @@ struct MacW {
     // LT2Q: words below 2q instead of canonical ones -- what the regular MAC leaves in the accumulator scratch: both of
     // its readers take them as they are (the inverse transform of the special-prime rows: first stage on words below 2q;
     // the mod-down epilogue: acc + 4q - f < 6q into a Shoup product), one conditional subtraction less per word
+    // what a DATA-prime accumulator row holds in scratch (read by the mod-down epilogue only): integer policies their
+    // result<LT2Q>; the FP64 policy its unfinished sums as doubles (MacF::result_data)
+    template <bool LT2Q = false>
+    __device__ __forceinline__ void result_data(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const { result<LT2Q>(r0, r1, c); }
     template <bool LT2Q = false>
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
     {
@@ -414,6 +418,8 @@ struct MacL {
         return LT2Q ? barrett128_lt2q(lo, hi, mc) : barrett128(lo, hi, mc);
     }
     template <bool LT2Q = false>
+    __device__ __forceinline__ void result_data(ulonglong2 &r0, ulonglong2 &r1, const Ctx &cx) const { result<LT2Q>(r0, r1, cx); }
+    template <bool LT2Q = false>
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &cx) const
     {
         r0.x = fold<LT2Q>(c[0], cx.mc);
@@ -457,7 +463,16 @@ struct MacF {
         a1x += ArithF64::mm(in.a1x, dx, c);
         a1y += ArithF64::mm(in.a1y, dy, c);
     }
-    template <bool LT2Q = false>  // FP64 rows are stored canonical either way
+    // Data-prime rows (round 5): the UNFINISHED sums as doubles -- |a| <= L * 0.52 q < 2^45 -- which the mod-down epilogue
+    // subtracts its unfinished transform value from as they are (ArithF64::moddown: |acc - f| < 2^46, a valid left operand of
+    // the modmul, hefx_ntt.cuh InvRecentre); no canonicalisation here (eight instructions per word) and no u64 -> f64
+    // conversion there (two).  The special prime's row stays canonical (result): the inverse transform reads it.
+    template <bool LT2Q = false>
+    __device__ __forceinline__ void result_data(ulonglong2 &r0, ulonglong2 &r1, const Ctx &) const
+    {
+        r0.x = ArithF64::raw(a0x), r0.y = ArithF64::raw(a0y), r1.x = ArithF64::raw(a1x), r1.y = ArithF64::raw(a1y);
+    }
+    template <bool LT2Q = false>  // (canonical either way)
     __device__ __forceinline__ void result(ulonglong2 &r0, ulonglong2 &r1, const Ctx &c) const
     {
         r0.x = ArithF64::canon(a0x, c);
@@ -578,11 +593,19 @@ __device__ __forceinline__ void mac_items(const DevTables &T, const u64 *key, in
 #pragma unroll
     for (int e = 0; e < NI; ++e) {
         ulonglong2 r0, r1;
+        if (jj < L) {  // a data prime's row: what the mod-down epilogue reads (result_data)
 #ifdef HEFX_NO_LT2Q
-        A[e].result(r0, r1, cx);
+            A[e].result_data(r0, r1, cx);
 #else
-        A[e].template result<true>(r0, r1, cx);
+            A[e].template result_data<true>(r0, r1, cx);
 #endif
+        } else {  // the special prime's row: the inverse transform's input
+#ifdef HEFX_NO_LT2Q
+            A[e].result(r0, r1, cx);
+#else
+            A[e].template result<true>(r0, r1, cx);
+#endif
+        }
         mac_store<STREAM>(acc0[e], acc1[e], w, r0, r1);
     }
 }
@@ -751,15 +774,29 @@ __global__ __launch_bounds__(256) void ks_mac_exact_kernel(DevTables T, const Ks
             term(i, xb, k0, k1);
         }
         ulonglong2 r0, r1, f0, f1;
-        A.result(r0, r1, cx);
         P C;
         C.mac_diag(B, wv, cx);
-        C.result(f0, f1, cx);
-        const u64 q = T.mods[m].q;
-        r0.x = addmod(r0.x, f0.x, q);
-        r0.y = addmod(r0.y, f0.y, q);
-        r1.x = addmod(r1.x, f1.x, q);
-        r1.y = addmod(r1.y, f1.y, q);
+        if constexpr (std::is_same<P, MacF>::value) {
+            if (jj < L) {  // a data prime's FP64 row: the two unfinished sums added as doubles (MacF::result_data)
+                P S2 = A;
+                S2.a0x += C.a0x, S2.a0y += C.a0y, S2.a1x += C.a1x, S2.a1y += C.a1y;
+                S2.result_data(r0, r1, cx);
+            } else {
+                A.result(r0, r1, cx);
+                C.result(f0, f1, cx);
+                const u64 q = T.mods[m].q;
+                r0.x = addmod(r0.x, f0.x, q), r0.y = addmod(r0.y, f0.y, q);
+                r1.x = addmod(r1.x, f1.x, q), r1.y = addmod(r1.y, f1.y, q);
+            }
+        } else {
+            A.result(r0, r1, cx);
+            C.result(f0, f1, cx);
+            const u64 q = T.mods[m].q;
+            r0.x = addmod(r0.x, f0.x, q);
+            r0.y = addmod(r0.y, f0.y, q);
+            r1.x = addmod(r1.x, f1.x, q);
+            r1.y = addmod(r1.y, f1.y, q);
+        }
         mac_store<false>(S.acc + (((size_t)b * 2 + 0) * (L + 1) + jj) * n, S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * n,
                          w, r0, r1);
     });
@@ -938,10 +975,13 @@ __global__ __launch_bounds__(FusedCfg<LOGN>::T, 4) void ks_ntt_macf_kernel(DevTa
         u64 *__restrict__ o1 = S.acc + (((size_t)b * 2 + 1) * (L + 1) + jj) * FC::N + off;
 #pragma unroll
         for (int r = 0; r < 8; r += 2) {
+            // (data primes: unfinished doubles, MacF::result_data; the special prime: canonical)
             *reinterpret_cast<ulonglong2 *>(o0 + C::idx_out(t, r)) =
-                make_ulonglong2(ArithF64::canon(a0[r], cx), ArithF64::canon(a0[r + 1], cx));
+                jj < L ? make_ulonglong2(ArithF64::raw(a0[r]), ArithF64::raw(a0[r + 1]))
+                       : make_ulonglong2(ArithF64::canon(a0[r], cx), ArithF64::canon(a0[r + 1], cx));
             *reinterpret_cast<ulonglong2 *>(o1 + C::idx_out(t, r)) =
-                make_ulonglong2(ArithF64::canon(a1[r], cx), ArithF64::canon(a1[r + 1], cx));
+                jj < L ? make_ulonglong2(ArithF64::raw(a1[r]), ArithF64::raw(a1[r + 1]))
+                       : make_ulonglong2(ArithF64::canon(a1[r], cx), ArithF64::canon(a1[r + 1], cx));
         }
         return;
     }
@@ -1589,13 +1629,23 @@ __device__ __forceinline__ void pair_mac_body(const DevTables &T, const KsItem &
         mac_digit(i, pair_mac_operand<AF, P>(p0, p1, slack, fx, cx), pair_mac_operand<AF, P>(p2, p3, slack, fx, cx));
     }
     ulonglong2 ra, rb, dead_a, dead_b;  // (slot 0 of each accumulator set; slot 1 is dead)
+    if (jj < L) {
 #ifdef HEFX_NO_LT2Q
-    A0.result(ra, dead_a, cx);
-    A1.result(rb, dead_b, cx);
+        A0.result_data(ra, dead_a, cx);
+        A1.result_data(rb, dead_b, cx);
 #else
-    A0.template result<true>(ra, dead_a, cx);
-    A1.template result<true>(rb, dead_b, cx);
+        A0.template result_data<true>(ra, dead_a, cx);
+        A1.template result_data<true>(rb, dead_b, cx);
 #endif
+    } else {
+#ifdef HEFX_NO_LT2Q
+        A0.result(ra, dead_a, cx);
+        A1.result(rb, dead_b, cx);
+#else
+        A0.template result<true>(ra, dead_a, cx);
+        A1.template result<true>(rb, dead_b, cx);
+#endif
+    }
     if (jj < L) {
         u64 *a = S.acc + (((size_t)b * 2 + c) * (L + 1) + jj) * N + 4 * (size_t)g;
         gst16(a, ra);
@@ -2010,6 +2060,9 @@ __global__ __launch_bounds__(256) void lt2_reduce_kernel(DevTables T, int L, int
         acc.x = addmod(acc.x, v.x, q);
         acc.y = addmod(acc.y, v.y, q);
     }
+    // the accumulator scratch (period L + 1) holds a data prime's FP64-policy row as doubles (MacF::result_data)
+    if (period == L + 1 && jj < L && T.modsf[jj].q != 0.0)
+        acc = make_ulonglong2(ArithF64::raw(ArithF64::from_u64(acc.x)), ArithF64::raw(ArithF64::from_u64(acc.y)));
     reinterpret_cast<ulonglong2 *>(out + (size_t)r * n)[w] = acc;
 }
 

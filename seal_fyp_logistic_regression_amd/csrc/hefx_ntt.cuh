@@ -420,7 +420,7 @@ struct ArithF64 {
     __device__ static __forceinline__ u64 moddown(V f, u64 acc, u64 sadd, u64 pt, bool has_pt, const Ctx &c,
                                                   const double2 &pinv)
     {
-        double z = from_u64(acc) - f;  // exact: |f| < 2^45
+        double z = unraw(acc) - f;  // acc: the key MAC's unfinished FP64 sum as a double (MacF::result_data, |acc| < 2^45); exact: |f| < 2^45
         z = mm(z, pinv.x, c) + from_u64(sadd);
         if (has_pt) {  // the product is already in (-0.52q, 0.52q): no re-centring before the sign fix-up
             z = mm(z, from_u64(pt), c);
@@ -429,6 +429,33 @@ struct ArithF64 {
         return canon(z, c);
     }
     __device__ static __forceinline__ u64 inv_finish(V x, const Ctx &c) { return canon(x, c); }
+};
+
+// ---- where the FP64 inverse cores re-centre (round 5) -------------------------------------------------------------
+// A Gentleman-Sande stage doubles the sum path (x' = x + y) and leaves the twiddled difference reduced, so between two
+// re-centrings (|x| <= 0.5 q) the values are bounded by 0.5 q * 2^s after s stages.  The modmul stays EXACT for a left
+// operand below 2^49 (DESIGN.md "FP64 modmul", extended: h + l = y*w is an error-free product for any doubles; the quotient
+// estimate rint(h * RN(1/q)) errs by < 0.5 + 2^48 * 3 * 2^-53 + 2^36 / q < 0.72, so |t| < 0.75 q; h - c q is an integer below
+// 2^41 and exact in the FMA; t = s + l is an integer below 2^42), hence every stage may be ENTERED with values up to
+// 64 q = 0.5 q * 2^7 (the difference it feeds the modmul is then below 128 q < 2^48 for q < 2^41).  A pass of c stages entered
+// at s re-centres first iff s + c - 1 > 7.  Until round 5 every pass did: four re-centrings per split-2 row at N = 16384
+// where this rule asks for one (-144 of ~1300 instructions per thread on the FP64 inverse rows).
+// Passes are numbered in execution order: k = 0 is the remainder pass when there is one (rstages > 0), then the full passes.
+struct InvRecentre {
+    static constexpr int SMAX = 7;
+    __host__ __device__ static constexpr bool at(int rstages, int nfull, int cfull, int s0, int k)
+    {
+        int s = s0;
+        bool rec = false;
+        const int npass = (rstages > 0 ? 1 : 0) + nfull;
+        for (int i = 0; i < npass && i <= k; ++i) {
+            const int c = (rstages > 0 && i == 0) ? rstages : cfull;
+            rec = s + c - 1 > SMAX;
+            if (rec) s = 0;
+            s += c;
+        }
+        return rec;
+    }
 };
 
 // ---- policy plumbing for code that is templated on the arithmetic policy ------------------------------------------
@@ -567,7 +594,9 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
 
 // v[r] holds NTT value idx_out(t,r) on entry (U64: [0,4q); F64: |v| < 2^45) and coefficient idx_nat(t,r) on exit,
 // NOT yet canonical (apply A::inv_finish).  itw[idx] = tw[idx]^-1 (same indexing); N^-1 folded in the last stage.
-template <int LOGN, class A>
+// S0: the values on entry are bounded by 0.5 q * 2^S0 in magnitude (FP64 policy; InvRecentre): 2 behind the first stage of a
+// split inverse (sums of two canonical words), 1 for canonical words
+template <int LOGN, class A, int S0 = 2>
 __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A::V *lds,
                                              const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
 {
@@ -575,7 +604,7 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
     typename A::TW w[15];
     if (C::R > 0) {
         load_rem_tw<LOGN, A>(w, itw, t, 1);
-        A::inv_pass_begin(v, cx);
+        if (InvRecentre::at(C::R, C::FP, 4, S0, 0)) A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = C::R - 1; u >= 0; --u) {
             const int half = C::G >> (u + 1);
@@ -611,7 +640,7 @@ __device__ __forceinline__ void ntt_inv_core(typename A::V (&v)[16], typename A:
 #pragma unroll
             for (int e = 0; e < 16; ++e) v[e] = lds[pb + ps * e];
         }
-        A::inv_pass_begin(v, cx);
+        if (InvRecentre::at(C::R, C::FP, 4, S0, (C::R > 0 ? 1 : 0) + (C::FP - 1 - p))) A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
             const int half = 8 >> u;

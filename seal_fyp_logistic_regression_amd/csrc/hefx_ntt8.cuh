@@ -185,13 +185,15 @@ __device__ __forceinline__ void load_inv_first_tw8(typename A::TW (&w)[7], const
 }
 
 // `w` = load_inv_first_tw8 on entry
-template <int LOGN, class A>
+// S0 (InvRecentre, hefx_ntt.cuh): on entry |v| <= 0.5 q * 2^S0 -- 3 behind the two stages the quarter loaders apply
+// (sums of four canonical words)
+template <int LOGN, class A, int S0 = 3>
 __device__ __forceinline__ void ntt8_inv_core_w(typename A::V (&v)[8], typename A::TW (&w)[7], typename A::V *lds,
                                                 const typename A::TW *__restrict__ itw, const typename A::Ctx &cx, int t)
 {
     using C = Ntt8Cfg<LOGN>;
     if (C::R > 0) {
-        A::inv_pass_begin(v, cx);
+        if (InvRecentre::at(C::R, C::FP, 3, S0, 0)) A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = C::R - 1; u >= 0; --u) {
             const int half = C::G >> (u + 1);
@@ -226,7 +228,7 @@ __device__ __forceinline__ void ntt8_inv_core_w(typename A::V (&v)[8], typename 
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] = lds[pb + ps * e];
         }
-        A::inv_pass_begin(v, cx);
+        if (InvRecentre::at(C::R, C::FP, 3, S0, (C::R > 0 ? 1 : 0) + (C::FP - 1 - p))) A::inv_pass_begin(v, cx);
 #pragma unroll
         for (int u = 2; u >= 0; --u) {
             const int half = 4 >> u;

@@ -47,7 +47,7 @@ def test_bench_two_ranks_one_json_line_and_sharded_bits():
     sharded leg over gloo, because RCCL wants a device per rank): rc 0, exactly ONE line on stdout and it is the JSON,
     n_gpus == 2, and the diagonal-sharded Linear_Transform_Plain has the bits of the serial one."""
     r, _ = _bench({}, "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "512", "--cpu-seconds", "0", "--lt", "16",
-                  "--secondary", "C2", "--sustain", "0.3", "--key-per-item", "0", "--lt-direct", "0")
+                  "--secondary", "C2", "--sustain", "0.3", "--key-per-item", "0", "--lt-direct", "0")  # (secondary: single-rank runs only)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout[-2000:]
@@ -57,9 +57,9 @@ def test_bench_two_ranks_one_json_line_and_sharded_bits():
     d16 = line["lt_sharded"]["d16"]
     assert d16["bits_equal_serial"] is True and d16["decrypts_to_Mv"] is True
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
-    # round 5: the N = 8192 leg, the longer second pass and the library hashes ride in the same line
-    c2 = line["secondary"]["C2"]
-    assert c2["verified"] is True and c2["value"] > 0 and 0 < c2["roofline"]["frac"] < 1, c2
+    # round 5: the longer second pass and the library hashes ride in the same line; the other parameter sets only in
+    # single-rank runs (tests/test_gpu_round5.py)
+    assert line["secondary"] == {}
     assert line["sustained"]["steps"] >= 2 and line["sustained"]["value"] > 0
     assert len(line["libhefx_sha16"]) == 16 and len(line["csrc_sha16"]) == 16 and line["rescale_mode"] in ("floor", "round")
 

@@ -105,7 +105,7 @@ def test_bench_world1_over_nccl_takes_the_collective_branches():
     env = _clean_env(HEFX_BENCH_FORCE_PG="1", HEFX_BENCH_C_ABI_COMM="1")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "512",
                         "--cpu-seconds", "0", "--lt", "16", "--lt-direct", "0", "--key-per-item", "0", "--variant-keys", "0",
-                        "--stream-keys", "0", "--secondary", "", "--sustain", "0.3"], cwd=ROOT, env=env,
+                        "--stream-keys", "0", "--secondary", "C2", "--sustain", "0.3"], cwd=ROOT, env=env,
                        capture_output=True, text=True, timeout=840)
     assert r.returncode == 0, r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
@@ -116,6 +116,10 @@ def test_bench_world1_over_nccl_takes_the_collective_branches():
     assert d16["bits_equal_serial"] is True and d16["decrypts_to_Mv"] is True, d16
     assert d16["c_abi_allreduce"].get("bits_equal_serial") is True, d16
     assert d16["key_switches_executed"] <= d16["key_switches_serial"] and d16["key_switches_executed"] > 0
+    # the N = 8192 leg (north_star's other degree), the sustained pass and the hashes ride in the single-rank line
+    c2 = line["secondary"]["C2"]
+    assert c2["verified"] is True and c2["value"] > 0 and 0 < c2["roofline"]["frac"] < 1, c2
+    assert line["sustained"]["steps"] >= 2 and len(line["csrc_sha16"]) == 16 and line["rescale_mode"] in ("floor", "round")
 
 
 def test_ks_stats_count_the_naf_forest_and_hoisting():

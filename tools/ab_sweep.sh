@@ -7,6 +7,6 @@ for tag in "$@"; do
   if [ "$tag" = default ]; then lib=""; else lib="$PWD/build/libhefx_$tag.so"; fi
   printf "%s %-4s %-10s " $round $set "$tag"
   case $set in C3) b=4608;; C2) b=9216;; C4) b=2304;; C5) b=2304;; esac
-  HEFX_LIB=$lib python bench.py --set $set --batch $b --steps 20 --warmup 2 --cpu-seconds 0 --lt= --variant-keys $([ $set = C3 ] && echo 16 || echo 0) 2>/dev/null | python -c "
-import sys,json; d=json.loads(sys.stdin.readline()); k=d['roofline']['kernel_avg_us']; print(round(d['value']), d['verified'], {n[3:-7]: round(v) for n,v in k.items() if v}, (d.get('variants') or {}).get('distinct_keys_16',{}).get('value'))"
+  HEFX_LIB=$lib python bench.py --set $set --batch $b --steps 30 --warmup 3 --quick 2>/dev/null | python -c "
+import sys,json; d=json.loads(sys.stdin.readline()); k=d['roofline']['kernel_avg_us']; print(round(d['value']), d['verified'], {n[3:-7]: round(v) for n,v in k.items() if v})"
 done; done; done
