@@ -57,7 +57,40 @@ class _DeviceWords:
                                          "strides": None}
 
 
-_comm_decisions = {}  # (id(group), world) -> bool: the collective outcome of the handshake below, equal on every rank
+# (id(group object), world) -> (weak reference to the group object, bool): the collective outcome of the handshake below,
+# equal on every rank.  The weak reference guards against an id reused by a later group: an entry counts only
+# while it still points at the very object it was made for.
+_comm_decisions = {}
+
+
+def _group_object(group):
+    import torch.distributed as dist
+    return group if group is not None else dist.group.WORLD
+
+
+def _decision_get(group, world):
+    import weakref
+    g = _group_object(group)
+    ent = _comm_decisions.get((id(g), world))
+    if ent is None:
+        return None
+    if ent[0]() is not g:  # the id belongs to another (dead) group's entry
+        del _comm_decisions[(id(g), world)]
+        return None
+    return ent[1]
+
+
+def _decision_set(group, world, ok):
+    import weakref
+    g = _group_object(group)
+    try:
+        _comm_decisions[(id(g), world)] = (weakref.ref(g), ok)
+    except TypeError:  # not weak-referenceable: decide anew next time (one small all-reduce)
+        pass
+
+
+def _decision_drop(group, world):
+    _comm_decisions.pop((id(_group_object(group)), world), None)
 
 
 def _all_true(flag: bool, group, backend: str) -> bool:
@@ -80,15 +113,15 @@ def _engine_comm_ready(ev: Evaluator, group, world: int) -> bool:
     backend = dist.get_backend(group)
     if ENGINE_COMM == "off" or not (ENGINE_COMM == "on" or backend == "nccl"):
         return False
-    key = (id(group), world)
-    if key in _comm_decisions:
-        if _comm_decisions[key] and eng.comm_world != world:  # destroyed behind our back (bench.py's opt-in leg does)
-            del _comm_decisions[key]
+    known = _decision_get(group, world)
+    if known is not None:
+        if known and eng.comm_world != world:  # destroyed behind our back (bench.py's opt-in leg does)
+            _decision_drop(group, world)
         else:
-            return _comm_decisions[key]
+            return known
     have = eng.comm_world == world
     if _all_true(have, group, backend):
-        _comm_decisions[key] = True
+        _decision_set(group, world, True)
         return True
     ok = _all_true(have or eng.comm_world == 0, group, backend)
     err = None
@@ -108,7 +141,7 @@ def _engine_comm_ready(ev: Evaluator, group, world: int) -> bool:
     if not ok and ENGINE_COMM == "on":
         raise RuntimeError("HEFX_ENGINE_COMM=on, but the engine communicator could not be attached on every rank"
                            + (f": {err!r}" if err else ""))
-    _comm_decisions[key] = ok
+    _decision_set(group, world, ok)
     return ok
 
 

@@ -204,3 +204,23 @@ def test_sharded_sparse_matrix_product_world2(n):
         for step1, (same, val) in zip((False, True), res):
             assert same, f"rank {rank}, shard_step1={step1}: sharded sparse product differs from the serial one"
             assert val
+
+
+def test_comm_decision_cache_is_tied_to_the_group_object():
+    """the collective 'engine communicator or torch' decision is cached per group -- keyed on the object's id, so an
+    entry must stop counting once that id belongs to another object."""
+    from seal_fyp_logistic_regression_amd import parallel as par
+
+    class Group:
+        pass
+
+    a = Group()
+    par._decision_set(a, 2, True)
+    assert par._decision_get(a, 2) is True and par._decision_get(a, 4) is None
+    b = Group()  # an id reused after `a` died: modelled by moving a's entry under b's id
+    par._comm_decisions[(id(b), 2)] = par._comm_decisions.pop((id(a), 2))
+    assert par._decision_get(b, 2) is None and (id(b), 2) not in par._comm_decisions
+    par._decision_set(b, 2, False)
+    assert par._decision_get(b, 2) is False
+    par._decision_drop(b, 2)
+    assert par._decision_get(b, 2) is None
