@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libckks_oracle.so")
+# HEFX_ORACLE_SO: another build of the same source (tests/test_oracle_sanitizers.py loads the ASan + UBSan one)
+_SO = os.environ.get("HEFX_ORACLE_SO") or os.path.join(_HERE, "libckks_oracle.so")
 
 u64p = np.ctypeslib.ndpointer(dtype=np.uint64, flags="C_CONTIGUOUS")
 u32p = np.ctypeslib.ndpointer(dtype=np.uint32, flags="C_CONTIGUOUS")
@@ -22,6 +23,8 @@ i32p = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
 
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "ckks_oracle.c")
+    if os.environ.get("HEFX_ORACLE_SO"):
+        return _SO
     if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
         subprocess.check_call(["make", "-s", "-C", _HERE, "libckks_oracle.so"])
     return _SO
