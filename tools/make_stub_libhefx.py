@@ -34,6 +34,8 @@ src.append("}")
 open(os.path.join(out, "stub.cpp"), "w").write("\n".join(src) + "\n")
 inc = os.path.join(root, "include")
 subprocess.check_call(["g++", "-O2", "-shared", "-fPIC", "-I" + inc, os.path.join(out, "stub.cpp"), "-o", os.path.join(out, "libhefx.so")])
-subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-w", "-I" + inc, os.path.join(root, "drivers", "lt_host_probe.cpp"), "-o",
+# --sanitize: the probe (i.e. include/seal/seal.h's host side) under AddressSanitizer + UBSan, for tests/test_shim_host_cpu.py
+san = ["-O1", "-fsanitize=address,undefined", "-fno-omit-frame-pointer"] if "--sanitize" in sys.argv[1:] else ["-O2"]
+subprocess.check_call(["g++"] + san + ["-g", "-std=c++17", "-w", "-I" + inc, os.path.join(root, "drivers", "lt_host_probe.cpp"), "-o",
                        os.path.join(out, "probe"), "-L" + out, "-lhefx", "-Wl,-rpath,$ORIGIN"])
 print(f"{len(seen)} entries stubbed; run {os.path.join(out, 'probe')} [d=1000] [reps=5]")
