@@ -276,7 +276,8 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         ct = enc.encrypt(encoder.encode(v, scale))
 
         def timed(fn):
-            r = fn()  # warm-up (scratch growth, Galois tables, pool slabs)
+            for _ in range(3):  # warm-up: scratch growth, Galois tables, pool slabs -- and the clock, which the host-side key
+                r = fn()        # generation before this leg lets drop (one 2 ms call does not bring it back)
             eng.sync()
             if use_pg:
                 dist.barrier()
@@ -349,7 +350,8 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
         diags = encoder.encode_many(list(alg.get_all_diagonals(M)), scale)
         ct = enc.encrypt(encoder.encode(v, scale))
         gk_direct = kg.galois_keys([-d] + list(range(1, d)))
-        r = alg.linear_transform_plain(ev, ct, diags, gk_direct)
+        for _ in range(3):  # (warm-up as above: 4 GB of keys were just generated with the GPU mostly idle)
+            r = alg.linear_transform_plain(ev, ct, diags, gk_direct)
         eng.sync()
         ts = []
         for _ in range(reps):
@@ -835,7 +837,7 @@ def main():
         dog.daemon = True
         dog.start()
         try:
-            lt = lt_sharded_bench(local_rank, world, dims, reps=3, direct_d=args.lt_direct, use_pg=use_pg)
+            lt = lt_sharded_bench(local_rank, world, dims, reps=10, direct_d=args.lt_direct, use_pg=use_pg)
         except Exception as ex:
             lt = {"error": repr(ex)[:400]}
         dog.cancel()
