@@ -274,7 +274,11 @@ int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, 
  *      rotate_internal (direct key when (key_elts, keys) holds it, else the NAF terms of the step); the NAF plans,
  *      their de-duplication, batching and the fusion of each plan's last key switch with multiply_plain happen
  *      behind the call.  Bit-identical to the op-by-op sequence.  HEFX_ERR_INVALID "Galois key not present" when a
- *      needed element is missing; the caller checks plaintext zero-ness (transparent result) beforehand. */
+ *      needed element is missing; the caller checks plaintext zero-ness (transparent result) beforehand.
+ *      A forest of 96 or more key switches below ct_new (the reference's default keys from d ~ 70 on) is dealt onto TWO
+ *      lanes -- the subtrees of about half the nodes each, every depth of a lane one batch on a stream of its own, the
+ *      second lane in the back half of the scratch buffer -- joined before the final sum; same words (HEFX_LT_LANES=0: one
+ *      lane). */
 int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
                                 const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                 const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
@@ -290,7 +294,11 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
  *      hefx_apply_galois_batch / hefx_rotate_multiply_plain_batch / hefx_apply_galois_add_batch take this path by
  *      themselves when a batch of more than 32 items rotates at most n/3 distinct ciphertexts, so this entry is now the
  *      same computation with a stricter contract (one source, which no output may alias) -- kept for its callers.
- *      d_pts may be NULL (no fused multiply_plain). */
+ *      d_pts may be NULL (no fused multiply_plain).
+ *      FIRST USE of a Galois element on this path builds its flip-mask table (k rows of N words, kept for the context's
+ *      life within HEFX_FLIPW_MB, default 8 GiB; beyond it the batch runs unhoisted, same words): one hipMalloc and one
+ *      hipStreamSynchronize on the caller's stream -- the one place where an asynchronous entry waits on the host, and a
+ *      reason not to capture the first call of a new element into a graph.  Later calls find the table. */
 int hefx_rotate_hoisted_batch(hefx_context *ctx, int L, const uint64_t *d_ct_in, int n, const uint32_t *galois_elts,
                               const uint64_t *const *d_keys, const uint64_t *const *d_pts, uint64_t *const *d_ct_out,
                               void *stream);

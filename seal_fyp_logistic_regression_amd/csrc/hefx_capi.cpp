@@ -1105,8 +1105,11 @@ static int ks_small_shape(int n, int L)
 static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *const *ct_in, const uint32_t *elts,
                   const uint64_t *const *keys, const uint64_t *single_key, const uint64_t *const *pts,
                   uint64_t *const *ct_out, void *stream, bool hoist = false, const uint64_t *const *acc_in = nullptr,
-                  uint64_t *const *acc_out = nullptr, bool trusted = false)
+                  uint64_t *const *acc_out = nullptr, bool trusted = false, size_t scratch_off = 0)
 {
+    // scratch_off (words; engine-internal, hefx_linear_transform_plain's second lane): this call's scratch starts there, so that
+    // it may run on another stream beside a call that uses the front of the buffer.  One chunk only (the chunk pipeline's
+    // internal streams and scratch halves are one set per context), and the caller has sized the buffer for both.
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
     if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
@@ -1277,7 +1280,9 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // (a hoisted chunk's fallback runs the digit transforms of all its items at once: x for the whole chunk)
     const size_t x_words = ks_x_words(c, L, fused || share || sub > cmax ? cmax : sub);
     const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
-    if (int rc = ensure_scratch(c, half_words * (size_t)ns)) return rc;
+    if (scratch_off && (two || c->scratch_words < scratch_off + half_words))
+        return fail(HEFX_ERR_INVALID, "internal: a laned key-switch batch must be one chunk inside the pre-sized scratch");
+    if (int rc = ensure_scratch(c, scratch_off + half_words * (size_t)ns)) return rc;
     hipStream_t user = (hipStream_t)stream;
     if (two) {
         HIPCHK(hipEventRecord(c->ev_fork, user));
@@ -1304,7 +1309,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
         KsItem *hb = c->h_items + (size_t)slot * KS_MAX_CHUNK, *db = c->d_items + (size_t)slot * KS_MAX_CHUNK;
         KsScratch S{};
-        S.d = c->scratch + (two ? (size_t)(ci % ns) * half_words : 0);
+        S.d = c->scratch + scratch_off + (two ? (size_t)(ci % ns) * half_words : 0);
         S.acc = S.d + (size_t)cnt * L * N;
         S.u = S.acc + (size_t)cnt * 2 * (L + 1) * N;
         S.x = S.u + (size_t)cnt * 2 * N;
@@ -2300,13 +2305,82 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     // overlap on the two internal streams, and half the latency-bound calls at the shallow depths (round 5; until then two
     // batches per depth.  HEFX_LT_MERGE=0 restores that).  A null entry of `pp` = no fused product for that item.
     static const bool merge = !(getenv("HEFX_LT_MERGE") && atoi(getenv("HEFX_LT_MERGE")) == 0);
-    for (int depth = 0; depth < max_depth; ++depth)
-        for (int pass = 0; pass < (merge ? 1 : 2); ++pass) {
+    // TWO LANES (round 5) for a forest of chains (the reference's default keys: every rotation a NAF chain, five depths at
+    // d = 512): a depth is a barrier only inside a subtree, so the subtrees below ct_new are dealt onto two lanes of about
+    // equal size and each lane's depth batches run on a stream of their own -- the ramp and tail of one lane's five launches
+    // under the other lane's wide ones.  Each lane's batches must be single chunks (ks_run's chunk pipeline is one per
+    // context); lane 1 works in the back half of the scratch buffer, sized here for both.  HEFX_LT_LANES=0 switches it off.
+    // From 96 nodes on (HEFX_LT_LANES_MIN): a small forest is a handful of latency-bound batches, and launches on two hardware
+    // queues start later than on one (N = 8192, d = 10: 0.23 against 0.20 ms; d = 100: 0.55 against 0.57; d = 1000: 2.37
+    // against 2.48; C3, d = 512: 3.25 against 3.43 -- profiles/r05/lt_naf_two_lanes.txt).
+    static const bool lanes_ok = !(getenv("HEFX_LT_LANES") && atoi(getenv("HEFX_LT_LANES")) == 0);
+    static const size_t lanes_min = getenv("HEFX_LT_LANES_MIN") ? (size_t)atoi(getenv("HEFX_LT_LANES_MIN")) : 96;
+    std::vector<uint8_t> lane_of(nodes.size(), 0);
+    size_t lane1_off = 0;
+    if (lanes_ok && merge && max_depth >= 2 && nodes.size() >= lanes_min && c->use_streams && !c->profiling && c->sub <= 0 &&
+        !c->fused) {
+        std::vector<int> root_of(nodes.size()), weight(nodes.size(), 0);
+        for (size_t i = 0; i < nodes.size(); ++i) {  // (a node's parent precedes it)
+            root_of[i] = nodes[i].parent < 0 ? (int)i : root_of[(size_t)nodes[i].parent];
+            ++weight[(size_t)root_of[i]];
+        }
+        std::vector<int> roots;
+        for (size_t i = 0; i < nodes.size(); ++i)
+            if (nodes[i].parent < 0) roots.push_back((int)i);
+        std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return weight[(size_t)a] > weight[(size_t)b]; });
+        int load[2] = {0, 0};
+        std::vector<uint8_t> root_lane(nodes.size(), 0);
+        for (int r : roots) {
+            const int ln = load[1] < load[0] ? 1 : 0;
+            root_lane[(size_t)r] = (uint8_t)ln;
+            load[ln] += weight[(size_t)r];
+        }
+        std::vector<int> cnt((size_t)max_depth * 2, 0);
+        int widest = 0;
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            lane_of[i] = root_lane[(size_t)root_of[i]];
+            widest = std::max(widest, ++cnt[(size_t)nodes[i].depth * 2 + lane_of[i]]);
+        }
+        int chunk = c->chunk;  // ks_run's rule for the items of one launch sequence
+        if (chunk <= 0) {
+            chunk = (int)(((size_t)1 << 30) / (ks_words_per_item(c, L) * sizeof(u64)));
+            const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
+            chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
+        }
+        if (load[0] && load[1] && widest <= chunk) {
+            lane1_off = ks_words_per_item(c, L) * (size_t)widest + ks_x_words(c, L, widest);
+            if (int rc = ensure_scratch(c, 2 * lane1_off)) return rc;
+            // whatever a lane's batches would build on first use is built HERE, on the caller's stream, before the lanes
+            // part: the flip-mask tables of exact hoisting (their transform borrows the front of the scratch at N = 32768)
+            // and the gather tables -- inside the lanes every lookup then hits
+            std::vector<uint32_t> all_elts(nodes.size());
+            for (size_t i = 0; i < nodes.size(); ++i) all_elts[i] = nodes[i].elt;
+            std::sort(all_elts.begin(), all_elts.end());
+            all_elts.erase(std::unique(all_elts.begin(), all_elts.end()), all_elts.end());
+            std::vector<const u64 *> unused;
+            if (int rc = ensure_flipw(c, all_elts.data(), (int)all_elts.size(), (hipStream_t)stream, unused)) return rc;
+            for (uint32_t e : all_elts) {
+                const uint32_t *perm = nullptr;
+                if (int rc = get_perm(c, e, &perm)) return rc;
+            }
+        } else
+            std::fill(lane_of.begin(), lane_of.end(), 0);
+    }
+    const int nlanes = lane1_off ? 2 : 1;
+    hipStream_t lane_stream[2] = {(hipStream_t)stream, c->streams[0]};
+    if (nlanes == 2) {
+        HIPCHK(hipEventRecord(c->ev_fork, lane_stream[0]));
+        HIPCHK(hipStreamWaitEvent(lane_stream[1], c->ev_fork, 0));
+    }
+    int lane_rc = HEFX_OK;
+    for (int depth = 0; depth < max_depth && lane_rc == HEFX_OK; ++depth)
+        for (int pass = 0; pass < (merge ? nlanes : 2) && lane_rc == HEFX_OK; ++pass) {
+            const int ln = nlanes == 2 ? pass : 0;
             in.clear(), kk.clear(), pp.clear(), oo.clear(), ee.clear();
             bool any_pt = false;
             for (size_t i = 0; i < nodes.size(); ++i) {
                 const Node &nd = nodes[i];
-                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0))) continue;
+                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0)) || (nlanes == 2 && lane_of[i] != ln)) continue;
                 in.push_back(node_ptr(nd.parent));
                 ee.push_back(nd.elt);
                 kk.push_back(K.at(nd.elt));
@@ -2317,10 +2391,16 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
             if (in.empty()) continue;
             // (node buffers are this context's workspace, disjoint by construction; the diagonals are the caller's and
             // cannot reach into it: the batch is trusted)
-            if (int rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr,
-                                any_pt ? pp.data() : nullptr, oo.data(), stream, hoisted, nullptr, nullptr, true))
-                return rc;
+            // (an error leaves the loop, not the function: lane 1's stream must be joined to the caller's whatever happened)
+            lane_rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr, any_pt ? pp.data() : nullptr,
+                             oo.data(), lane_stream[ln], hoisted, nullptr, nullptr, true, ln ? lane1_off : 0);
         }
+    if (nlanes == 2) {
+        hipError_t ej = hipEventRecord(c->ev_join[0], lane_stream[1]);
+        if (ej == hipSuccess) ej = hipStreamWaitEvent(lane_stream[0], c->ev_join[0], 0);
+        if (ej != hipSuccess && lane_rc == HEFX_OK) lane_rc = hipfail(ej, "join of the linear transform's second lane");
+    }
+    if (lane_rc != HEFX_OK) return lane_rc;
     lap("key-switch batches submitted");
     // ---- out = add_many(res)               (helper.h:259)
     std::vector<const uint64_t *> res(d);

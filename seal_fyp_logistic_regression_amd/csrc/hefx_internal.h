@@ -88,7 +88,7 @@ __device__ __forceinline__ uint32_t galois_index(uint32_t i, uint32_t elt, int l
 // copy per chunk), so a chunk is not limited by the 4 KiB kernel-argument segment.
 constexpr int KS_MAX_CHUNK = 1024;   // descriptor-ring slot size: the most items HEFX_CHUNK (or the size rule) may ask for
 constexpr int KS_AUTO_CHUNK = 256;  // what the size rule asks for at most (N >= 16384: 256 items fill the chip in whole rounds)
-constexpr int KS_RING = 8;
+constexpr int KS_RING = 32;  // (a laned linear transform submits ten batches and a pointer table per call: with 8 slots the host waited on its own call)
 
 // Scratch layout for one chunk of key-switch items, in units of N words per item.  The Galois-permuted inputs are
 // never materialised: the inverse transform of the digits, the own-prime term of the key MAC and the add-in of the

@@ -197,3 +197,55 @@ def test_chain_refuses_null_and_overlapping_outputs_before_anything_runs():
             t = o.apply_galois(t, elt, o.uniform(k, 2 * L, 3).reshape(L, 2, k, N))
             a = o.add(a, t)
         assert (outs[i].download() == t).all() and (accs[i].download() == a).all()
+
+
+@pytest.mark.gpu
+def test_naf_forest_on_two_lanes_bit_exact_vs_op_by_op_and_vs_one_lane():
+    """hefx_linear_transform_plain with the reference's default keys deals the subtrees of a large NAF forest onto two lanes
+    (two streams, two halves of the scratch buffer).  d = 160 at N = 4096 is well above the 96-node bound: the words must
+    be those of the oracle-backed twin's op-by-op loop (helper.h:237-262), and those of the same call with HEFX_LT_LANES=0."""
+    import hashlib
+    import numpy as np
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from tests.test_gpu_composites import both, bits, decode
+    d = 160
+    rng = np.random.default_rng(160)
+    M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
+
+    def run(e):
+        scale = 2.0 ** 30
+        diags = [e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)]
+        ct = e["enc"].encrypt(e["encoder"].encode(v, scale))
+        eng = getattr(e["ctx"].backend, "engine", None)
+        s0 = eng.ks_stats() if eng else None
+        out = alg.linear_transform_plain(e["ev"], ct, diags, e["gk"])
+        return out, (eng.ks_stats()["chunks"] - s0["chunks"]) if eng else None
+
+    r = both(4096, [50, 30, 30, 50], run)
+    (eg, (ag, seqs)), (eo, (ao, _)) = r["gpu"], r["oracle"]
+    assert (bits(eg, ag) == bits(eo, ao)).all()
+    assert np.allclose(decode(eg, ag, d), M @ v, atol=0.5)  # scale 2^30 and ~400 key switches: value check only loosely
+    digest = hashlib.sha256(np.ascontiguousarray(bits(eg, ag)).tobytes()).hexdigest()
+    code = textwrap.dedent(f"""
+        import hashlib, sys
+        import numpy as np
+        sys.path.insert(0, {ROOT!r})
+        from seal_fyp_logistic_regression_amd import algorithms as alg
+        from tests.test_gpu_composites import make, bits
+        d = {d}
+        rng = np.random.default_rng(160)
+        M, v = rng.standard_normal((d, d)), rng.standard_normal(d)
+        e = make(4096, [50, 30, 30, 50], "gpu")
+        diags = [e["encoder"].encode(x, 2.0 ** 30) for x in alg.get_all_diagonals(M)]
+        ct = e["enc"].encrypt(e["encoder"].encode(v, 2.0 ** 30))
+        eng = e["ctx"].backend.engine
+        s0 = eng.ks_stats()["chunks"]
+        out = alg.linear_transform_plain(e["ev"], ct, diags, e["gk"])
+        print(hashlib.sha256(np.ascontiguousarray(bits(e, out)).tobytes()).hexdigest(), eng.ks_stats()["chunks"] - s0)
+    """)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HEFX_LT_LANES="0"), capture_output=True, text=True,
+                       timeout=600, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-3000:]
+    one_lane_digest, one_lane_seqs = p.stdout.split()[-2:]
+    assert one_lane_digest == digest
+    assert seqs > int(one_lane_seqs), (seqs, one_lane_seqs)  # the laned call really submitted more (smaller) launch sequences
