@@ -2315,8 +2315,13 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     // against 2.48; C3, d = 512: 3.25 against 3.43 -- profiles/r05/lt_naf_two_lanes.txt).
     static const bool lanes_ok = !(getenv("HEFX_LT_LANES") && atoi(getenv("HEFX_LT_LANES")) == 0);
     static const size_t lanes_min = getenv("HEFX_LT_LANES_MIN") ? (size_t)atoi(getenv("HEFX_LT_LANES_MIN")) : 96;
+    constexpr int MAXL = 1 + hefx_context::MAX_STREAMS;
+    // (HEFX_LT_NLANES: three lanes measure like two -- 3.31-3.33 against 3.29-3.33 ms at C3, d = 512; 2.30 both at N = 8192, d = 1000)
+    static const int want_env = getenv("HEFX_LT_NLANES") ? atoi(getenv("HEFX_LT_NLANES")) : 2;
+    const int want = std::max(2, std::min(want_env, 1 + c->nstreams));
     std::vector<uint8_t> lane_of(nodes.size(), 0);
     size_t lane1_off = 0;
+    int nlanes = 1;
     if (lanes_ok && merge && max_depth >= 2 && nodes.size() >= lanes_min && c->use_streams && !c->profiling && c->sub <= 0 &&
         !c->fused) {
         std::vector<int> root_of(nodes.size()), weight(nodes.size(), 0);
@@ -2328,28 +2333,33 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         for (size_t i = 0; i < nodes.size(); ++i)
             if (nodes[i].parent < 0) roots.push_back((int)i);
         std::stable_sort(roots.begin(), roots.end(), [&](int a, int b) { return weight[(size_t)a] > weight[(size_t)b]; });
-        int load[2] = {0, 0};
+        int load[MAXL] = {};
         std::vector<uint8_t> root_lane(nodes.size(), 0);
-        for (int r : roots) {
-            const int ln = load[1] < load[0] ? 1 : 0;
+        for (int r : roots) {  // heaviest subtree first, each onto the lightest lane
+            int ln = 0;
+            for (int q = 1; q < want; ++q)
+                if (load[q] < load[ln]) ln = q;
             root_lane[(size_t)r] = (uint8_t)ln;
             load[ln] += weight[(size_t)r];
         }
-        std::vector<int> cnt((size_t)max_depth * 2, 0);
+        std::vector<int> cnt((size_t)max_depth * MAXL, 0);
         int widest = 0;
         for (size_t i = 0; i < nodes.size(); ++i) {
             lane_of[i] = root_lane[(size_t)root_of[i]];
-            widest = std::max(widest, ++cnt[(size_t)nodes[i].depth * 2 + lane_of[i]]);
+            widest = std::max(widest, ++cnt[(size_t)nodes[i].depth * MAXL + lane_of[i]]);
         }
+        bool all_loaded = true;
+        for (int q = 0; q < want; ++q) all_loaded = all_loaded && load[q] > 0;
         int chunk = c->chunk;  // ks_run's rule for the items of one launch sequence
         if (chunk <= 0) {
             chunk = (int)(((size_t)1 << 30) / (ks_words_per_item(c, L) * sizeof(u64)));
             const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
             chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
         }
-        if (load[0] && load[1] && widest <= chunk) {
+        if (all_loaded && widest <= chunk) {
             lane1_off = ks_words_per_item(c, L) * (size_t)widest + ks_x_words(c, L, widest);
-            if (int rc = ensure_scratch(c, 2 * lane1_off)) return rc;
+            if (int rc = ensure_scratch(c, (size_t)want * lane1_off)) return rc;
+            nlanes = want;
             // whatever a lane's batches would build on first use is built HERE, on the caller's stream, before the lanes
             // part: the flip-mask tables of exact hoisting (their transform borrows the front of the scratch at N = 32768)
             // and the gather tables -- inside the lanes every lookup then hits
@@ -2366,21 +2376,21 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         } else
             std::fill(lane_of.begin(), lane_of.end(), 0);
     }
-    const int nlanes = lane1_off ? 2 : 1;
-    hipStream_t lane_stream[2] = {(hipStream_t)stream, c->streams[0]};
-    if (nlanes == 2) {
+    hipStream_t lane_stream[MAXL] = {(hipStream_t)stream};
+    for (int q = 1; q < MAXL; ++q) lane_stream[q] = c->streams[q - 1];
+    if (nlanes > 1) {
         HIPCHK(hipEventRecord(c->ev_fork, lane_stream[0]));
-        HIPCHK(hipStreamWaitEvent(lane_stream[1], c->ev_fork, 0));
+        for (int q = 1; q < nlanes; ++q) HIPCHK(hipStreamWaitEvent(lane_stream[q], c->ev_fork, 0));
     }
     int lane_rc = HEFX_OK;
     for (int depth = 0; depth < max_depth && lane_rc == HEFX_OK; ++depth)
         for (int pass = 0; pass < (merge ? nlanes : 2) && lane_rc == HEFX_OK; ++pass) {
-            const int ln = nlanes == 2 ? pass : 0;
+            const int ln = nlanes > 1 ? pass : 0;
             in.clear(), kk.clear(), pp.clear(), oo.clear(), ee.clear();
             bool any_pt = false;
             for (size_t i = 0; i < nodes.size(); ++i) {
                 const Node &nd = nodes[i];
-                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0)) || (nlanes == 2 && lane_of[i] != ln)) continue;
+                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0)) || (nlanes > 1 && lane_of[i] != ln)) continue;
                 in.push_back(node_ptr(nd.parent));
                 ee.push_back(nd.elt);
                 kk.push_back(K.at(nd.elt));
@@ -2393,12 +2403,12 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
             // cannot reach into it: the batch is trusted)
             // (an error leaves the loop, not the function: lane 1's stream must be joined to the caller's whatever happened)
             lane_rc = ks_run(c, L, (int)in.size(), false, in.data(), ee.data(), kk.data(), nullptr, any_pt ? pp.data() : nullptr,
-                             oo.data(), lane_stream[ln], hoisted, nullptr, nullptr, true, ln ? lane1_off : 0);
+                             oo.data(), lane_stream[ln], hoisted, nullptr, nullptr, true, (size_t)ln * lane1_off);
         }
-    if (nlanes == 2) {
-        hipError_t ej = hipEventRecord(c->ev_join[0], lane_stream[1]);
-        if (ej == hipSuccess) ej = hipStreamWaitEvent(lane_stream[0], c->ev_join[0], 0);
-        if (ej != hipSuccess && lane_rc == HEFX_OK) lane_rc = hipfail(ej, "join of the linear transform's second lane");
+    for (int q = 1; q < nlanes; ++q) {
+        hipError_t ej = hipEventRecord(c->ev_join[q - 1], lane_stream[q]);
+        if (ej == hipSuccess) ej = hipStreamWaitEvent(lane_stream[0], c->ev_join[q - 1], 0);
+        if (ej != hipSuccess && lane_rc == HEFX_OK) lane_rc = hipfail(ej, "join of the linear transform's lanes");
     }
     if (lane_rc != HEFX_OK) return lane_rc;
     lap("key-switch batches submitted");
