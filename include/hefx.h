@@ -184,7 +184,9 @@ int hefx_apply_galois_batch(hefx_context *ctx, int L, int n, const uint64_t *con
                             uint64_t *const *d_ct_out, void *stream);
 /* the hot-loop body of Linear_Transform_Plain (helper.h:255-256): out_i = rotate(ct_i, elt_i) (.) pt_i with
  * a directly keyed element, multiply_plain fused into the key-switch epilogue.  This is the unit
- * BASELINE.json's metric counts. */
+ * BASELINE.json's metric counts.  A NULL d_pts[i] makes item i a plain rotation (no product): the rotations of one
+ * dependency depth of a NAF forest -- some end in a diagonal product, some only feed deeper rotations -- go out as ONE
+ * batch that way (the C++ shim's recorder does). */
 int hefx_rotate_multiply_plain_batch(hefx_context *ctx, int L, int n, const uint64_t *const *d_ct_in,
                                      const uint32_t *galois_elts, const uint64_t *const *d_keys,
                                      const uint64_t *const *d_pts, uint64_t *const *d_ct_out, void *stream);

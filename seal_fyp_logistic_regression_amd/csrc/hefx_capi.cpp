@@ -158,6 +158,7 @@ struct hefx_context {
     // scratch (grown on demand, reused across calls so it stays cache-resident)
     u64 *scratch = nullptr;
     size_t scratch_words = 0;
+    std::vector<u64 *> scratch_retired;  // outgrown scratch buffers, freed with the context (ensure_scratch)
     int chunk = 0;  // items per launch sequence; 0 = sized from the scratch budget (HEFX_CHUNK overrides)
     int *d_flag = nullptr;  // [0] transparent count, [1 + i] "non-zero seen beyond c0" of ciphertext i of the call
     int flag_cap = 1 + 4096;
@@ -225,17 +226,44 @@ struct hefx_context {
     uint64_t stat_ks_items = 0, stat_ks_hoisted = 0, stat_ks_chunks = 0, stat_ks_calls = 0;
 };
 
+// The scratch buffer grows geometrically and WITHOUT waiting for the device: a buffer that became too small is retired, not
+// freed (hipFree synchronises the device, and work already submitted may still be using it) -- retired buffers go with
+// the context, and being a geometric series they hold less than the live one.  (Until round 5 every growth was
+// hipDeviceSynchronize + hipFree + hipMalloc, ~0.2 ms of host time each plus the drained queue: a one-shot caller like the
+// reference's linear_transformation.cpp, whose batches get wider level by level, paid it three times per transform --
+// 0.6 of the 1.3 ms its d = 100 case spent submitting.)
 static int ensure_scratch(hefx_context *c, size_t words)
 {
     if (c->scratch_words >= words) return HEFX_OK;
-    if (c->scratch) {
+    static const bool dbg = getenv("HEFX_DEBUG") && atoi(getenv("HEFX_DEBUG")) >= 2;
+    const auto t0 = std::chrono::steady_clock::now();
+    // (at least 64 MiB, so that a caller that starts small does not climb a ladder of tiny buffers)
+    const size_t want = std::max(std::max(words, 2 * c->scratch_words), (size_t)8 << 20);
+    u64 *fresh = nullptr;
+    hipError_t e = hipMalloc((void **)&fresh, want * sizeof(u64));
+    size_t got = want;
+    if (e != hipSuccess && want > words) {  // no room for the generous size: the exact one
+        (void)hipGetLastError();
+        got = words;
+        e = hipMalloc((void **)&fresh, got * sizeof(u64));
+    }
+    if (e != hipSuccess) {  // still none: give back what is retired (which needs the device idle), then once more
+        (void)hipGetLastError();
         HIPCHK(hipDeviceSynchronize());
-        HIPCHK(hipFree(c->scratch));
+        for (u64 *p : c->scratch_retired) (void)hipFree(p);
+        c->scratch_retired.clear();
+        if (c->scratch) (void)hipFree(c->scratch);
+    for (u64 *p : c->scratch_retired) (void)hipFree(p);
         c->scratch = nullptr;
         c->scratch_words = 0;
+        HIPCHK(hipMalloc((void **)&fresh, got * sizeof(u64)));
     }
-    HIPCHK(hipMalloc((void **)&c->scratch, words * sizeof(u64)));
-    c->scratch_words = words;
+    if (c->scratch) c->scratch_retired.push_back(c->scratch);
+    c->scratch = fresh;
+    c->scratch_words = got;
+    if (dbg)
+        fprintf(stderr, "[hefx] scratch grown to %zu MiB in %.1f us (%zu retired buffers)\n", (got * sizeof(u64)) >> 20,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), c->scratch_retired.size());
     return HEFX_OK;
 }
 
@@ -565,8 +593,9 @@ extern "C" int hefx_malloc(hefx_context *c, size_t bytes, void **d_ptr)
         {   // a slab normally takes ~20 us; a driver that makes the caller wait (seen on this pool: seconds, with the process
             // asleep) is worth a line on stderr -- it is not the engine's time
             const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_alloc).count();
-            if (ms > 100.0)
-                fprintf(stderr, "[hefx] hipMalloc of a %zu MiB pool slab took %.0f ms (pool holds %zu MiB in %zu slabs)\n",
+            static const bool dbg = getenv("HEFX_DEBUG") && atoi(getenv("HEFX_DEBUG")) >= 2;
+            if (ms > 100.0 || dbg)
+                fprintf(stderr, "[hefx] hipMalloc of a %zu MiB pool slab took %.3f ms (pool holds %zu MiB in %zu slabs)\n",
                         ((size_t)n * rounded) >> 20, ms, c->pool_cached >> 20, c->pool_slabs.size());
         }
         if (e != hipSuccess) {  // out of memory: give back what is parked, then ask for a single block
@@ -1111,6 +1140,10 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // it may run on another stream beside a call that uses the front of the buffer.  One chunk only (the chunk pipeline's
     // internal streams and scratch halves are one set per context), and the caller has sized the buffer for both.
     CTXCHK(c);
+    static const bool ksdbg = getenv("HEFX_DEBUG") && atoi(getenv("HEFX_DEBUG")) >= 2;  // host time of the call's phases
+    const auto ks_t0 = std::chrono::steady_clock::now();
+    auto ks_us = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ks_t0).count(); };
+    double t_valid = 0, t_tables = 0;
     if (int rc = check_ks_level(c, L)) return rc;
     if (n < 1 || !ct_in || !ct_out) return fail(HEFX_ERR_INVALID, "bad key-switch batch arguments");
     if (!relin && (!elts || !keys)) return fail(HEFX_ERR_INVALID, "missing Galois elements / keys");
@@ -1233,6 +1266,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
             if (meets(ct_in[j], j, false) || meets(acc_in[j], j, true))
                 return fail(HEFX_ERR_INVALID, "accumulate: an input overlaps another item's sum");
     }
+    t_valid = ks_us();
     // The items of a batch are independent, so they are PROCESSED grouped by key (stable order inside a group): items
     // that share a Galois key become neighbours -- the MAC loads the key once for two neighbours, and a chunk touches
     // few keys, which then stay in L2 / Infinity Cache.  A linear transform's rotations arrive step by step, i.e. keys
@@ -1280,6 +1314,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // (a hoisted chunk's fallback runs the digit transforms of all its items at once: x for the whole chunk)
     const size_t x_words = ks_x_words(c, L, fused || share || sub > cmax ? cmax : sub);
     const size_t half_words = per * (size_t)cmax + x_words + (any_alias ? (size_t)cmax * 2 * L * c->n : 0);
+    t_tables = ks_us();
     if (scratch_off && (two || c->scratch_words < scratch_off + half_words))
         return fail(HEFX_ERR_INVALID, "internal: a laned key-switch batch must be one chunk inside the pre-sized scratch");
     if (int rc = ensure_scratch(c, scratch_off + half_words * (size_t)ns)) return rc;
@@ -1406,6 +1441,9 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         }
     }
     if (herr != hipSuccess) return hipfail(herr, hwhat);
+    if (ksdbg)
+        fprintf(stderr, "[hefx] ks_run n=%d L=%d chunks=%d share=%d: checks %.1f us, order/tables %.1f us, scratch+submit %.1f us\n", n, L,
+                nchunks, (int)share, t_valid, t_tables - t_valid, ks_us() - t_tables);
     return HEFX_OK;
 }
 
@@ -1425,8 +1463,7 @@ extern "C" int hefx_rotate_multiply_plain_batch(hefx_context *c, int L, int n, c
                                                 const uint64_t *const *pts, uint64_t *const *ct_out, void *stream)
 {
     if (!pts) return fail(HEFX_ERR_INVALID, "missing plaintexts");
-    for (int i = 0; i < n; ++i)
-        if (!pts[i]) return fail(HEFX_ERR_INVALID, "null plaintext pointer in batch");
+    // (a null ENTRY is a plain rotation: hefx.h)
     return ks_run(c, L, n, false, ct_in, elts, keys, nullptr, pts, ct_out, stream);
 }
 extern "C" int hefx_apply_galois_add_batch(hefx_context *c, int L, int n, const uint64_t *const *ct_in,
