@@ -182,6 +182,12 @@ struct hefx_context {
     hipEvent_t stage_ev[STAGE_SLOTS] = {};
     bool stage_busy[STAGE_SLOTS] = {};
     unsigned stage_next = 0;
+    // ... and two pinned buffers for large encodes (many vectors in one call), alternating
+    double *h_big[2] = {};
+    size_t big_cap[2] = {};
+    hipEvent_t big_ev[2] = {};
+    bool big_busy[2] = {};
+    unsigned big_next = 0;
     NoiseTable noise{};  // inverse-CDF thresholds of the clipped normal (sigma 3.2, bound 19.2, truncated)
     // linear-transform workspace (rotated copies and products of one hefx_linear_transform_plain call)
     u64 *lt_ws = nullptr;
@@ -524,6 +530,10 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->d_enc_tables) (void)hipFree(c->d_enc_tables);
     if (c->d_vals) (void)hipFree(c->d_vals);
     if (c->h_stage) (void)hipHostFree(c->h_stage);
+    for (int b = 0; b < 2; ++b) {
+        if (c->h_big[b]) (void)hipHostFree(c->h_big[b]);
+        if (c->big_ev[b]) (void)hipEventDestroy(c->big_ev[b]);
+    }
     for (auto &ev : c->stage_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (c->lt_ws) (void)hipFree(c->lt_ws);
@@ -2099,9 +2109,28 @@ extern "C" int hefx_ckks_encode(hefx_context *c, int L, const double *h_re, cons
         HIPCHK(hipEventRecord(c->stage_ev[slot], s));
         c->stage_busy[slot] = true;
     } else {
-        HIPCHK(hipMemcpyAsync(c->d_vals, h_re, nv * sizeof(double), hipMemcpyHostToDevice, s));
-        if (h_im) HIPCHK(hipMemcpyAsync(c->d_vals + nv, h_im, nv * sizeof(double), hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));  // the host arrays may be transient
+        // large: through one of two pinned buffers sized for the call (grown on demand), so that the call neither copies
+        // from pageable memory (1-3 GB/s through the runtime's bounce buffers) nor waits for the STREAM -- until round 5
+        // it ended in hipStreamSynchronize because the host arrays may be transient, i.e. every batch of encodes waited
+        // for all the work queued before it: 30 ms per 546 one-hot masks inside the reference's prediction loop
+        // (logistic_regression_ckks.cpp:222-225), a quarter of that driver's run
+        const unsigned b = c->big_next++ & 1u;
+        if (c->big_busy[b]) HIPCHK(hipEventSynchronize(c->big_ev[b]));
+        c->big_busy[b] = false;
+        if (c->big_cap[b] < need) {
+            if (c->h_big[b]) HIPCHK(hipHostFree(c->h_big[b]));
+            c->h_big[b] = nullptr;
+            c->big_cap[b] = 0;
+            HIPCHK(hipHostMalloc((void **)&c->h_big[b], need * sizeof(double), hipHostMallocDefault));
+            c->big_cap[b] = need;
+        }
+        if (!c->big_ev[b]) HIPCHK(hipEventCreateWithFlags(&c->big_ev[b], hipEventDisableTiming));
+        double *h = c->h_big[b];
+        memcpy(h, h_re, nv * sizeof(double));
+        if (h_im) memcpy(h + nv, h_im, nv * sizeof(double));
+        HIPCHK(hipMemcpyAsync(c->d_vals, h, need * sizeof(double), hipMemcpyHostToDevice, s));
+        HIPCHK(hipEventRecord(c->big_ev[b], s));
+        c->big_busy[b] = true;
     }
     if (c->logn == 15) {  // the N = 32768 transform is out of place: coefficients into scratch, NTT into d_out
         const size_t words = (size_t)count * L * c->n;
