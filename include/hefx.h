@@ -346,7 +346,9 @@ int hefx_linear_transform_plain_bsgs(hefx_context *ctx, int L, const uint64_t *d
  *      `count` vectors of `nvalues` <= N/2 slot values each (host arrays; h_im may be NULL for real vectors) ->
  *      `count` contiguous NTT-form plaintexts of L rows at d_out.  Canonical embedding with slot i <-> root
  *      zeta^(3^i), coefficients rounded half away from zero like std::round.  Floating point: matches any other
- *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit. */
+ *      correct encoder to +-1 in a small fraction of coefficients, not bit for bit.
+ *      The host arrays are copied into pinned staging memory before the call returns (they may be transient); the call
+ *      does not wait for the stream -- at most for an earlier encode that still owns the staging buffer it wants. */
 int hefx_ckks_encode(hefx_context *ctx, int L, const double *h_re, const double *h_im, int nvalues, int count,
                      double scale, uint64_t *d_out, void *stream);
 /* the same for `count` vectors whose plaintexts are separately allocated: d_outs[i] receives vector i (host arrays as
