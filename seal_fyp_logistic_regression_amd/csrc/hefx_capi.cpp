@@ -238,13 +238,13 @@ struct hefx_context {
 // hipDeviceSynchronize + hipFree + hipMalloc, ~0.2 ms of host time each plus the drained queue: a one-shot caller like the
 // reference's linear_transformation.cpp, whose batches get wider level by level, paid it three times per transform --
 // 0.6 of the 1.3 ms its d = 100 case spent submitting.)
-static int ensure_scratch(hefx_context *c, size_t words)
+// (the key switch's scratch and the linear transforms' node buffers grow this way)
+static int grow_retiring(hefx_context *c, u64 **buf, size_t *cap, size_t words, size_t floor_words, const char *what)
 {
-    if (c->scratch_words >= words) return HEFX_OK;
+    if (*cap >= words) return HEFX_OK;
     static const bool dbg = getenv("HEFX_DEBUG") && atoi(getenv("HEFX_DEBUG")) >= 2;
     const auto t0 = std::chrono::steady_clock::now();
-    // (at least 64 MiB, so that a caller that starts small does not climb a ladder of tiny buffers)
-    const size_t want = std::max(std::max(words, 2 * c->scratch_words), (size_t)8 << 20);
+    const size_t want = std::max(std::max(words, 2 * *cap), floor_words);
     u64 *fresh = nullptr;
     hipError_t e = hipMalloc((void **)&fresh, want * sizeof(u64));
     size_t got = want;
@@ -258,19 +258,23 @@ static int ensure_scratch(hefx_context *c, size_t words)
         HIPCHK(hipDeviceSynchronize());
         for (u64 *p : c->scratch_retired) (void)hipFree(p);
         c->scratch_retired.clear();
-        if (c->scratch) (void)hipFree(c->scratch);
-    for (u64 *p : c->scratch_retired) (void)hipFree(p);
-        c->scratch = nullptr;
-        c->scratch_words = 0;
+        if (*buf) (void)hipFree(*buf);
+        *buf = nullptr;
+        *cap = 0;
         HIPCHK(hipMalloc((void **)&fresh, got * sizeof(u64)));
     }
-    if (c->scratch) c->scratch_retired.push_back(c->scratch);
-    c->scratch = fresh;
-    c->scratch_words = got;
+    if (*buf) c->scratch_retired.push_back(*buf);
+    *buf = fresh;
+    *cap = got;
     if (dbg)
-        fprintf(stderr, "[hefx] scratch grown to %zu MiB in %.1f us (%zu retired buffers)\n", (got * sizeof(u64)) >> 20,
+        fprintf(stderr, "[hefx] %s grown to %zu MiB in %.1f us (%zu retired buffers)\n", what, (got * sizeof(u64)) >> 20,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), c->scratch_retired.size());
     return HEFX_OK;
+}
+static int ensure_scratch(hefx_context *c, size_t words)
+{
+    // (at least 64 MiB, so that a caller that starts small does not climb a ladder of tiny buffers)
+    return grow_retiring(c, &c->scratch, &c->scratch_words, words, (size_t)8 << 20, "scratch");
 }
 
 extern "C" const char *hefx_last_error(void) { return g_err.c_str(); }
@@ -2296,14 +2300,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     }
     lap("key map + rotation plans");
     // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
-    if (c->lt_head_cap < 4 * ctw) {
-        HIPCHK(hipDeviceSynchronize());
-        if (c->lt_head) HIPCHK(hipFree(c->lt_head));
-        c->lt_head = nullptr;
-        c->lt_head_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lt_head, 4 * ctw * sizeof(u64)));
-        c->lt_head_cap = 4 * ctw;
-    }
+    if (int rc = grow_retiring(c, &c->lt_head, &c->lt_head_cap, 4 * ctw, 0, "linear-transform head")) return rc;
     uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_head), *pong = ping + ctw, *ct_new = pong + ctw, *prod0 = ct_new + ctw;
     // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247): launched FIRST, so that the planning below (0.1 ms of host
     // time at d = 512) runs beside it instead of in front of it
@@ -2352,14 +2349,7 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     lap("forest");
     // ---- workspace, part 2: one ciphertext per node
     const size_t need = ctw * nodes.size();
-    if (c->lt_cap < need) {
-        HIPCHK(hipDeviceSynchronize());
-        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
-        c->lt_ws = nullptr;
-        c->lt_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lt_ws, (need ? need : 1) * sizeof(u64)));
-        c->lt_cap = need;
-    }
+    if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, need ? need : 1, 0, "linear-transform nodes")) return rc;
     uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
     auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
     // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth   (helper.h:252-257)
@@ -2545,14 +2535,7 @@ extern "C" int hefx_linear_transform_plain_bsgs(hefx_context *c, int L, const ui
     }
     // ---- workspace: ping / pong / ct_new, n1-1 baby rotations, n2 inner sums, n2-1 rotated inner sums
     const size_t need = ctw * (size_t)(3 + (n1 - 1) + n2 + (n2 - 1));
-    if (c->lt_cap < need) {
-        HIPCHK(hipDeviceSynchronize());
-        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
-        c->lt_ws = nullptr;
-        c->lt_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lt_ws, need * sizeof(u64)));
-        c->lt_cap = need;
-    }
+    if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, need, 0, "linear-transform workspace")) return rc;
     uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw,
              *rots = ct_new + ctw, *inner = rots + (size_t)(n1 - 1) * ctw, *grot = inner + (size_t)n2 * ctw;
     // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247)
@@ -2635,14 +2618,7 @@ static int lt2_impl(hefx_context *c, int L, const uint64_t *ct, int d, int nterm
     std::vector<KsItem> items((size_t)nterms + 1);  // [0]: source (ct_new); [1..nterms-1]: rotations; last: the mod-down
     // ---- workspace
     const size_t ws_words = 4 * ctw + (size_t)chunks * (2 * (size_t)k + L) * N + (items.size() * sizeof(KsItem) + 7) / 8;
-    if (c->lt_cap < ws_words) {
-        HIPCHK(hipDeviceSynchronize());
-        if (c->lt_ws) HIPCHK(hipFree(c->lt_ws));
-        c->lt_ws = nullptr;
-        c->lt_cap = 0;
-        HIPCHK(hipMalloc((void **)&c->lt_ws, ws_words * sizeof(u64)));
-        c->lt_cap = ws_words;
-    }
+    if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, ws_words, 0, "linear-transform workspace")) return rc;
     uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_ws), *pong = ping + ctw, *ct_new = pong + ctw, *cbuf = ct_new + ctw;
     u64 *partial_s = reinterpret_cast<u64 *>(cbuf + ctw), *partial_c0 = partial_s + (size_t)chunks * 2 * k * N;
     KsItem *d_items = reinterpret_cast<KsItem *>(partial_c0 + (size_t)chunks * L * N);
