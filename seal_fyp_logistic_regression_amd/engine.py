@@ -310,11 +310,12 @@ class Engine:
         return outs, acc_outs
 
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs=None, stream=None):
+        """out_i = rotate(ct_i, elt_i) (.) pt_i; a None entry of `pts` makes item i a plain rotation (hefx.h)"""
         n = len(cts)
         outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
         capi.check(capi.lib().hefx_rotate_multiply_plain_batch(
             self._h, L, n, capi.ptr_array([c.ptr for c in cts]), capi.u32_array(elts),
-            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([p.ptr for p in pts]),
+            capi.ptr_array([k.ptr for k in keys]), capi.ptr_array([p.ptr if p is not None else 0 for p in pts]),
             capi.ptr_array([o.ptr for o in outs]), stream))
         return outs
 

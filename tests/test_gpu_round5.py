@@ -249,3 +249,40 @@ def test_naf_forest_on_two_lanes_bit_exact_vs_op_by_op_and_vs_one_lane():
     one_lane_digest, one_lane_seqs = p.stdout.split()[-2:]
     assert one_lane_digest == digest
     assert seqs > int(one_lane_seqs), (seqs, one_lane_seqs)  # the laned call really submitted more (smaller) launch sequences
+
+
+@pytest.mark.gpu
+def test_mixed_batch_of_plain_and_fused_rotations_and_growing_batches_without_a_sync():
+    """(1) hefx_rotate_multiply_plain_batch with NULL plaintext entries: the items without a plaintext are plain rotations, the
+    others fused products -- one batch, the oracle's words for both kinds (what the C++ shim submits per forest depth).
+    (2) batches that grow from 3 to 300 items submitted back to back WITHOUT a synchronisation in between: the scratch buffer is
+    re-allocated under work in flight (outgrown buffers are retired, not freed) -- every output must still be the oracle's."""
+    import numpy as np
+    from oracle import oracle as O
+    from seal_fyp_logistic_regression_amd import Engine
+    N, primes = 4096, O.coeff_modulus_create(4096, [50, 30, 30, 50])
+    L = len(primes) - 1
+    o, e = O.Oracle(N, primes), Engine(N, primes, device=0)
+    key = o.uniform(len(primes), 2 * L, 3).reshape(L, 2, len(primes), N)
+    dkey = e.to_device(key)
+    elts = [O.galois_elt_from_step(N, s) for s in (1, -1, 2, 5)]
+    cts = [o.uniform(L, 2, 100 + i) for i in range(300)]
+    pts = [o.uniform(L, 1, 500 + i)[0] for i in range(300)]
+    dcts, dpts = [e.to_device(c) for c in cts], [e.to_device(p) for p in pts]
+    # (1) forty items, every third one without a plaintext
+    n = 40
+    mix = [None if i % 3 == 0 else dpts[i] for i in range(n)]
+    outs = e.rotate_multiply_plain_batch(L, dcts[:n], [elts[i % 4] for i in range(n)], [dkey] * n, mix)
+    for i in range(n):
+        want = o.apply_galois(cts[i], elts[i % 4], key) if i % 3 == 0 else o.rotate_mulplain(cts[i], elts[i % 4], key, pts[i])
+        assert (outs[i].download() == want).all(), i
+    # (2) a fresh engine (small scratch), growing batches, no sync until the end
+    e2 = Engine(N, primes, device=0)
+    dkey2 = e2.to_device(key)
+    d2c, d2p = [e2.to_device(c) for c in cts], [e2.to_device(p) for p in pts]
+    results = []
+    for n in (3, 20, 70, 300):
+        results.append((n, e2.rotate_multiply_plain_batch(L, d2c[:n], [elts[i % 4] for i in range(n)], [dkey2] * n, d2p[:n])))
+    for n, outs in results:
+        for i in sorted(set([0, 1, n // 2, n - 1])):
+            assert (outs[i].download() == o.rotate_mulplain(cts[i], elts[i % 4], key, pts[i])).all(), (n, i)
