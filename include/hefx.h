@@ -285,6 +285,19 @@ int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, 
                                 const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                 const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
 
+/* ---- A FOREST of rotations in one call: node i rotates the result of node parent[i] (parent[i] < 0: the ciphertext
+ *      d_ext_in[i]) by galois_elts[i] with d_keys[i] into d_out[i]; a non-NULL d_pts[i] multiplies the rotated ciphertext
+ *      by that plaintext in the key-switch epilogue (d_pts itself may be NULL: no products).  parent[i] < i.  This is what
+ *      Evaluator::rotate_vector's NAF chains of a linear transform add up to once shared prefixes are computed once
+ *      (helper.h:252-257 with the default keys of linear_transformation2.cpp:239): the nodes run depth by depth -- one
+ *      batch per depth and lane, the subtrees of a forest of 96 nodes or more on two lanes, wide one-source depths
+ *      exactly hoisted -- the schedule hefx_linear_transform_plain uses behind its own planner.  Every node's words are
+ *      those of hefx_apply_galois / hefx_rotate_multiply_plain_batch on the same operands.  Outputs must be pairwise
+ *      disjoint and disjoint from every external input and plaintext (HEFX_ERR_INVALID before anything runs). */
+int hefx_apply_galois_forest(hefx_context *ctx, int L, int n, const int32_t *parent, const uint64_t *const *d_ext_in,
+                             const uint32_t *galois_elts, const uint64_t *const *d_keys, const uint64_t *const *d_pts,
+                             uint64_t *const *d_out, void *stream);
+
 /* ---- HOISTED rotations: n rotations of ONE ciphertext share its digit decomposition -- INTT and
  *      digit x modulus NTTs of c1 once, each rotation gathers them through its Galois table, multiplies with its key and
  *      mods down: (L+1)(L+2) -> 2 + 2L transforms per rotation.  EXACT since round 4, i.e. the same words as

@@ -71,6 +71,7 @@ _SIGS = {
     "hefx_rotate_multiply_plain_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_apply_galois_add_batch": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _pp, _vp]),
     "hefx_rotate_add_chain": (_i, [_vp, _i, _i, _pp, C.POINTER(_u32), _pp, _pp, _pp, _pp, _i, _vp]),
+    "hefx_apply_galois_forest": (_i, [_vp, _i, _i, C.POINTER(C.c_int32), _pp, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_relinearize": (_i, [_vp, _i, _vp, _vp, _vp, _vp]),
     "hefx_relinearize_batch": (_i, [_vp, _i, _i, _pp, _vp, _pp, _vp]),
     "hefx_rescale_to_next": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),

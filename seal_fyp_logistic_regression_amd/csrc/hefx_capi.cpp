@@ -2266,93 +2266,19 @@ const char *lt_plan(int steps, size_t n, const LtKeys &keys, std::vector<uint32_
 }
 }  // namespace
 
-static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint64_t *const *diag_pts, int nkeys,
-                   const uint32_t *key_elts, const uint64_t *const *keys, uint64_t *out, void *stream, bool hoisted)
+// A forest of key switches: node i rotates its parent's result (parent < 0: the external ciphertext in_ext) by `elt` with
+// `key`, optionally multiplied by the plaintext `pt` in the epilogue, into `out`.  Parents precede their children; `depth`
+// is the distance to the root.  Runs depth by depth, the subtrees on lanes (below).  Shared by hefx_linear_transform_plain
+// and hefx_apply_galois_forest.
+struct ForestNode {
+    int parent;
+    uint32_t elt;
+    int depth;
+    const uint64_t *in_ext, *key, *pt;
+    uint64_t *out;
+};
+static int run_forest(hefx_context *c, int L, const std::vector<ForestNode> &nodes, int max_depth, void *stream, bool hoisted)
 {
-    CTXCHK(c);
-    if (int rc = check_ks_level(c, L)) return rc;
-    if (!ct || !out || d < 1 || !diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
-        return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
-    for (int i = 0; i < d; ++i)
-        if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
-    static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
-    auto t_last = std::chrono::steady_clock::now();
-    auto lap = [&](const char *what) {
-        if (!dbg) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
-        t_last = now;
-    };
-    LtKeys K;
-    for (int i = 0; i < nkeys; ++i)
-        if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
-    K.set(nkeys, key_elts, keys);
-    const size_t N = c->n, ctw = 2 * (size_t)L * N;
-    std::vector<uint32_t> first;
-    if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
-    // a missing key or a step too large must be reported before anything runs, like the op-by-op sequence would: plans of
-    // every step first (cheap), the node forest later -- while the GPU is already at work on ct_new
-    std::vector<std::vector<uint32_t>> plans((size_t)d);
-    for (int l = 1; l < d; ++l) {
-        if (const char *err = lt_plan(l, N, K, plans[(size_t)l])) return fail(HEFX_ERR_INVALID, err);
-        if (hoisted && plans[(size_t)l].size() != 1)
-            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
-    }
-    lap("key map + rotation plans");
-    // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
-    if (int rc = grow_retiring(c, &c->lt_head, &c->lt_head_cap, 4 * ctw, 0, "linear-transform head")) return rc;
-    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_head), *pong = ping + ctw, *ct_new = pong + ctw, *prod0 = ct_new + ctw;
-    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247): launched FIRST, so that the planning below (0.1 ms of host
-    // time at d = 512) runs beside it instead of in front of it
-    const uint64_t *src = ct;
-    for (size_t t = 0; t < first.size(); ++t) {
-        uint64_t *dst = (t & 1) ? pong : ping;
-        const uint64_t *key = K.at(first[t]);
-        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
-        src = dst;
-    }
-    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
-    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
-    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
-    lap("head submitted (rotate -d, add, product 0)");
-    // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
-    struct Node {
-        int parent;  // -1: ct_new
-        uint32_t elt;
-        int fused;   // diagonal index whose plaintext multiplies this node's output, or -1
-        int depth;
-    };
-    std::vector<Node> nodes;
-    // (parent node + 1, element, fused diagonal + 1) packed into 64 bits: parent < 2^22 nodes, element < 2^16 (N <= 32768),
-    // diagonal < 2^22
-    std::unordered_map<uint64_t, int> index;
-    index.reserve((size_t)d * 2);
-    nodes.reserve((size_t)d * 2);
-    std::vector<int> leaf(d, -1);
-    int max_depth = 0;
-    for (int l = 1; l < d; ++l) {
-        const std::vector<uint32_t> &plan = plans[(size_t)l];
-        int cur = -1;
-        for (size_t t = 0; t < plan.size(); ++t) {
-            const int fused = t + 1 == plan.size() ? l : -1;
-            const uint64_t key = ((uint64_t)(cur + 1) << 42) | ((uint64_t)plan[t] << 24) | (uint64_t)(fused + 1);
-            auto it = index.find(key);
-            if (it == index.end()) {
-                nodes.push_back(Node{cur, plan[t], fused, (int)t});
-                it = index.emplace(key, (int)nodes.size() - 1).first;
-                if ((int)t + 1 > max_depth) max_depth = (int)t + 1;
-            }
-            cur = it->second;
-        }
-        leaf[l] = cur;
-    }
-    lap("forest");
-    // ---- workspace, part 2: one ciphertext per node
-    const size_t need = ctw * nodes.size();
-    if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, need ? need : 1, 0, "linear-transform nodes")) return rc;
-    uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
-    auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
-    // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth   (helper.h:252-257)
     std::vector<const uint64_t *> in, kk, pp;
     std::vector<uint64_t *> oo;
     std::vector<uint32_t> ee;
@@ -2445,14 +2371,14 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
             in.clear(), kk.clear(), pp.clear(), oo.clear(), ee.clear();
             bool any_pt = false;
             for (size_t i = 0; i < nodes.size(); ++i) {
-                const Node &nd = nodes[i];
-                if (nd.depth != depth || (!merge && (nd.fused >= 0) != (pass != 0)) || (nlanes > 1 && lane_of[i] != ln)) continue;
-                in.push_back(node_ptr(nd.parent));
+                const ForestNode &nd = nodes[i];
+                if (nd.depth != depth || (!merge && (nd.pt != nullptr) != (pass != 0)) || (nlanes > 1 && lane_of[i] != ln)) continue;
+                in.push_back((nd.parent < 0 ? nd.in_ext : nodes[(size_t)nd.parent].out));
                 ee.push_back(nd.elt);
-                kk.push_back(K.at(nd.elt));
-                oo.push_back(node_ptr((int)i));
-                pp.push_back(nd.fused >= 0 ? diag_pts[nd.fused] : nullptr);
-                any_pt = any_pt || nd.fused >= 0;
+                kk.push_back(nd.key);
+                oo.push_back(nd.out);
+                pp.push_back(nd.pt);
+                any_pt = any_pt || nd.pt != nullptr;
             }
             if (in.empty()) continue;
             // (node buffers are this context's workspace, disjoint by construction; the diagonals are the caller's and
@@ -2466,7 +2392,105 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         if (ej == hipSuccess) ej = hipStreamWaitEvent(lane_stream[0], c->ev_join[q - 1], 0);
         if (ej != hipSuccess && lane_rc == HEFX_OK) lane_rc = hipfail(ej, "join of the linear transform's lanes");
     }
-    if (lane_rc != HEFX_OK) return lane_rc;
+    return lane_rc;
+}
+
+static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint64_t *const *diag_pts, int nkeys,
+                   const uint32_t *key_elts, const uint64_t *const *keys, uint64_t *out, void *stream, bool hoisted)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (!ct || !out || d < 1 || !diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+        return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    for (int i = 0; i < d; ++i)
+        if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
+    static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!dbg) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        t_last = now;
+    };
+    LtKeys K;
+    for (int i = 0; i < nkeys; ++i)
+        if (!keys[i]) return fail(HEFX_ERR_INVALID, "null Galois key");
+    K.set(nkeys, key_elts, keys);
+    const size_t N = c->n, ctw = 2 * (size_t)L * N;
+    std::vector<uint32_t> first;
+    if (const char *err = lt_plan(-d, N, K, first)) return fail(HEFX_ERR_INVALID, err);
+    // a missing key or a step too large must be reported before anything runs, like the op-by-op sequence would: plans of
+    // every step first (cheap), the node forest later -- while the GPU is already at work on ct_new
+    std::vector<std::vector<uint32_t>> plans((size_t)d);
+    for (int l = 1; l < d; ++l) {
+        if (const char *err = lt_plan(l, N, K, plans[(size_t)l])) return fail(HEFX_ERR_INVALID, err);
+        if (hoisted && plans[(size_t)l].size() != 1)
+            return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
+    }
+    lap("key map + rotation plans");
+    // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
+    if (int rc = grow_retiring(c, &c->lt_head, &c->lt_head_cap, 4 * ctw, 0, "linear-transform head")) return rc;
+    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_head), *pong = ping + ctw, *ct_new = pong + ctw, *prod0 = ct_new + ctw;
+    // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247): launched FIRST, so that the planning below (0.1 ms of host
+    // time at d = 512) runs beside it instead of in front of it
+    const uint64_t *src = ct;
+    for (size_t t = 0; t < first.size(); ++t) {
+        uint64_t *dst = (t & 1) ? pong : ping;
+        const uint64_t *key = K.at(first[t]);
+        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
+        src = dst;
+    }
+    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
+    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
+    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
+    lap("head submitted (rotate -d, add, product 0)");
+    // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
+    struct Node {
+        int parent;  // -1: ct_new
+        uint32_t elt;
+        int fused;   // diagonal index whose plaintext multiplies this node's output, or -1
+        int depth;
+    };
+    std::vector<Node> nodes;
+    // (parent node + 1, element, fused diagonal + 1) packed into 64 bits: parent < 2^22 nodes, element < 2^16 (N <= 32768),
+    // diagonal < 2^22
+    std::unordered_map<uint64_t, int> index;
+    index.reserve((size_t)d * 2);
+    nodes.reserve((size_t)d * 2);
+    std::vector<int> leaf(d, -1);
+    int max_depth = 0;
+    for (int l = 1; l < d; ++l) {
+        const std::vector<uint32_t> &plan = plans[(size_t)l];
+        int cur = -1;
+        for (size_t t = 0; t < plan.size(); ++t) {
+            const int fused = t + 1 == plan.size() ? l : -1;
+            const uint64_t key = ((uint64_t)(cur + 1) << 42) | ((uint64_t)plan[t] << 24) | (uint64_t)(fused + 1);
+            auto it = index.find(key);
+            if (it == index.end()) {
+                nodes.push_back(Node{cur, plan[t], fused, (int)t});
+                it = index.emplace(key, (int)nodes.size() - 1).first;
+                if ((int)t + 1 > max_depth) max_depth = (int)t + 1;
+            }
+            cur = it->second;
+        }
+        leaf[l] = cur;
+    }
+    lap("forest");
+    // ---- workspace, part 2: one ciphertext per node
+    const size_t need = ctw * nodes.size();
+    if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, need ? need : 1, 0, "linear-transform nodes")) return rc;
+    uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
+    auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
+    // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth on lanes   (helper.h:252-257; run_forest)
+    {
+        std::vector<ForestNode> fn(nodes.size());
+        for (size_t i = 0; i < nodes.size(); ++i) {
+            const Node &nd = nodes[i];
+            fn[i] = ForestNode{nd.parent, nd.elt, nd.depth, ct_new, K.at(nd.elt), nd.fused >= 0 ? diag_pts[nd.fused] : nullptr,
+                               node_ptr((int)i)};
+        }
+        if (int rc = run_forest(c, L, fn, max_depth, stream, hoisted)) return rc;
+    }
     lap("key-switch batches submitted");
     // ---- out = add_many(res)               (helper.h:259)
     std::vector<const uint64_t *> res(d);
@@ -2475,6 +2499,47 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
     const int rc = hefx_add_many(c, L, 2, d, res.data(), out, stream);
     lap("add_many submitted");
     return rc;
+}
+
+extern "C" int hefx_apply_galois_forest(hefx_context *c, int L, int n, const int32_t *parent, const uint64_t *const *ext_in,
+                                        const uint32_t *elts, const uint64_t *const *keys, const uint64_t *const *pts,
+                                        uint64_t *const *outs, void *stream)
+{
+    CTXCHK(c);
+    if (int rc = check_ks_level(c, L)) return rc;
+    if (n < 1 || !parent || !ext_in || !elts || !keys || !outs) return fail(HEFX_ERR_INVALID, "bad rotation-forest arguments");
+    std::vector<ForestNode> nodes((size_t)n);
+    int max_depth = 0;
+    for (int i = 0; i < n; ++i) {
+        if (parent[i] >= i) return fail(HEFX_ERR_INVALID, "rotation forest: a node's parent must precede it");
+        if (!keys[i] || !outs[i] || (parent[i] < 0 && !ext_in[i])) return fail(HEFX_ERR_INVALID, "null pointer in rotation forest");
+        const int depth = parent[i] < 0 ? 0 : nodes[(size_t)parent[i]].depth + 1;
+        nodes[(size_t)i] = ForestNode{parent[i] < 0 ? -1 : parent[i], elts[i], depth, parent[i] < 0 ? ext_in[i] : nullptr, keys[i],
+                                      pts ? pts[i] : nullptr, outs[i]};
+        max_depth = std::max(max_depth, depth + 1);
+    }
+    // outputs pairwise disjoint; no external input or plaintext reaches into an output (byte ranges, like ks_run's check --
+    // the per-depth batches below then run trusted)
+    {
+        const size_t row = (size_t)c->n * sizeof(u64), out_b = 2 * (size_t)L * row, pt_b = (size_t)L * row;
+        std::vector<uintptr_t> o((size_t)n);
+        for (int i = 0; i < n; ++i) o[(size_t)i] = (uintptr_t)outs[i];
+        std::sort(o.begin(), o.end());
+        for (int i = 1; i < n; ++i)
+            if (o[(size_t)i - 1] + out_b > o[(size_t)i]) return fail(HEFX_ERR_INVALID, "rotation forest: two nodes write overlapping outputs");
+        auto hits = [&](const void *p, size_t bytes) {
+            const uintptr_t a = (uintptr_t)p;
+            auto it = std::upper_bound(o.begin(), o.end(), a);
+            if (it != o.begin() && *(it - 1) + out_b > a) return true;
+            return it != o.end() && *it < a + bytes;
+        };
+        for (int i = 0; i < n; ++i) {
+            if (parent[i] < 0 && hits(ext_in[i], out_b))
+                return fail(HEFX_ERR_INVALID, "rotation forest: an external input overlaps a node's output");
+            if (pts && pts[i] && hits(pts[i], pt_b)) return fail(HEFX_ERR_INVALID, "rotation forest: a plaintext overlaps a node's output");
+        }
+    }
+    return run_forest(c, L, nodes, max_depth, stream, false);
 }
 
 extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_t *ct, int d,

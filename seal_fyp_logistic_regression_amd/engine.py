@@ -309,6 +309,19 @@ class Engine:
             capi.ptr_array([a.ptr for a in acc_outs]), capi.ptr_array([o.ptr for o in outs]), int(steps), stream))
         return outs, acc_outs
 
+    def apply_galois_forest(self, L, parents, ext_ins, elts, keys, pts=None, outs=None, stream=None):
+        """hefx_apply_galois_forest: node i rotates node parents[i]'s result (parents[i] < 0: ext_ins[i]) by elts[i] with keys[i];
+        a non-None pts[i] is multiplied in.  Returns the nodes' results."""
+        n = len(parents)
+        outs = outs if outs is not None else self.empty_many(n, (2, L, self.N))
+        par = (C.c_int32 * n)(*[int(p) for p in parents])
+        capi.check(capi.lib().hefx_apply_galois_forest(
+            self._h, L, n, par, capi.ptr_array([x.ptr if x is not None else 0 for x in ext_ins]), capi.u32_array(elts),
+            capi.ptr_array([k.ptr for k in keys]),
+            capi.ptr_array([p.ptr if p is not None else 0 for p in pts]) if pts is not None else None,
+            capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts, outs=None, stream=None):
         """out_i = rotate(ct_i, elt_i) (.) pt_i; a None entry of `pts` makes item i a plain rotation (hefx.h)"""
         n = len(cts)
