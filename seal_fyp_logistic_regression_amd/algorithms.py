@@ -38,7 +38,28 @@ def _rotations_batched(ev: Evaluator, ct: Ciphertext, steps: Sequence[int], gal_
     be, L = ev.be, ct.parms_id()
     plans = [ev.rotation_plan(s, gal_keys) for s in steps]
     cur = [ct.data for _ in steps]
-    for depth in range(max((len(p) for p in plans), default=0)):
+    if hasattr(be, "apply_galois_forest") and sum(len(p) for p in plans) > 1:
+        # the engine's own scheduler for the whole forest (depth batches, subtrees on lanes, hoisted depths): one call
+        index, parents, elts, node_pts = {}, [], [], []
+        leaf = [-1] * len(plans)
+        for i, p in enumerate(plans):
+            c = -1
+            for depth, elt in enumerate(p):
+                fuse = pts is not None and depth == len(p) - 1
+                key = (c, elt, i if fuse else -1)
+                j = index.get(key)
+                if j is None:
+                    j = index[key] = len(parents)
+                    parents.append(c), elts.append(elt), node_pts.append(pts[i].data if fuse else None)
+                c = j
+            leaf[i] = c
+        outs = be.apply_galois_forest(L, parents, [ct.data if q < 0 else None for q in parents], elts,
+                                      [gal_keys.key(e) for e in elts], node_pts if pts is not None else None)
+        cur = [outs[j] if j >= 0 else ct.data for j in leaf]
+        plans_done = True
+    else:
+        plans_done = False
+    for depth in range(0 if plans_done else max((len(p) for p in plans), default=0)):
         jobs, job_list, owner = {}, [], {}
         for i, p in enumerate(plans):
             if depth >= len(p):

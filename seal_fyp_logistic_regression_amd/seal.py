@@ -182,6 +182,11 @@ class GpuBackend:
     def rotate_multiply_plain_batch(self, L, cts, elts, keys, pts):
         return self.engine.rotate_multiply_plain_batch(L, cts, elts, keys, pts)
 
+    def apply_galois_forest(self, L, parents, ext_ins, elts, keys, pts=None):
+        """a forest of rotations in one engine call (hefx_apply_galois_forest); the oracle-backed twin of the tests has no
+        such method and runs the same nodes depth by depth (algorithms._rotations_batched)"""
+        return self.engine.apply_galois_forest(L, parents, ext_ins, elts, keys, pts)
+
     def rotate_add_chain(self, L, cts, elts, keys, accs, steps):
         """`steps` x (t = apply_galois(t); a = a + t) per pair, in lockstep (helper.h:472-476 as one engine call)"""
         return self.engine.rotate_add_chain(L, cts, elts, keys, accs, steps)
