@@ -90,6 +90,32 @@ while time.time() < t_end:
                 acc = t if acc is None else o.add(acc, t)
             assert (ps[gi].download() == acc).all(), ("mulplain_sum", N, bits, L, gi)
         checks += 4 * n + 3 + len(ps)
+    # a random rotation forest (hefx_apply_galois_forest): random parents, a handful of elements / keys, plaintext products on
+    # some nodes -- every third round, sometimes large enough for two lanes and hoisted depths; the oracle node by node
+    if k > 1 and N <= 8192 and rounds % 3 == 0:
+        L = k - 1
+        steps = [1, -1, 2, 4, -8]
+        felts = [O.galois_elt_from_step(N, s_) for s_ in steps]
+        fkeys = [o.uniform(k, 2 * (k - 1), seed + 900 + i).reshape(k - 1, 2, k, N) for i in range(len(steps))]
+        dfk = [e.to_device(x) for x in fkeys]
+        nn = int(rng.choice([5, 20, 60, 130, 220]))
+        srcs = [o.uniform(L, 2, seed + 950 + i) for i in range(2)]
+        dsrcs = [e.to_device(x) for x in srcs]
+        nroots = max(1, nn // int(rng.choice([3, 8, 20])))
+        par = [-1 if i < nroots else int(rng.integers(0, i)) for i in range(nn)]
+        which = [int(rng.integers(len(steps))) for _ in range(nn)]
+        src_i = [int(rng.integers(2)) if par[i] < 0 else None for i in range(nn)]
+        fpts = [o.uniform(L, 1, seed + 1000 + i)[0] if rng.random() < 0.3 else None for i in range(nn)]
+        outs = e.apply_galois_forest(L, par, [dsrcs[j] if j is not None else None for j in src_i], [felts[w] for w in which],
+                                     [dfk[w] for w in which], [e.to_device(p_) if p_ is not None else None for p_ in fpts])
+        want = []
+        for i in range(nn):
+            src = srcs[src_i[i]] if par[i] < 0 else want[par[i]]
+            want.append(o.apply_galois(src, felts[which[i]], fkeys[which[i]]) if fpts[i] is None else
+                        o.rotate_mulplain(src, felts[which[i]], fkeys[which[i]], fpts[i]))
+        for i in range(nn):
+            assert (outs[i].download() == want[i]).all(), ("forest", N, bits, nn, i)
+        checks += nn
     key32 = bytes(rng.integers(0, 256, 32, dtype=np.uint8))
     for kind in ("uniform", "ternary", "noise"):
         sid = int(rng.integers(1 << 40))
