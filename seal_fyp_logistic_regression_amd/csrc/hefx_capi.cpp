@@ -1085,8 +1085,11 @@ static int ensure_flipw(hefx_context *c, const uint32_t *elts, int n, hipStream_
     d_ginv = reinterpret_cast<uint32_t *>(rows + per * miss.size());
     hipError_t e = hipMemcpy(d_ginv, ginv.data(), ginv.size() * sizeof(uint32_t), hipMemcpyHostToDevice);
     int rc = HEFX_OK;
-    for (size_t i0 = 0; i0 < miss.size() && e == hipSuccess && rc == HEFX_OK; i0 += 1024) {  // (grid.z; bounded scratch at N = 32768)
-        const int cnt = (int)std::min<size_t>(1024, miss.size() - i0);
+    // (slices: grid.z <= 1024; at N = 32768 the transform is out of place through the context's scratch buffer, which never
+    // shrinks -- 64 tables at a time keep that loan at 100 MB instead of GBs)
+    const size_t slice = c->logn == 15 ? 64 : 1024;
+    for (size_t i0 = 0; i0 < miss.size() && e == hipSuccess && rc == HEFX_OK; i0 += slice) {
+        const int cnt = (int)std::min<size_t>(slice, miss.size() - i0);
         e = launch_flip_rows(c->T, d_ginv + i0, cnt, rows + per * i0, s);
         if (e == hipSuccess) rc = ntt_common(c, false, (uint64_t *)(rows + per * i0), cnt, c->k, 0, (void *)s);
     }
