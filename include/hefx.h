@@ -3,8 +3,8 @@
  *
  * Drop-in boundary for the hot path of MarwanNour/SEAL-FYP-Logistic-Regression.  The reference has no
  * FFI layer of its own: its boundary is the C++ class API of Microsoft SEAL 3.4.5's `seal::Evaluator`
- * (`#include "seal/seal.h"`, /root/reference/helper.h:4; CMake target SEAL::seal,
- * /root/reference/CMakeLists.txt:25-41).  Every entry point below names the Evaluator member it
+ * (`#include "seal/seal.h"`, reference file helper.h:4 (all file:line citations in this header are relative to the reference repo root); CMake target SEAL::seal,
+ * CMakeLists.txt:25-41).  Every entry point below names the Evaluator member it
  * replaces and the reference call sites that reach it; include/seal/seal.h is the C++ shim that maps
  * the class API onto these calls.
  *
@@ -50,7 +50,7 @@ const char *hefx_version(void);
 int hefx_device_count(void);
 
 /* ---- context: replaces SEALContext::Create(parms) + the Evaluator's NTT tables
- *      (/root/reference/linear_transformation2.cpp:229-237, helper.h:239-240).
+ *      (linear_transformation2.cpp:229-237, helper.h:239-240).
  *      N = poly_modulus_degree in {1024..16384, 32768}; primes = coeff_modulus (last = special prime). */
 int hefx_context_create(uint32_t poly_degree, const uint64_t *primes, int k, int device, hefx_context **out);
 void hefx_context_destroy(hefx_context *ctx);
@@ -92,7 +92,7 @@ int hefx_context_device(const hefx_context *ctx);
  * what a host side sizes its budgets with (the shim's pending-results budget is a quarter of the device) */
 int hefx_device_memory(hefx_context *ctx, size_t *free_bytes, size_t *total_bytes);
 /* How many key-switch chunks of this context were REDONE item by item so far: batches that rotate few distinct
- * ciphertexts many times (the d-1 rotations of Linear_Transform_Plain, /root/reference/helper.h:252-257) run exactly
+ * ciphertexts many times (the d-1 rotations of Linear_Transform_Plain, helper.h:252-257) run exactly
  * hoisted -- the source is decomposed once per chunk -- which covers every input except a source whose c1 has a zero
  * coefficient in some RNS component (a transparent or hand-made ciphertext); such a chunk falls back on the device to
  * the per-item sequence, same bits either way.  Waits for the device.  A diagnostic: tests assert 0 on random inputs
@@ -102,7 +102,7 @@ int hefx_ks_fallback_count(hefx_context *ctx, uint64_t *chunks);
  * submitted (items of every batch, relinearisations included), out[1] of them run exactly hoisted (sharing their source's
  * decomposition), out[2] launch sequences (chunks), out[3] batched calls.  What a caller needs to price a composite --
  * e.g. how many key switches the NAF forest of one Linear_Transform_Plain with the reference's power-of-two keys
- * (/root/reference/linear_transformation2.cpp:239) executes after prefix sharing. */
+ * (linear_transformation2.cpp:239) executes after prefix sharing. */
 int hefx_ks_stats(hefx_context *ctx, uint64_t out[4]);
 int hefx_memset_zero(hefx_context *ctx, void *d_dst, size_t bytes, void *stream);
 int hefx_stream_sync(hefx_context *ctx, void *stream);
@@ -230,10 +230,13 @@ int hefx_relinearize_batch(hefx_context *ctx, int L, int n, const uint64_t *cons
  *      The division by the dropped prime q_l exists in two forms and which one SEAL 3.4.5 uses is the one item of
  *      SURVEY App. A.9 that could not be verified offline, so both are built (and both are bit-exact against the
  *      oracle's orc_rescale(rounded = 0 / 1)):
- *        HEFX_RESCALE_FLOOR  out_j = (c_j - [c_l]_(q_j)) * q_l^-1  -- App. A.9's statement of 3.4.x; the default.
+ *        HEFX_RESCALE_FLOOR  out_j = (c_j - [c_l]_(q_j)) * q_l^-1  -- App. A.9's [M]-confidence statement of 3.4.x
+ *                            (BaseConverter::floor_last_coeff_modulus_ntt_inplace).
  *        HEFX_RESCALE_ROUND  out_j = (c_j - ([c_l + q_l/2]_(q_l) mod q_j - (q_l/2 mod q_j))) * q_l^-1 -- round to
- *                            nearest, SEAL >= 3.5's RNSTool::divide_and_round_q_last_inplace.
- *      hefx_rescale_to_next uses the context's mode (hefx_set_rescale_mode; environment HEFX_RESCALE=round|floor
+ *                            nearest: 3.4.x's BaseConverter::round_last_coeff_modulus_ntt_inplace as two independent
+ *                            reviews recall Evaluator::mod_switch_scale_to_next calling it, and SEAL >= 3.5's
+ *                            RNSTool::divide_and_round_q_last_ntt_inplace.  The default since round 6.
+ *      hefx_rescale_to_next uses the context's mode (hefx_set_rescale_mode; environment HEFX_RESCALE=floor|round
  *      presets it at hefx_context_create); hefx_rescale_to_next_mode names it per call. */
 #define HEFX_RESCALE_FLOOR 0
 #define HEFX_RESCALE_ROUND 1

@@ -351,10 +351,12 @@ inline std::shared_ptr<Engine> get_engine(std::uint32_t n, const std::vector<std
                      (double)std::clock() / CLOCKS_PER_SEC, n, primes.size());
     if (const char *l = std::getenv("SEAL_SHIM_LAZY")) e->lazy = std::atoi(l) != 0;
     if (const char *nd = std::getenv("SEAL_SHIM_DEVICES")) e->ndev = std::max(1, std::min(64, std::atoi(nd)));
-    // the one SEAL semantic that could not be verified offline: SEAL_SHIM_RESCALE=round switches
-    // rescale_to_next from the floor division (3.4.x as App. A.9 reads it; default) to round-to-nearest (3.5+)
+    // the one SEAL semantic that could not be verified offline: rescale_to_next divides with
+    // round-to-nearest by default (the engine's default since round 6: Evaluator::mod_switch_scale_to_next calling
+    // BaseConverter::round_last_coeff_modulus_ntt_inplace); SEAL_SHIM_RESCALE=floor selects the
+    // floor division App. A.9 reads 3.4.x as
     if (const char *r = std::getenv("SEAL_SHIM_RESCALE"))
-        check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "round" ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR));
+        check(hefx_set_rescale_mode(e->ctx_raw, std::string(r) == "floor" ? HEFX_RESCALE_FLOOR : HEFX_RESCALE_ROUND));
     {   // results a submission will STORE may reach 8 GiB (a quarter of the device on a small one) before it is forced;
         // elided results do not count (record()).  profiles/r04/lr_driver_pending_budget.txt has the measurements that led
         // here: with every recorded result counted and allocated, 8 GiB cut the LR driver's eight gradient chains across
@@ -1683,7 +1685,7 @@ public:
         c.ntt_form_ = shim::get_u8(stream) != 0;
         const std::uint64_t size = shim::get_u64(stream), n = shim::get_u64(stream), rows = shim::get_u64(stream);
         c.scale_ = shim::get_f64(stream);
-        if (size > 16 || rows > (std::uint64_t)ctx->k() || (size && n != ctx->n()))
+        if (size > 16 || rows > (std::uint64_t)ctx->k() || (size && (n != ctx->n() || !rows)))
             throw std::invalid_argument("ciphertext data is invalid");
         auto w = shim::get_words(stream, size * rows * n);
         if (w.size() != (std::size_t)(size * rows * n)) throw std::invalid_argument("ciphertext data is invalid");
@@ -1701,7 +1703,10 @@ public:
         Ciphertext c;
         c.unsafe_load(ctx, stream);
         if (c.size_) {
-            if (ctx->rows_of(c.id_) != c.rows || c.size_ < 2 || c.ntt_form_ != ctx->is_ckks())
+            // (rows_of() is 0 for a parms_id this context does not know: rejected as is_valid_for does, even when the stream
+            // also says "zero rows")
+            const int known_rows = ctx->rows_of(c.id_);
+            if (!known_rows || known_rows != c.rows || c.size_ < 2 || c.ntt_form_ != ctx->is_ckks())
                 throw std::invalid_argument("ciphertext data is invalid");
             const std::uint64_t *w = c.data();
             for (std::size_t p = 0; p < c.size_; ++p)

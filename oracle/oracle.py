@@ -256,7 +256,7 @@ class Oracle:
         lib().orc_relinearize(self._h, ct3.shape[1], ct3, key, out)
         return out
 
-    def rescale(self, ct, rounded=False):
+    def rescale(self, ct, rounded=True):
         out = self._new(ct.shape[0], ct.shape[1] - 1)
         lib().orc_rescale(self._h, ct.shape[1], ct.shape[0], ct, out, int(rounded))
         return out

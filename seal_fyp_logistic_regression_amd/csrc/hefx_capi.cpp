@@ -164,7 +164,7 @@ struct hefx_context {
     int flag_cap = 1 + 4096;
     void *comm = nullptr;  // ncclComm_t of hefx_comm_init (RCCL, resolved at run time), one per context = per rank
     int comm_world = 0, comm_rank = 0;
-    int rescale_mode = HEFX_RESCALE_FLOOR;  // default of hefx_rescale_to_next (HEFX_RESCALE=round|floor presets it)
+    int rescale_mode = HEFX_RESCALE_ROUND;  // default of hefx_rescale_to_next (HEFX_RESCALE=floor|round presets it)
     static constexpr int MAX_STREAMS = 4;
     hipStream_t streams[MAX_STREAMS] = {};  // internal streams for chunk pipelining
     hipEvent_t ev_fork = nullptr, ev_join[MAX_STREAMS] = {};
@@ -474,7 +474,7 @@ extern "C" int hefx_context_create(uint32_t poly_degree, const uint64_t *primes,
     if (const char *fv = getenv("HEFX_FLIPW_MB")) c->flipw_cap = (size_t)strtoull(fv, nullptr, 10) << 20;
     if (const char *pv = getenv("HEFX_POOL_MB")) c->pool_cap = (size_t)strtoull(pv, nullptr, 10) << 20;
     if (const char *fv = getenv("HEFX_FUSED")) c->fused = atoi(fv) != 0;
-    if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "round") ? HEFX_RESCALE_ROUND : HEFX_RESCALE_FLOOR;
+    if (const char *rv = getenv("HEFX_RESCALE")) c->rescale_mode = !strcmp(rv, "floor") ? HEFX_RESCALE_FLOOR : HEFX_RESCALE_ROUND;
     if (e != hipSuccess) {
         hefx_context_destroy(c);  // frees whatever exists so far (tables, flags, streams, events, ring, gate words)
         return hipfail(e, "context table upload");
@@ -529,6 +529,8 @@ extern "C" void hefx_context_destroy(hefx_context *c)
     if (c->chain_items) (void)hipFree(c->chain_items);
     if (c->lt_head) (void)hipFree(c->lt_head);
     if (c->scratch) (void)hipFree(c->scratch);
+    for (u64 *p : c->scratch_retired) (void)hipFree(p);  // outgrown scratch / lt_head / lt_ws buffers (grow_retiring)
+    c->scratch_retired.clear();
     if (c->d_flag) (void)hipFree(c->d_flag);
     if (c->d_tables) (void)hipFree(c->d_tables);
     if (c->d_enc_tables) (void)hipFree(c->d_enc_tables);
@@ -1375,7 +1377,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         bool chunk_alias = false;
         int nsrc = 0;  // > 0: this chunk runs exactly hoisted over that many distinct sources
         std::unordered_map<const void *, uint32_t> src_of;
-        if (share && cnt > ks_small_max() && one_source) {
+        if (share && cnt > ks_small_max() && one_source && cnt + 1 <= KS_MAX_CHUNK) {  // (room for the source descriptor in the ring slot)
             src_of.emplace((const void *)ct_in[0], 0u);
             nsrc = 1;
         } else if (share && cnt > ks_small_max()) {

@@ -23,15 +23,46 @@ __global__ __launch_bounds__(NttCfg<LOGN>::T, 4) void ntt_rows_kernel(DevTables 
     const ModConst mc = T.mods[m];
     u64 v[16];
     if (!INV) {
+        // The row's arithmetic policy (FP64 for primes below 2^41, integers otherwise) is uniform over the workgroup.  Each
+        // policy's branch does its OWN loads -- from its own copy of t, laundered through an empty asm so that the two
+        // sets of loads are not recognised as common code and hoisted above the branch.  With the loads in front of the
+        // branch the compiler lays the function out as "integer block, then FP64 block if a flag says so", the FP64 block
+        // is reachable from the integer block as far as register allocation can tell, and the sixteen loaded words stay
+        // live across the whole integer transform for a use that never happens: 12-22 VGPRs in scratch memory at every
+        // degree until round 6.
+        const ModConstF mf = T.modsf[m];
+        int tl = t;
+        if (mf.q != 0.0) {
+            asm volatile("" : "+v"(tl));
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = p[C::idx_nat(t, r)];
-        ntt_fwd_row<LOGN>(v, lds, ntt_tables(T, m), mc, T.modsf[m], t);
+            for (int r = 0; r < 16; ++r) v[r] = p[C::idx_nat(tl, r)];
+            ntt_fwd_row<LOGN>(v, lds, ntt_tables(T, m), mc, mf, t);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = p[C::idx_nat(tl, r)];
+            ntt_fwd_row<LOGN>(v, lds, ntt_tables(T, m), mc, mf, t);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[C::idx_out(t, r)] = v[r];
     } else {
+        // (loads per policy branch as above -- at N = 8192 only: that instantiation kept 4 VGPRs in scratch with the loads
+        // in front of the branch; the others fit 120-127 that way and LOSE registers with the loads duplicated)
+        const ModConstF mf = T.modsf[m];
+        int tl = t;
+        if (LOGN != 13) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) v[r] = p[C::idx_out(t, r)];
-        ntt_inv_row<LOGN>(v, lds, ntt_tables(T, m), mc, T.modsf[m], t);
+            for (int r = 0; r < 16; ++r) v[r] = p[C::idx_out(t, r)];
+            ntt_inv_row<LOGN>(v, lds, ntt_tables(T, m), mc, mf, t);
+        } else if (mf.q != 0.0) {
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = p[C::idx_out(tl, r)];
+            ntt_inv_row<LOGN>(v, lds, ntt_tables(T, m), mc, mf, t);
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = p[C::idx_out(tl, r)];
+            ntt_inv_row<LOGN>(v, lds, ntt_tables(T, m), mc, mf, t);
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) p[C::idx_nat(t, r)] = v[r];
     }

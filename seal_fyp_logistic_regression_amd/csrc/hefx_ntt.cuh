@@ -527,7 +527,11 @@ struct NoHook {
 // sixteen registers of a thread with workgroup-uniform twiddles and hands its results to LDS, so which column of the
 // T x 16 array a thread owns there is free; loaders over [evens | odds] rows pick the one that makes lane-adjacent reads
 // adjacent in memory (eo_lane, hefx_keyswitch.hip).  Every later pass works by t.
-template <int LOGN, class A, class HOOK = NoHook>
+// LEAN (stand-alone row kernel, hefx_kernels.hip): the thread index the NEXT pass's twiddle addresses are formed from is
+// laundered through an empty asm at the point of use.  Without it the compiler forms every pass's twiddle addresses at
+// kernel entry (they depend on t only) and carries them -- 12-22 VGPRs -- through the whole transform, which under the
+// 128-VGPR cap of a 1024-thread workgroup means scratch memory.
+template <int LOGN, class A, class HOOK = NoHook, bool LEAN = false>
 __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A::V *lds,
                                              const typename A::TW *__restrict__ tw, const typename A::Ctx &cx, int t,
                                              int pre, const HOOK &tail_hook = HOOK(), int t0 = -1)
@@ -558,10 +562,12 @@ __device__ __forceinline__ void ntt_fwd_core(typename A::V (&v)[16], typename A:
                 A::ct(v[e], v[e | half], w[(1 << u) - 1 + (e >> (4 - u))], cx, 4 * p + u);
             }
         }
+        int tl = t;
+        if (LEAN) asm volatile("" : "+v"(tl));
         if (p + 1 < C::FP)
-            load_pass_tw<LOGN, A>(w, tw, p + 1, t, pre);
+            load_pass_tw<LOGN, A>(w, tw, p + 1, tl, pre);
         else if (C::R > 0)
-            load_rem_tw<LOGN, A>(w, tw, t, pre);
+            load_rem_tw<LOGN, A>(w, tw, tl, pre);
         if (p + 1 < C::FP || C::R > 0) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) lds[pb + ps * e] = v[e];

@@ -232,18 +232,21 @@ def cc_matrix_multiplication_sharded(ev: Evaluator, ctA: Ciphertext, ctB: Cipher
     ctA0 = linear_transform_plain_sharded(ev, ctA, U_sigma, gal_keys, group)      # :22
     ctB0 = linear_transform_plain_sharded(ev, ctB, U_tau, gal_keys, group)        # :25
     mine = list(shard(dimension - 1, rank, world))
-    ctAk = [alg.linear_transform_plain(ev, ctA0, V_diagonals[k], gal_keys) for k in mine]   # :42
-    ctBk = [alg.linear_transform_plain(ev, ctB0, W_diagonals[k], gal_keys) for k in mine]   # :43
-    for c in ctAk + ctBk:
-        ev.rescale_to_next_inplace(c)                                              # :69-73
+    # this rank's transforms of ctA0 / ctB0 share the rotations of their input (alg._linear_transforms_of_one_input, as the
+    # serial form does for all n-1): same bits as transform by transform, 1 / len(mine) of the key switches
+    ctAk = alg._linear_transforms_of_one_input(ev, ctA0, [V_diagonals[k] for k in mine], gal_keys)   # :42
+    ctBk = alg._linear_transforms_of_one_input(ev, ctB0, [W_diagonals[k] for k in mine], gal_keys)   # :43
+    ev.rescale_to_next_many_inplace(ctAk)                                          # :69-73
+    ev.rescale_to_next_many_inplace(ctBk)
     ctAB = ev.multiply(ctA0, ctB0)                                                 # :104
     ev.mod_switch_to_next_inplace(ctAB)                                            # :112
     for c in ctAk + ctBk:
         c.scale = 2.0 ** int(np.log2(c.scale))                                     # :117-121
-    partial = ctAB if rank == 0 else _zero_like(ev, ctAB)                          # A_0 (.) B_0 is counted once
-    for a, b in zip(ctAk, ctBk):
-        ev.add_inplace(partial, ev.multiply(a, b))                                 # :123-129
-    return allreduce_ciphertext(ev, partial, group)
+    terms = ([ctAB] if rank == 0 else []) + (ev.multiply_many(ctAk, ctBk) if ctAk else [])   # A_0 (.) B_0 counted once
+    partial = ev.add_many(terms) if terms else _zero_like(ev, ctAB)                # :123-129 (this rank's share)
+    out = allreduce_ciphertext(ev, partial, group)
+    out.scale = ctAB.scale  # the serial sum carries its first addend's scale (A_0 (.) B_0) on every rank
+    return out
 
 
 def linear_transform_plain_sparse_sharded(ev: Evaluator, ct: Ciphertext, d: int, diagonals: dict,

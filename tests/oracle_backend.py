@@ -121,7 +121,7 @@ class OracleBackend:
     def relinearize(self, L, ct3, key):
         return self.o.relinearize(self._ct(ct3, 3, L), key)
 
-    rescale_rounded = False  # floor (3.4.x per App. A.9) unless a test switches the twin to the rounded variant
+    rescale_rounded = True  # round to nearest, like the engine's default; tests switch the twin to floor
 
     def rescale(self, L, size, ct):
         return self.o.rescale(self._ct(ct, size, L), rounded=self.rescale_rounded)

@@ -15,9 +15,9 @@ def make(N, bits, backend_kind, seed=1, galois_steps=None):
     parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
     backend = OracleBackend(N, parms.coeff_modulus()) if backend_kind == "oracle" else None
     ctx = S.SEALContext.Create(parms, backend=backend)
-    # both twins rescale the way the environment says (the `rescale_mode` fixture of tests/conftest.py; default: floor)
+    # both twins rescale the way the environment says (the `rescale_mode` fixture of tests/conftest.py; default: round)
     import os
-    assert ctx.backend.rescale_rounded == (os.environ.get("HEFX_RESCALE") == "round"), backend_kind
+    assert ctx.backend.rescale_rounded == (os.environ.get("HEFX_RESCALE", "round") != "floor"), backend_kind
     kg = S.KeyGenerator(ctx, seed)
     return dict(ctx=ctx, kg=kg, enc=S.Encryptor(ctx, kg.public_key(), seed + 1), dec=S.Decryptor(ctx, kg.secret_key()),
                 encoder=S.CKKSEncoder(ctx, device_encode=False), ev=S.Evaluator(ctx), rk=kg.relin_keys(), gk=kg.galois_keys(galois_steps))

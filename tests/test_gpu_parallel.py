@@ -177,3 +177,69 @@ def test_config5_sparse_matrix_product_sharded_world2():
         for name, (same, err) in res.items():
             assert same, f"rank {rank} {name}: sharded sparse product differs from the serial one"
             assert err < 1e-3, (name, err)
+
+
+def _worker_config5_dense(rank, world, port, q, mode):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["HEFX_RESCALE"] = mode
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from seal_fyp_logistic_regression_amd import algorithms as alg
+        from seal_fyp_logistic_regression_amd import parallel as par
+        from seal_fyp_logistic_regression_amd import seal as S
+        N, n = 32768, 8
+        parms = S.EncryptionParameters("ckks")
+        parms.set_poly_modulus_degree(N)
+        parms.set_coeff_modulus(S.CoeffModulus.Create(N, [60, 40, 40, 40, 40, 60]))
+        ctx = S.SEALContext.Create(parms)
+        assert ctx.backend.name == "hip" and ctx.backend.rescale_rounded == (mode == "round")
+        kg = S.KeyGenerator(ctx, 31)
+        enc_, dec_ = S.Encryptor(ctx, kg.public_key(), 32), S.Decryptor(ctx, kg.secret_key())
+        encoder, ev, gk = S.CKKSEncoder(ctx), S.Evaluator(ctx), kg.galois_keys()
+        rng = np.random.default_rng(58)
+        A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+        scale = 2.0 ** 40
+        dense = lambda U: encoder.encode_many(list(alg.get_all_diagonals(U) + 1e-8), scale)   # matrix_multiplication.cpp:239-297
+        Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+        ctA, ctB = enc_.encrypt(encoder.encode(A.reshape(-1), scale)), enc_.encrypt(encoder.encode(B.reshape(-1), scale))
+        args = (ctA, ctB, n, dense(Us), dense(Ut), [dense(x) for x in V], [dense(x) for x in W], gk)
+        serial = alg.cc_matrix_multiplication(ev, *args)
+        sharded = par.cc_matrix_multiplication_sharded(ev, *args)
+        bits = lambda c: ctx.backend.to_host(c.data)
+        same = bool((bits(serial) == bits(sharded)).all()) and sharded.size() == 3 and sharded.scale == serial.scale
+        got = encoder.decode(dec_.decrypt(sharded))[:n * n].real.reshape(n, n)
+        q.put((rank, same, float(np.abs(got - A @ B).max())))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("mode", ["floor", "round"])
+def test_config5_dense_n8_matrix_product_sharded_world2(mode):
+    """BASELINE config 5 in the survey's reading (n = 8: 64 x 64 U matrices, N = 32768) and the reference's exact dense
+    composition (matrix_mult_benchmark.cpp:13-71, every diagonal, +1e-8), sharded over two ranks: Step 1 by diagonal (one
+    all-reduce each), Step 2 and the products by k, one all-reduce of the size-3 sum -- bits equal the serial product on
+    both ranks in both rescale divisions; decrypts to A.B."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_config5_dense, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = []
+    for _ in procs:
+        try:
+            out.append(q.get(timeout=600))
+        except Exception:
+            break
+    for p in procs:
+        p.join(timeout=20)
+        if p.is_alive():
+            p.terminate()
+    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed or hung (see its traceback above)"
+    for rank, same, err in sorted(out):
+        assert same, f"rank {rank}: sharded dense product differs from the serial one"
+        assert err < 1e-3, (rank, err)

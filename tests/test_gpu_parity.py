@@ -182,7 +182,7 @@ def test_row_batched_ops_bit_exact(c2):
     rs = e.rescale_batch(L, 2, r2)          # slab in, one launch
     key = _rand_key(o, 5)
     for i in (0, 8):
-        want = o.rescale(o.relinearize(o.multiply(cts[i % 7], cts[3]), key))
+        want = o.rescale(o.relinearize(o.multiply(cts[i % 7], cts[3]), key), rounded=e.rescale_rounded)
         assert (rs[i].download() == want).all()
     sums = e.add_batch(L, 2, r2, r2[::-1])  # second list is not in slab order -> per-item path
     sums2 = e.add_batch(L, 2, r2, r2)       # both slabs -> one launch
@@ -294,9 +294,9 @@ def test_relinearize_and_rescale_bit_exact(c3):
         assert (outs[1].download() == o.relinearize(o.multiply(b, b), key)).all()
         rs = e.rescale_to_next(L, 2, e.to_device(want)).download()
         assert rs.shape == (2, L - 1, o.N)
-        assert (rs == o.rescale(want)).all()
+        assert (rs == o.rescale(want, rounded=e.rescale_rounded)).all()
         rs3 = e.rescale_to_next(L, 3, e.to_device(m)).download()
-        assert (rs3 == o.rescale(m)).all()
+        assert (rs3 == o.rescale(m, rounded=e.rescale_rounded)).all()
     md = e.mod_drop(5, 3, 2, e.to_device(a if a.shape[1] == 5 else o.uniform(5, 2, 1))).download()
     assert md.shape == (2, 3, o.N)
 

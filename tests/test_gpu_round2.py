@@ -76,14 +76,15 @@ def test_rescale_floor_and_rounded_bit_exact(setname):
     for rounded in (False, True):
         got = e.rescale_to_next(L, 2, e.to_device(cts), count=3, rounded=rounded).download()
         assert (got == np.stack([o.rescale(c, rounded=rounded) for c in cts])).all()
-    # context default: floor unless switched
-    assert e.rescale_rounded is False
+    # context default: round (round 6) unless HEFX_RESCALE=floor / set_rescale_rounded(False)
+    assert e.rescale_rounded is (os.environ.get("HEFX_RESCALE", "round") != "floor")
     ct = o.uniform(L, 2, 77)
-    assert (e.rescale_to_next(L, 2, e.to_device(ct)).download() == o.rescale(ct)).all()
+    e.set_rescale_rounded(False)
+    assert e.rescale_rounded is False
+    assert (e.rescale_to_next(L, 2, e.to_device(ct)).download() == o.rescale(ct, rounded=False)).all()
     e.set_rescale_rounded(True)
     assert e.rescale_rounded is True
     assert (e.rescale_to_next(L, 2, e.to_device(ct)).download() == o.rescale(ct, rounded=True)).all()
-    e.set_rescale_rounded(False)
     # edge values: zero rows and q-1 everywhere
     edge = np.zeros((2, L, o.N), dtype=np.uint64)
     for j in range(L):
@@ -384,7 +385,7 @@ def test_two_contexts_with_the_current_device_switched_underneath():
             got = e.rotate_multiply_plain_batch(3, [d], [3], [e.to_device(key)], [e.to_device(pt)])[0].download()
             assert (got == want).all(), (rep, i)
             m = e.relinearize(3, e.square(3, d), e.to_device(key))
-            assert (e.rescale_to_next(3, 2, m).download() == o.rescale(o.relinearize(o.multiply(ct, ct), key))).all()
+            assert (e.rescale_to_next(3, 2, m).download() == o.rescale(o.relinearize(o.multiply(ct, ct), key), rounded=e.rescale_rounded)).all()
     if ndev > 1:
         torch.cuda.set_device(0)
 
@@ -432,7 +433,7 @@ def test_pointer_table_batch_entries_bit_exact():
         assert (outs[t].download() == o.add(B[idx[t]], B[(idx[t] + 1) % n])).all()
     outs = e.rescale_batch(L, 2, [dB[i] for i in idx])
     for t in (0, 767, 768, 799):
-        assert (outs[t].download() == o.rescale(B[idx[t]])).all()
+        assert (outs[t].download() == o.rescale(B[idx[t]], rounded=e.rescale_rounded)).all()
     with pytest.raises(ValueError):
         e.rescale_batch(1, 2, dB[::-1])
     del pad

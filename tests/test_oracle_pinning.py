@@ -143,7 +143,7 @@ def test_switch_key_and_rescale_kat_toy():
     got1 = o.switch_key(np.ascontiguousarray(ct[:, :1]), np.ascontiguousarray(target[:1]), key)
     want1 = pm.switch_key(ct[:, :1].tolist(), target[:1].tolist(), key.tolist(), primes, psis, 1)
     assert got1.tolist() == want1
-    assert o.rescale(ct).tolist() == pm.rescale_floor(ct.tolist(), primes, psis, L)
+    assert o.rescale(ct, rounded=False).tolist() == pm.rescale_floor(ct.tolist(), primes, psis, L)
 
 
 @pytest.fixture(scope="module")

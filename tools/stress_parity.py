@@ -74,7 +74,7 @@ while time.time() < t_end:
         want = o.relinearize(m, keys[0])
         assert (r.download() == want).all(), ("relin", N, bits, L)
         if L >= 2:
-            assert (e.rescale_to_next(L, 2, r).download() == o.rescale(want)).all(), ("rescale", N, bits, L)
+            assert (e.rescale_to_next(L, 2, r).download() == o.rescale(want, rounded=e.rescale_rounded)).all(), ("rescale", N, bits, L)
             assert (e.rescale_to_next(L, 3, dm, rounded=True).download() == o.rescale(m, rounded=True)).all(), ("rescale round", N, bits, L)
         # row-batched ops and the one-pass product sum (inputs scattered over the pooled allocator)
         mb = e.multiply_batch(L, dcts, [dcts[0]] * n)
