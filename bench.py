@@ -20,6 +20,10 @@ Besides the headline, the same JSON line carries:
                 RCCL SUM(uint64) all-reduce per transform (parallel.linear_transform_plain_sharded); the sharded bits are
                 asserted equal to the serial ones in the run
   roofline.valu the integer / FP64 butterfly issue-cycle bound next to the HBM one
+  batch_ladder  the unit at B = 1, 16, 256, 1024: us per op and roofline fraction; chain_level_us: one
+                rotate-by-1 + add level of the dot products' chains at n = 1 / 8, L = 2
+  composites    SURVEY 8(d)'s scaling workloads: matmul_C3_n4, matmul_C5_n8 (dense, every diagonal), lr_rows_2000x8 --
+                serial ms, and with more than one rank the sharded forms with bits asserted equal to the serial ones
 
 Prints ONE JSON line on rank 0.
 """
@@ -374,6 +378,125 @@ def lt_sharded_bench(local_rank: int, world: int, dims, reps: int, direct_d: int
     return out
 
 
+def composites_bench(local_rank: int, world: int, which, use_pg: bool = False, reps: int = 5):
+    """SURVEY 8(d)'s scaling workloads, compute phase only (keys generated, inputs encoded / encrypted beforehand):
+      matmul_C3_n4    CC_Matrix_Multiplication (matrix_multiplication.cpp:11-132) n = 4 at C3: 8 transforms x 16 diagonals
+      matmul_C5_n8    the same at n = 8, N = 32768 (matrix_mult_benchmark.cpp:13-71; config 5 as SURVEY App. B reads it:
+                      64 x 64 U matrices): 16 transforms x 64 diagonals, every diagonal, the 1e-8 epsilons
+      lr_rows_2000x8  predict_cipher_weights (logistic_regression_ckks.cpp:208-266) over 2000 rows x 8 weights at C4
+    Serial ms on this rank (median of `reps` calls incl. the host side); with more than one rank also the sharded form of
+    parallel.py (max over ranks) with its bits asserted equal to the serial ones.  Same seeds on every rank."""
+    import numpy as np
+    import torch.distributed as dist
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from seal_fyp_logistic_regression_amd import parallel as par
+    from seal_fyp_logistic_regression_amd import seal as S
+    out = {}
+
+    def context(setname):
+        N, primes = SETS[setname]
+        parms = S.EncryptionParameters("ckks")
+        parms.set_poly_modulus_degree(N)
+        parms.set_coeff_modulus(primes)
+        ctx = S.SEALContext.Create(parms, device=local_rank)
+        kg = S.KeyGenerator(ctx, 0xC5)
+        return ctx, kg, S.Decryptor(ctx, kg.secret_key()), S.CKKSEncoder(ctx), S.Evaluator(ctx)
+
+    def measure(eng, serial_fn, sharded_fn, bits):
+        for _ in range(2):
+            r = serial_fn()
+        eng.sync()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            r = serial_fn()
+            eng.sync()
+            ts.append(time.perf_counter() - t0)
+        s0 = eng.ks_stats()
+        serial_fn()
+        s1 = eng.ks_stats()
+        ms = sorted(ts)[len(ts) // 2] * 1e3
+        ks = s1["key_switches"] - s0["key_switches"]
+        rec = {"serial_ms": ms, "key_switches_executed": ks, "launch_sequences": s1["chunks"] - s0["chunks"],
+               "key_switches_per_s": ks / (ms * 1e-3)}
+        if use_pg:
+            import torch
+            par.ENGINE_COMM = "off"
+            for _ in range(2):
+                sh = sharded_fn()
+            eng.sync()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                sh = sharded_fn()
+            eng.sync()
+            sms = (time.perf_counter() - t0) / reps * 1e3
+            same = bool((bits(r) == bits(sh)).all())
+            tt = torch.tensor([sms, 1.0 if same else 0.0], dtype=torch.float64)
+            if dist.get_backend() == "nccl":
+                tt = tt.cuda()
+            mx, mn = tt.clone(), tt.clone()
+            dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+            dist.all_reduce(mn, op=dist.ReduceOp.MIN)
+            rec.update({"sharded_ms": float(mx[0].item()), "speedup_vs_1": ms / float(mx[0].item()),
+                        "bits_equal_serial": bool(mn[1].item() == 1.0)})
+            assert rec["bits_equal_serial"], "a sharded composite differs from the serial one"
+        return r, rec
+
+    for name in which:
+        if name.startswith("matmul_"):
+            setname, n = name.split("_")[1], int(name.split("_n")[1])
+            ctx, kg, dec, encoder, ev = context(setname)
+            eng = ctx.backend.engine
+            N = ctx.N
+            Lr = len(SETS[setname][1]) - 1
+            enc, gk = S.Encryptor(ctx, kg.public_key(), 0xC6), kg.galois_keys()
+            rng = np.random.default_rng(500 + n)
+            A, B = rng.uniform(-1, 1, (n, n)), rng.uniform(-1, 1, (n, n))
+            scale = 2.0 ** 40
+            dense = lambda U: encoder.encode_many(list(alg.get_all_diagonals(U) + 1e-8), scale)   # matrix_multiplication.cpp:239-297
+            Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+            ctA, ctB = enc.encrypt(encoder.encode(A.reshape(-1), scale)), enc.encrypt(encoder.encode(B.reshape(-1), scale))
+            args = (ctA, ctB, n, dense(Us), dense(Ut), [dense(x) for x in V], [dense(x) for x in W], gk)
+            bits = lambda c: ctx.backend.to_host(c.data)
+            r, rec = measure(eng, lambda: alg.cc_matrix_multiplication(ev, *args),
+                             lambda: par.cc_matrix_multiplication_sharded(ev, *args), bits)
+            got = encoder.decode(dec.decrypt(r))[:n * n].real.reshape(n, n)
+            rec.update({"decrypts_to_AB": bool(np.allclose(got, A @ B, atol=1e-3)), "max_abs_err": float(np.abs(got - A @ B).max()),
+                        "rotations_op_by_op": 2 * n * n * n, "plaintext_diagonals": 2 * n * n * n, "plaintext_bytes": 2 * n * n * n * Lr * N * 8,
+                        "frac_of_8TBps_algorithmic": rec["key_switches_per_s"] * 8 * N * Lr * (2 * Lr + 7) / 8e12,
+                        "workload": f"{setname}: n={n}, {2 * n} Linear_Transform_Plain x {n * n} diagonals, default power-of-two Galois keys"})
+            out[name] = rec
+            del args, gk, ctx, kg, enc, ev, encoder, dec
+        elif name.startswith("lr_rows_"):
+            rows, nw = (int(x) for x in name[len("lr_rows_"):].split("x"))
+            ctx, kg, dec, encoder, ev = context("C4")
+            eng = ctx.backend.engine
+            gk, rk = kg.galois_keys(), kg.relin_keys()
+            enc = S.Encryptor(ctx, kg.public_key(), 0xC6)
+            rng = np.random.default_rng(700 + rows)
+            X, w = rng.uniform(-1, 1, (rows, nw)), rng.uniform(-0.5, 0.5, nw)
+            scale = 2.0 ** 40
+            feats = [enc.encrypt(p) for p in encoder.encode_many(list(X), scale)]
+            cw = enc.encrypt(encoder.encode(w, scale))
+            bits = lambda c: ctx.backend.to_host(c.data)
+            fresh = lambda: S.Encryptor(ctx, kg.public_key(), 0xC7)  # (the sigmoid encrypts a constant: same seed, same bits)
+            r, rec = measure(eng, lambda: alg.predict_cipher_weights(ev, encoder, fresh(), feats, cw, nw, scale, gk, rk),
+                             lambda: par.predict_cipher_weights_sharded(ev, encoder, fresh(), feats, cw, nw, scale, gk, rk), bits)
+            got = encoder.decode(dec.decrypt(r))[:rows].real
+            c = alg.SIGMOID_COEFFS[3]
+            z = X @ w
+            want = c[0] + c[1] * z + c[2] * z ** 2 + c[3] * z ** 3
+            # the reference's packing replicates a dot product over slots 0..size: only the first `nw` rows carry theirs in full
+            rec.update({"decrypts_to_sigmoid_of_Xw": bool(np.abs(got - want)[:nw].max() < 1e-2),
+                        "max_abs_err_first_rows": float(np.abs(got - want)[:nw].max()), "rows": rows, "weights": nw,
+                        "workload": f"C4: {rows} rows x (multiply + relinearize + rescale + {nw} sequential rotate-by-1 + add), "
+                                    "masks, add_many, degree-3 sigmoid (Horner)"})
+            out[name] = rec
+            del feats, gk, rk, ctx, kg, enc, ev, encoder, dec
+    return out
+
+
 def alg_key_switches(ev, d, gk) -> int:
     """key switches of one Linear_Transform_Plain with these keys (NAF rule)"""
     return sum(len(ev.rotation_plan(s, gk)) for s in [-d] + list(range(1, d)))
@@ -450,12 +573,16 @@ def main():
                     "poly_modulus_degree in {8192, 16384}); '' disables")
     ap.add_argument("--lt-direct", type=int, default=512, help="dimension of the direct-key Linear_Transform_Plain leg "
                     "(one Galois key per step: 4 GB of keys at d = 512, C3); 0 disables")
+    ap.add_argument("--composites", default="matmul_C3_n4,matmul_C5_n8,lr_rows_2000x8", help="SURVEY 8(d)'s scaling workloads "
+                    "(serial ms; sharded + bits_equal_serial with more than one rank); '' disables")
+    ap.add_argument("--ladder", default="1,16,256,1024", help="batch sizes of the `batch_ladder` block (SURVEY 8d); '' disables")
     ap.add_argument("--quick", action="store_true", help="headline only (A/B and profiler runs): no CPU baseline, variants, "
                     "key-per-item, secondary sets, sustained pass or linear-transform legs")
     args = ap.parse_args()
     if args.quick:
         args.cpu_seconds, args.variant_keys, args.stream_keys, args.key_per_item = 0.0, 0, 0, 0
         args.lt, args.lt_direct, args.secondary, args.sustain = "", 0, "", 0.0
+        args.composites, args.ladder = "", ""
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(launch(args))  # nothing in this process has touched the GPU
@@ -570,6 +697,57 @@ def main():
         sdt_, sgpu_ = timed(step, ssteps, 0)
         sustained = {"steps": ssteps, "seconds": sdt_, "value": B * ssteps * world / sdt_, "ms_per_step": sdt_ / ssteps * 1e3,
                      "gpu_ms_per_step": sgpu_ / ssteps}
+
+    # SURVEY 8(d)'s batch ladder B in {1, 16, 256, 1024} of the same unit (prepared call + wait, median; on this rank) and the
+    # latency of one rotate-by-1 + add level of the dot products' chains (helper.h:472-476) on the LR ring at L = 2 -- the
+    # regimes configs 2-4 live in, next to the throughput headline; 0.2 s of GPU time
+    batch_ladder, chain_level_us, unprepared = None, None, None
+    if args.ladder:
+        import statistics
+        batch_ladder = []
+        bytes_op_ = algorithmic_bytes_per_op(N, L)
+        for Bl in [int(x) for x in args.ladder.split(",") if x and int(x) <= B]:
+            prep_l = e.prepare_rotate_multiply_plain_batch(L, cts[:Bl], elts[:Bl], keys[:Bl], pts[:Bl], outs[:Bl])
+            for _ in range(3):
+                e.rotate_multiply_plain_prepared(prep_l)
+            e.sync()
+            ts = []
+            for _ in range(40 if Bl <= 16 else 20):
+                t0 = time.perf_counter()
+                e.rotate_multiply_plain_prepared(prep_l)
+                e.sync()
+                ts.append(time.perf_counter() - t0)
+            med = statistics.median(ts)
+            batch_ladder.append({"batch": Bl, "us_per_call": med * 1e6, "us_per_op": med / Bl * 1e6, "ops_per_s": Bl / med,
+                                 "frac": Bl * bytes_op_ / med / 1e9 / HBM_PEAK_GBS})
+            del prep_l
+        try:
+            from seal_fyp_logistic_regression_amd.seal import galois_elt_from_step
+            Nc, pc = SETS["C4"]
+            ec = Engine(Nc, pc, device=local_rank)
+            kc, Lc, steps_c = len(pc), 2, 300
+            ckey = ec.sample("uniform", key32("chain-key"), 1, 2 * (kc - 1), kc, 0)
+            chain_level_us = {"ring": "C4 (the LR parameter set), L = 2", "steps": steps_c}
+            for nc in (1, 8):
+                ccts = [ec.sample("uniform", key32("chain-ct"), 10 + i, 2, Lc, 0) for i in range(nc)]
+                caccs = [ec.sample("uniform", key32("chain-acc"), 50 + i, 2, Lc, 0) for i in range(nc)]
+                celt = [galois_elt_from_step(1, Nc)] * nc
+                ec.rotate_add_chain(Lc, ccts, celt, [ckey] * nc, caccs, steps_c)
+                ec.sync()
+                t0 = time.perf_counter()
+                ec.rotate_add_chain(Lc, ccts, celt, [ckey] * nc, caccs, steps_c)
+                ec.sync()
+                chain_level_us[f"n{nc}"] = (time.perf_counter() - t0) / steps_c * 1e6
+            del ckey, ccts, caccs
+            ec.close()
+        except Exception as ex:  # reported, never fatal for the headline
+            chain_level_us = {"error": repr(ex)[:300]}
+        # the PUBLIC Python entry (Engine.rotate_multiply_plain_batch: list marshalling on every call) next to the prepared
+        # C-ABI call the headline times since round 5 (keep the marshalling cost visible)
+        usteps = max(3, args.steps // 5)
+        udt, _ = timed(lambda: e.rotate_multiply_plain_batch(L, cts, elts, keys, pts, outs), usteps, 1)
+        unprepared = {"value": B * usteps * world / udt, "steps": usteps, "ms_per_step": udt / usteps * 1e3,
+                      "note": "Engine.rotate_multiply_plain_batch with Python lists (the r01-r04 headline's call)"}
 
     # what was timed is checked: one item of EVERY chunk of the launch sequence (the engine cuts the batch into chunks of
     # at most 256 items on alternating internal streams) plus the last item, word for word against the CPU oracle (rank 0)
@@ -688,7 +866,7 @@ def main():
         # (FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note, WRITE_SIZE as is), scaled to one step.
         src16, lib16 = _hashes()
         traffic, traffic_src, traffic_stale = None, None, None
-        for rnd in ("r05", "r04", "r03", "r02", "r01"):
+        for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
             pmc = os.path.join(ROOT, "profiles", f"{rnd}_bench_pmc_traffic.json")
             if args.set == "C3" and os.path.exists(pmc):
                 try:
@@ -706,7 +884,7 @@ def main():
         # engine clock sampled during this run that is cycles of wall time per instruction and SIMD -- against ~5 cycles
         # of issue cost for this mix (4 for 32-bit ops, 4.75 v_fma_f64, 5.7 v_mad_u64_u32: profiles/r01_valu_issue_rates.txt)
         issue = None
-        sqf = next((f for f in (os.path.join(ROOT, "profiles", f"{r}_bench_sq_counters.json") for r in ("r05", "r04", "r03"))
+        sqf = next((f for f in (os.path.join(ROOT, "profiles", f"{r}_bench_sq_counters.json") for r in ("r06", "r05", "r04", "r03"))
                     if os.path.exists(f)), "")
         if args.set == "C3" and sqf:
             try:
@@ -747,6 +925,9 @@ def main():
             "csrc_sha16": src16,         # ... and of the engine sources (csrc/ + include/hefx.h) it was built from
             "rescale_mode": "round" if e.rescale_rounded else "floor",  # the engine's default division
             "sustained": sustained,
+            "batch_ladder": batch_ladder,          # B in {1, 16, 256, 1024}, us per op and roofline frac
+            "chain_level_us": chain_level_us,      # one rotate-by-1 + add level (helper.h:472-476), n = 1 and 8 chains, L = 2
+            "unprepared_call": unprepared,
             "secondary": secondary,
             "config": {
                 "workload": f"{args.set}: N={N}, coeff_modulus bits "
@@ -805,6 +986,7 @@ def main():
             "variants": variants,
             "board_under_load": board_rec,
             "lt_sharded": None,
+            "composites": None,
         }
         if args.cpu_seconds > 0 and world == 1:
             try:
@@ -843,6 +1025,28 @@ def main():
         dog.cancel()
         if rank == 0:
             line["lt_sharded"] = lt
+    # SURVEY 8(d)'s scaling workloads (matrix products at C3 / C5, LR row batch): same watchdog rule
+    if args.composites and args.set == "C3":
+        if prepared:
+            prepared.clear()
+            del big_ct, big_pt, big_out, cts, pts, outs
+
+        def bail2():
+            if rank == 0:
+                line["composites"] = {"error": "timed out after 600 s (the headline measurement is unaffected)"}
+                emit()
+            os._exit(3)
+
+        dog = threading.Timer(600.0, bail2)
+        dog.daemon = True
+        dog.start()
+        try:
+            comp = composites_bench(local_rank, world, [x for x in args.composites.split(",") if x], use_pg=use_pg)
+        except Exception as ex:
+            comp = {"error": repr(ex)[:400]}
+        dog.cancel()
+        if rank == 0:
+            line["composites"] = comp
     emit()
     if use_pg:
         dist.barrier()

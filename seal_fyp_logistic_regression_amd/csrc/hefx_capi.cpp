@@ -1180,6 +1180,21 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
         chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
     }
+    // MID-BATCH LANES (round 6): a batch that is ONE chunk but too wide for the latency path leaves most of the chip idle in
+    // its narrow launches (the 2 n mod-down inverse rows, the n L digit inverses) and pays every launch boundary with the
+    // whole batch waiting.  Cut into `mid_lanes` sub-chunks on the internal streams, the narrow launches of one lane run
+    // beside the wide ones of the other.  HEFX_MID_LANES=<k> (0 / 1: off), HEFX_MID_MIN / HEFX_MID_MAX=<items> bound the range.
+    static const int mid_lanes = getenv("HEFX_MID_LANES") ? atoi(getenv("HEFX_MID_LANES")) : 0;
+    static const int mid_min = getenv("HEFX_MID_MIN") ? atoi(getenv("HEFX_MID_MIN")) : 8;
+    static const int mid_max = getenv("HEFX_MID_MAX") ? atoi(getenv("HEFX_MID_MAX")) : 64;
+    bool laned = false;
+    if (mid_lanes > 1 && n <= chunk && n >= mid_min && n <= mid_max && c->use_streams && !c->profiling && !scratch_off && !hoist) {
+        const int lanes = mid_lanes < c->nstreams ? mid_lanes : c->nstreams;
+        if (lanes > 1) {
+            chunk = (n + lanes - 1) / lanes;
+            laned = true;
+        }
+    }
     const int nchunks = (n + chunk - 1) / chunk;
     const bool two = nchunks > 1 && c->use_streams && !c->profiling;
     int sub = c->sub;
@@ -1317,7 +1332,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // source; the levels of a NAF forest have 2..20, and there 2 and 3 measure 2-3 % under 4 (3.85 / 3.85-3.96 / 3.98-4.01 ms
     // at C3, d = 512; 2.76-2.79 / 2.70-2.74 / 2.78-2.83 ms at N = 8192, d = 1000)
     static const size_t share_ratio = getenv("HEFX_SHARE_RATIO") ? (size_t)std::max(1, atoi(getenv("HEFX_SHARE_RATIO"))) : 3;
-    bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
+    bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax && !laned;
     bool one_source = share;  // the common case -- a linear transform's rotations of ct_new -- needs no hash set
     for (int i = 1; i < n && one_source; ++i) one_source = ct_in[i] == ct_in[0];
     if (share && !one_source) {
@@ -1437,7 +1452,8 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         // digit transforms up to 256 (beyond that 2 split workgroups per row win: 14 us for 256 of them against 19 us for
         // 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none / all, HEFX_QMASK=<bits> any
         // combination (KS_Q_*)
-        const int quarter = (small && !fused && nchunks == 1) ? ks_small_shape(cnt, L) : 0;
+        static const bool mid_shape_total = getenv("HEFX_MID_SHAPE_TOTAL") && atoi(getenv("HEFX_MID_SHAPE_TOTAL"));
+        const int quarter = (small && !fused && (nchunks == 1 || laned)) ? ks_small_shape(laned && mid_shape_total ? n : cnt, L) : 0;
         for (const auto &so : src_of) {  // the distinct sources, behind the items: only c_in and elt are read (noperm)
             if (!nsrc) break;
             KsItem &sd = hb[cnt + (int)so.second];

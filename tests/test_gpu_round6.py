@@ -71,7 +71,7 @@ def test_chunk_1024_one_source_leaves_room_for_the_source_descriptor():
         "import numpy as np\n"
         "from oracle import oracle as O\n"
         "from seal_fyp_logistic_regression_amd import Engine\n"
-        "N = 1024\n"
+        "N = 2048\n"
         "from seal_fyp_logistic_regression_amd import seal as S\n"
         "primes = [int(p) for p in S.CoeffModulus.Create(N, [50, 40, 50])]\n"
         "o, e = O.Oracle(N, primes), Engine(N, primes); L, k = 2, 3\n"
