@@ -287,6 +287,15 @@ int hefx_reduce_canonical(hefx_context *ctx, int L, int size, uint64_t *d_data, 
 int hefx_linear_transform_plain(hefx_context *ctx, int L, const uint64_t *d_ct, int d,
                                 const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
                                 const uint64_t *const *d_keys, uint64_t *d_out, void *stream);
+/* `count` (1..64) Linear_Transform_Plain calls of the same dimension and key set IN LOCKSTEP: d_out[t] =
+ * Linear_Transform_Plain(d_cts[t], d_diag_pts[t * d .. t * d + d)).  Independent transforms -- the sigma and tau
+ * transforms of ctA and ctB in CC_Matrix_Multiplication (matrix_multiplication.cpp:22-25), the n independent products of
+ * matrix_mult_benchmark.cpp -- share every launch sequence (the -d rotations, each depth of the rotation forest): the same
+ * number of dependent sequences as ONE transform, each `count` times as wide.  Per input the operations and their order
+ * are those of hefx_linear_transform_plain: same words.  Outputs pairwise distinct and distinct from the inputs. */
+int hefx_linear_transform_plain_many(hefx_context *ctx, int L, int count, const uint64_t *const *d_cts, int d,
+                                     const uint64_t *const *d_diag_pts, int nkeys, const uint32_t *key_elts,
+                                     const uint64_t *const *d_keys, uint64_t *const *d_outs, void *stream);
 
 /* ---- A FOREST of rotations in one call: node i rotates the result of node parent[i] (parent[i] < 0: the ciphertext
  *      d_ext_in[i]) by galois_elts[i] with d_keys[i] into d_out[i]; a non-NULL d_pts[i] multiplies the rotated ciphertext

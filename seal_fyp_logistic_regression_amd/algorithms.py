@@ -255,6 +255,31 @@ def _native_key_args(gal_keys: KSwitchKeys):
     return cache[1], cache[2]
 
 
+def linear_transforms_plain_many(ev: Evaluator, cts: Sequence[Ciphertext], diag_sets: Sequence[Sequence[Plaintext]],
+                                 gal_keys: KSwitchKeys) -> List[Ciphertext]:
+    """[Linear_Transform_Plain(cts[t], diag_sets[t], gal_keys) for t] -- INDEPENDENT transforms of one dimension, e.g.
+    the sigma transform of ctA and the tau transform of ctB (matrix_multiplication.cpp:22-25).  On the HIP engine they run
+    in lockstep behind one call (hefx_linear_transform_plain_many: every dependent launch sequence carries the items of all
+    inputs); per input the operations and their order are those of linear_transform_plain -- same bits, which is also what
+    every other backend (and mixed shapes) gets from the loop."""
+    native = getattr(ev.be, "linear_transform_plain_many", None)
+    d = len(diag_sets[0]) if diag_sets else 0
+    same = (len(cts) > 1 and len(cts) == len(diag_sets) and all(len(ds) == d for ds in diag_sets)
+            and all(c.size() == 2 and c.parms_id() == cts[0].parms_id() for c in cts)
+            and len({id(c.data) for c in cts}) == len(cts))
+    if native is None or not same or len(cts) > 64:
+        return [linear_transform_plain(ev, c, ds, gal_keys) for c, ds in zip(cts, diag_sets)]
+    L = cts[0].parms_id()
+    scales = [_plain_product_scale(ev, c, ds) for c, ds in zip(cts, diag_sets)]   # SEAL's checks, transform by transform
+    elts, keys = _native_key_args(gal_keys)
+    flat = [p.data for ds in diag_sets for p in ds]
+    if flat and hasattr(flat[0], "ptr"):
+        from . import capi
+        flat = capi.ptr_array([p.ptr for p in flat])
+    outs = native(L, [c.data for c in cts], flat, elts, keys)
+    return [Ciphertext()._set(o, 2, L, s) for o, s in zip(outs, scales)]
+
+
 # ---- baby-step / giant-step form of Linear_Transform_Plain (SURVEY 8f rank 3) -----------------------------------
 # With l = j*n1 + i (i < n1 baby, j < n2 giant):
 #   sum_l diag_l (.) rot_l(v)  =  sum_j rot_(j*n1)( sum_i rot_(-j*n1)(diag_l) (.) rot_i(v) )
@@ -442,15 +467,76 @@ def _linear_transforms_of_one_input(ev: Evaluator, ct: Ciphertext, diag_sets: Se
     return ev.multiply_plain_sum(terms_ct, terms_pt, group=d)        # :250, :256, :259
 
 
+def _rotations_of_many(ev: Evaluator, cts: Sequence[Ciphertext], steps: Sequence[int],
+                       gal_keys: KSwitchKeys) -> List[List[Ciphertext]]:
+    """[[rotate_vector(ct, l) for l in steps] for ct in cts] with the NAF forests of all inputs in ONE engine call
+    (hefx_apply_galois_forest takes any number of roots): the depths of the forests run side by side, so k inputs cost the
+    dependent launch sequences of one.  Backends without the forest entry, a single input or a zero step take the
+    per-input path."""
+    be = ev.be
+    if len(cts) < 2 or not hasattr(be, "apply_galois_forest") or any(s == 0 for s in steps) or \
+            len({c.parms_id() for c in cts}) != 1 or any(c.size() != 2 for c in cts):
+        return [_rotations_batched(ev, c, steps, gal_keys) for c in cts]
+    L = cts[0].parms_id()
+    plans = [ev.rotation_plan(s, gal_keys) for s in steps]
+    parents, ext, elts = [], [], []
+    leaf = [[-1] * len(plans) for _ in cts]
+    for t, ct in enumerate(cts):
+        index = {}
+        for i, p in enumerate(plans):
+            c = -1
+            for elt in p:
+                j = index.get((c, elt))
+                if j is None:
+                    j = index[(c, elt)] = len(parents)
+                    parents.append(c), ext.append(ct.data if c < 0 else None), elts.append(elt)
+                c = j
+            leaf[t][i] = c
+    outs = be.apply_galois_forest(L, parents, ext, elts, [gal_keys.key(e) for e in elts], None)
+    return [[Ciphertext()._set(outs[j], 2, L, ct.scale) for j in leaf[t]] for t, ct in enumerate(cts)]
+
+
+def _linear_transforms_of_inputs(ev: Evaluator, cts: Sequence[Ciphertext],
+                                 diag_sets_per_input: Sequence[Sequence[Sequence[Plaintext]]],
+                                 gal_keys: KSwitchKeys) -> List[List[Ciphertext]]:
+    """[_linear_transforms_of_one_input(ct, sets) for ct, sets] with the rotations of ALL inputs formed together
+    (matrix_multiplication.cpp:40-43: the V_k of ctA0 and the W_k of ctB0 are independent of one another): the -d rotations
+    as one batch, the rotation forests in one call, every plaintext product and sum in one pass.  Per input the same
+    operations in the same order: same bits."""
+    ds = [len(s[0]) for s in diag_sets_per_input if s]
+    if len(cts) < 2 or len(ds) != len(cts) or len(set(ds)) != 1 or \
+            any(len(x) != ds[0] for s in diag_sets_per_input for x in s) or not hasattr(ev.be, "apply_galois_forest"):
+        return [_linear_transforms_of_one_input(ev, c, s, gal_keys) for c, s in zip(cts, diag_sets_per_input)]
+    d = ds[0]
+    dup = _rotations_of_many(ev, cts, [-d], gal_keys)                 # helper.h:244
+    ct_news = [ev.add(c, r[0]) for c, r in zip(cts, dup)]             # :247
+    rots = _rotations_of_many(ev, ct_news, list(range(1, d)), gal_keys)   # :255
+    terms_ct, terms_pt, counts = [], [], []
+    for ct_new, rr, sets in zip(ct_news, rots, diag_sets_per_input):
+        full = [ct_new] + rr
+        terms_ct += [full[l] for _ in sets for l in range(d)]
+        terms_pt += [s[l] for s in sets for l in range(d)]
+        counts.append(len(sets))
+    sums = ev.multiply_plain_sum(terms_ct, terms_pt, group=d)          # :250, :256, :259
+    out, at = [], 0
+    for k in counts:
+        out.append(sums[at:at + k])
+        at += k
+    return out
+
+
 def cc_matrix_multiplication(ev: Evaluator, ctA: Ciphertext, ctB: Ciphertext, dimension: int,
                              U_sigma: Sequence[Plaintext], U_tau: Sequence[Plaintext],
                              V_diagonals: Sequence[Sequence[Plaintext]], W_diagonals: Sequence[Sequence[Plaintext]],
                              gal_keys: KSwitchKeys) -> Ciphertext:
     """CC_Matrix_Multiplication, /root/reference/matrix_multiplication.cpp:11-132 (Jiang et al. 2018/1041)."""
-    ctA0 = linear_transform_plain(ev, ctA, U_sigma, gal_keys)        # :22
-    ctB0 = linear_transform_plain(ev, ctB, U_tau, gal_keys)          # :25
-    ctAk = _linear_transforms_of_one_input(ev, ctA0, V_diagonals, gal_keys)   # :42
-    ctBk = _linear_transforms_of_one_input(ev, ctB0, W_diagonals, gal_keys)   # :43
+    # Step 1's two transforms are independent of one another, and so are Step 2's two families: each pair runs in
+    # lockstep (round 6) -- 2 x (1 + NAF depth) dependent launch sequences for the whole product instead of 4 x
+    ctA0, ctB0 = linear_transforms_plain_many(ev, [ctA, ctB], [U_sigma, U_tau], gal_keys)    # :22, :25
+    if dimension > 1:
+        ctAk, ctBk = _linear_transforms_of_inputs(ev, [ctA0, ctB0], [V_diagonals, W_diagonals], gal_keys)   # :42, :43
+    else:
+        ctAk, ctBk = [], []
     return _matmul_step3(ev, ctA0, ctB0, ctAk, ctBk)
 
 

@@ -91,6 +91,7 @@ _SIGS = {
     "hefx_comm_rank": (_i, [_vp]),
     "hefx_allreduce_sum": (_i, [_vp, _i, _i, _vp, _vp]),
     "hefx_linear_transform_plain": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
+    "hefx_linear_transform_plain_many": (_i, [_vp, _i, _i, _pp, _i, _pp, _i, C.POINTER(_u32), _pp, _pp, _vp]),
     "hefx_rotate_hoisted_batch": (_i, [_vp, _i, _vp, _i, C.POINTER(_u32), _pp, _pp, _pp, _vp]),
     "hefx_linear_transform_plain_hoisted": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),
     "hefx_linear_transform_plain_hoisted2": (_i, [_vp, _i, _vp, _i, _pp, _i, C.POINTER(_u32), _pp, _vp, _vp]),

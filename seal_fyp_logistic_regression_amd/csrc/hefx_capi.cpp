@@ -1180,21 +1180,6 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         const int cap = c->logn <= 13 ? 2 * KS_AUTO_CHUNK : KS_AUTO_CHUNK;
         chunk = chunk > cap ? cap : (chunk < 16 ? 16 : chunk & ~7);
     }
-    // MID-BATCH LANES (round 6): a batch that is ONE chunk but too wide for the latency path leaves most of the chip idle in
-    // its narrow launches (the 2 n mod-down inverse rows, the n L digit inverses) and pays every launch boundary with the
-    // whole batch waiting.  Cut into `mid_lanes` sub-chunks on the internal streams, the narrow launches of one lane run
-    // beside the wide ones of the other.  HEFX_MID_LANES=<k> (0 / 1: off), HEFX_MID_MIN / HEFX_MID_MAX=<items> bound the range.
-    static const int mid_lanes = getenv("HEFX_MID_LANES") ? atoi(getenv("HEFX_MID_LANES")) : 0;
-    static const int mid_min = getenv("HEFX_MID_MIN") ? atoi(getenv("HEFX_MID_MIN")) : 8;
-    static const int mid_max = getenv("HEFX_MID_MAX") ? atoi(getenv("HEFX_MID_MAX")) : 64;
-    bool laned = false;
-    if (mid_lanes > 1 && n <= chunk && n >= mid_min && n <= mid_max && c->use_streams && !c->profiling && !scratch_off && !hoist) {
-        const int lanes = mid_lanes < c->nstreams ? mid_lanes : c->nstreams;
-        if (lanes > 1) {
-            chunk = (n + lanes - 1) / lanes;
-            laned = true;
-        }
-    }
     const int nchunks = (n + chunk - 1) / chunk;
     const bool two = nchunks > 1 && c->use_streams && !c->profiling;
     int sub = c->sub;
@@ -1332,7 +1317,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
     // source; the levels of a NAF forest have 2..20, and there 2 and 3 measure 2-3 % under 4 (3.85 / 3.85-3.96 / 3.98-4.01 ms
     // at C3, d = 512; 2.76-2.79 / 2.70-2.74 / 2.78-2.83 ms at N = 8192, d = 1000)
     static const size_t share_ratio = getenv("HEFX_SHARE_RATIO") ? (size_t)std::max(1, atoi(getenv("HEFX_SHARE_RATIO"))) : 3;
-    bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax && !laned;
+    bool share = share_ok && !relin && !fused && !any_alias && n > ks_small_max() && sub >= cmax;
     bool one_source = share;  // the common case -- a linear transform's rotations of ct_new -- needs no hash set
     for (int i = 1; i < n && one_source; ++i) one_source = ct_in[i] == ct_in[0];
     if (share && !one_source) {
@@ -1452,8 +1437,7 @@ static int ks_run(hefx_context *c, int L, int n, bool relin, const uint64_t *con
         // digit transforms up to 256 (beyond that 2 split workgroups per row win: 14 us for 256 of them against 19 us for
         // 512 quarters), the mod-down finish up to 320.  HEFX_QUARTER=0/1 forces none / all, HEFX_QMASK=<bits> any
         // combination (KS_Q_*)
-        static const bool mid_shape_total = getenv("HEFX_MID_SHAPE_TOTAL") && atoi(getenv("HEFX_MID_SHAPE_TOTAL"));
-        const int quarter = (small && !fused && (nchunks == 1 || laned)) ? ks_small_shape(laned && mid_shape_total ? n : cnt, L) : 0;
+        const int quarter = (small && !fused && nchunks == 1) ? ks_small_shape(cnt, L) : 0;
         for (const auto &so : src_of) {  // the distinct sources, behind the items: only c_in and elt are read (noperm)
             if (!nsrc) break;
             KsItem &sd = hb[cnt + (int)so.second];
@@ -2416,21 +2400,29 @@ static int run_forest(hefx_context *c, int L, const std::vector<ForestNode> &nod
     return lane_rc;
 }
 
-static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint64_t *const *diag_pts, int nkeys,
-                   const uint32_t *key_elts, const uint64_t *const *keys, uint64_t *out, void *stream, bool hoisted)
+// `count` transforms with the same dimension and key set in lockstep (count = 1: hefx_linear_transform_plain): transform t
+// maps cts[t] with the diagonals diag_pts[t * d .. t * d + d) to outs[t].  The rotation plans are those of ONE transform;
+// every launch sequence -- the -d rotation, each depth of the rotation forest -- carries the items of all `count` inputs
+// (round 6: CC_Matrix_Multiplication's sigma / tau transforms of ctA / ctB, matrix_multiplication.cpp:22-25, are
+// independent of one another: half the dependent launch sequences, each twice as wide).  Per input the operations and
+// their order are those of the single transform: same bits.
+static int lt_impl(hefx_context *c, int L, int count, const uint64_t *const *cts, int d, const uint64_t *const *diag_pts, int nkeys,
+                   const uint32_t *key_elts, const uint64_t *const *keys, uint64_t *const *outs, void *stream, bool hoisted)
 {
     CTXCHK(c);
     if (int rc = check_ks_level(c, L)) return rc;
-    if (!ct || !out || d < 1 || !diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
+    if (count < 1 || count > 64 || !cts || !outs || d < 1 || !diag_pts || nkeys < 0 || (nkeys && (!key_elts || !keys)))
         return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
-    for (int i = 0; i < d; ++i)
+    for (int t = 0; t < count; ++t)
+        if (!cts[t] || !outs[t]) return fail(HEFX_ERR_INVALID, "bad linear-transform arguments");
+    for (int i = 0; i < count * d; ++i)
         if (!diag_pts[i]) return fail(HEFX_ERR_INVALID, "null diagonal plaintext");
     static const bool dbg = getenv("HEFX_DEBUG") != nullptr;  // host time of the call's phases on stderr
     auto t_last = std::chrono::steady_clock::now();
     auto lap = [&](const char *what) {
         if (!dbg) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[hefx] linear_transform(d=%d): %-36s %7.1f us\n", d, what, std::chrono::duration<double, std::micro>(now - t_last).count());
+        fprintf(stderr, "[hefx] linear_transform(d=%d x %d): %-36s %7.1f us\n", d, count, what, std::chrono::duration<double, std::micro>(now - t_last).count());
         t_last = now;
     };
     LtKeys K;
@@ -2449,22 +2441,41 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
             return fail(HEFX_ERR_INVALID, "hoisted linear transform needs a direct Galois key for every step 1..d-1");
     }
     lap("key map + rotation plans");
-    // ---- workspace, part 1: ping/pong for the first rotation chain, ct_new, product 0
-    if (int rc = grow_retiring(c, &c->lt_head, &c->lt_head_cap, 4 * ctw, 0, "linear-transform head")) return rc;
-    uint64_t *ping = reinterpret_cast<uint64_t *>(c->lt_head), *pong = ping + ctw, *ct_new = pong + ctw, *prod0 = ct_new + ctw;
+    // ---- workspace, part 1, per input: ping/pong for the first rotation chain, ct_new, product 0
+    if (int rc = grow_retiring(c, &c->lt_head, &c->lt_head_cap, (size_t)count * 4 * ctw, 0, "linear-transform head")) return rc;
+    uint64_t *head = reinterpret_cast<uint64_t *>(c->lt_head);
+    auto ping = [&](int t) { return head + (size_t)t * 4 * ctw; };
+    auto pong = [&](int t) { return ping(t) + ctw; };
+    auto ct_new = [&](int t) { return ping(t) + 2 * ctw; };
+    auto prod0 = [&](int t) { return ping(t) + 3 * ctw; };
     // ---- ct_new = ct + rotate(ct, -d)      (helper.h:244-247): launched FIRST, so that the planning below (0.1 ms of host
-    // time at d = 512) runs beside it instead of in front of it
-    const uint64_t *src = ct;
-    for (size_t t = 0; t < first.size(); ++t) {
-        uint64_t *dst = (t & 1) ? pong : ping;
-        const uint64_t *key = K.at(first[t]);
-        if (int rc = ks_run(c, L, 1, false, &src, &first[t], &key, nullptr, nullptr, &dst, stream)) return rc;
-        src = dst;
+    // time at d = 512) runs beside it instead of in front of it.  The sum rides in the epilogue of the chain's last key
+    // switch (acc_out = acc_in + rotation, the kernels of hefx_apply_galois_add_batch): one launch less than rotate + add
+    {
+        std::vector<const uint64_t *> src((size_t)count), kk((size_t)count), ain((size_t)count);
+        std::vector<uint64_t *> dst((size_t)count), aout((size_t)count);
+        std::vector<uint32_t> ee((size_t)count);
+        for (int t = 0; t < count; ++t) src[(size_t)t] = cts[t], ain[(size_t)t] = cts[t], aout[(size_t)t] = ct_new(t);
+        for (size_t s = 0; s < first.size(); ++s) {
+            const bool last = s + 1 == first.size();
+            for (int t = 0; t < count; ++t) {
+                dst[(size_t)t] = (s & 1) ? pong(t) : ping(t);
+                kk[(size_t)t] = K.at(first[s]);
+                ee[(size_t)t] = first[s];
+            }
+            if (int rc = ks_run(c, L, count, false, src.data(), ee.data(), kk.data(), nullptr, nullptr, dst.data(), stream, false,
+                                last ? ain.data() : nullptr, last ? aout.data() : nullptr))
+                return rc;
+            for (int t = 0; t < count; ++t) src[(size_t)t] = dst[(size_t)t];
+        }
+        if (first.empty())  // d == 0 mod N/2 cannot happen (lt_plan refuses it); kept for completeness: ct_new = ct + ct
+            for (int t = 0; t < count; ++t)
+                if (int rc = hefx_add(c, L, 2, 1, cts[t], cts[t], ct_new(t), stream)) return rc;
     }
-    if (int rc = hefx_add(c, L, 2, 1, ct, src, ct_new, stream)) return rc;
     // ---- res[0] = ct_new * diag[0]         (helper.h:250)
-    if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new, diag_pts[0], prod0, stream)) return rc;
-    lap("head submitted (rotate -d, add, product 0)");
+    for (int t = 0; t < count; ++t)
+        if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new(t), diag_pts[(size_t)t * d], prod0(t), stream)) return rc;
+    lap("head submitted (rotate -d + add, product 0)");
     // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
     struct Node {
         int parent;  // -1: ct_new
@@ -2497,27 +2508,34 @@ static int lt_impl(hefx_context *c, int L, const uint64_t *ct, int d, const uint
         leaf[l] = cur;
     }
     lap("forest");
-    // ---- workspace, part 2: one ciphertext per node
-    const size_t need = ctw * nodes.size();
+    // ---- workspace, part 2: one ciphertext per node and input
+    const size_t nn = nodes.size();
+    const size_t need = ctw * nn * (size_t)count;
     if (int rc = grow_retiring(c, &c->lt_ws, &c->lt_cap, need ? need : 1, 0, "linear-transform nodes")) return rc;
     uint64_t *node0 = reinterpret_cast<uint64_t *>(c->lt_ws);
-    auto node_ptr = [&](int i) { return i < 0 ? ct_new : node0 + (size_t)i * ctw; };
-    // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth on lanes   (helper.h:252-257; run_forest)
-    {
-        std::vector<ForestNode> fn(nodes.size());
-        for (size_t i = 0; i < nodes.size(); ++i) {
-            const Node &nd = nodes[i];
-            fn[i] = ForestNode{nd.parent, nd.elt, nd.depth, ct_new, K.at(nd.elt), nd.fused >= 0 ? diag_pts[nd.fused] : nullptr,
-                               node_ptr((int)i)};
-        }
+    auto node_ptr = [&](int t, int i) { return i < 0 ? ct_new(t) : node0 + ((size_t)t * nn + (size_t)i) * ctw; };
+    // ---- res[l] = rotate(ct_new, l) * diag[l], depth by depth on lanes   (helper.h:252-257; run_forest): the forests of
+    // the inputs side by side, input t's nodes at t * nn ..
+    if (nn) {
+        std::vector<ForestNode> fn(nn * (size_t)count);
+        for (int t = 0; t < count; ++t)
+            for (size_t i = 0; i < nn; ++i) {
+                const Node &nd = nodes[i];
+                fn[(size_t)t * nn + i] = ForestNode{nd.parent < 0 ? -1 : (int)((size_t)t * nn) + nd.parent, nd.elt, nd.depth, ct_new(t),
+                                                    K.at(nd.elt), nd.fused >= 0 ? diag_pts[(size_t)t * d + nd.fused] : nullptr,
+                                                    node_ptr(t, (int)i)};
+            }
         if (int rc = run_forest(c, L, fn, max_depth, stream, hoisted)) return rc;
     }
     lap("key-switch batches submitted");
     // ---- out = add_many(res)               (helper.h:259)
     std::vector<const uint64_t *> res(d);
-    res[0] = prod0;
-    for (int l = 1; l < d; ++l) res[l] = node_ptr(leaf[l]);
-    const int rc = hefx_add_many(c, L, 2, d, res.data(), out, stream);
+    int rc = HEFX_OK;
+    for (int t = 0; t < count && rc == HEFX_OK; ++t) {
+        res[0] = prod0(t);
+        for (int l = 1; l < d; ++l) res[l] = node_ptr(t, leaf[l]);
+        rc = hefx_add_many(c, L, 2, d, res.data(), outs[t], stream);
+    }
     lap("add_many submitted");
     return rc;
 }
@@ -2567,14 +2585,20 @@ extern "C" int hefx_linear_transform_plain(hefx_context *c, int L, const uint64_
                                            const uint64_t *const *diag_pts, int nkeys, const uint32_t *key_elts,
                                            const uint64_t *const *keys, uint64_t *out, void *stream)
 {
-    return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, false);
+    return lt_impl(c, L, 1, &ct, d, diag_pts, nkeys, key_elts, keys, &out, stream, false);
+}
+extern "C" int hefx_linear_transform_plain_many(hefx_context *c, int L, int count, const uint64_t *const *cts, int d,
+                                                const uint64_t *const *diag_pts, int nkeys, const uint32_t *key_elts,
+                                                const uint64_t *const *keys, uint64_t *const *outs, void *stream)
+{
+    return lt_impl(c, L, count, cts, d, diag_pts, nkeys, key_elts, keys, outs, stream, false);
 }
 extern "C" int hefx_linear_transform_plain_hoisted(hefx_context *c, int L, const uint64_t *ct, int d,
                                                    const uint64_t *const *diag_pts, int nkeys,
                                                    const uint32_t *key_elts, const uint64_t *const *keys,
                                                    uint64_t *out, void *stream)
 {
-    return lt_impl(c, L, ct, d, diag_pts, nkeys, key_elts, keys, out, stream, true);
+    return lt_impl(c, L, 1, &ct, d, diag_pts, nkeys, key_elts, keys, &out, stream, true);
 }
 // Baby-step / giant-step Linear_Transform_Plain: with l = j*n1 + i,
 //   sum_l diag_l (.) rot_l(ct_new) = sum_j rot_(j*n1)( sum_i diag'_l (.) rot_i(ct_new) ),  diag'_l = diag_l shifted

@@ -252,6 +252,7 @@ __global__ __launch_bounds__(SplitCfg<LOGN>::T, KsWaves<LOGN>::INV) void ks_intt
 // ------------------------------------------------------------------------------------------------
 // (2) digit i -> modulus slot jj != i: x[b][i][jj] = NTT_m(d[b][i] mod m)
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool slot_is_f64(const DevTables &T, int L, int jj);
 template <int LOGN>
 __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int rows, int item0, int stream_x,
                                               const KsScratch &S, u64 *lds)
@@ -259,7 +260,34 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     using SC = SplitCfg<LOGN>;
     using C = typename SC::C;
     int g, jj, h;
-    group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
+    if (stream_x & 2) {
+        // HEAVY FIRST (small chunks, round 6): an integer-policy target row costs twice the butterflies of an FP64 one, and a
+        // chunk of a few hundred workgroups is one resident wave -- which workgroups end up SHARING a CU decides when the
+        // launch ends (n = 8, L = 5: per-workgroup times 8 / 14 / 22.6 us min / median / max, profiles/r06/stamps_default_L5_n8.txt).
+        // Dispatch order = block id: member-major, group-minor, the integer-policy members of every digit first -- the
+        // heavy workgroups take CUs of their own while there are free ones, the light ones double up.
+        const int x = blockIdx.x & 7, rest = blockIdx.x >> 3;
+        const int nsg = (rows + 7) >> 3;
+        const int sg = rest % nsg, slot = rest / nsg;
+        g = sg * 8 + x;
+        h = slot & 1;
+        const int rank = slot >> 1, di = g % L;
+        int heavy = 0;  // integer-policy targets of digit di: members 0..L-1 -> slots 0..L without di
+        for (int mm = 0; mm < L; ++mm) heavy += !slot_is_f64(T, L, mm >= di ? mm + 1 : mm);
+        int want = rank < heavy ? rank : rank - heavy;  // the want-th heavy (rank < heavy) or light member
+        jj = 0;
+        for (int mm = 0; mm < L; ++mm) {
+            const bool hv = !slot_is_f64(T, L, mm >= di ? mm + 1 : mm);
+            if (hv == (rank < heavy)) {
+                if (want == 0) {
+                    jj = mm;
+                    break;
+                }
+                --want;
+            }
+        }
+    } else
+        group_decode(blockIdx.x, L, g, jj, h);  // g = digit (b, i); jj = one of its L target moduli
     if (g >= rows || (S.gate_mode == 2 && ks_gated_out(S))) return;  // (mode 1 gates only the launch that writes outputs)
     const int t = threadIdx.x;
     const int bl = g / L, i = g % L;  // bl: item index inside the sub-chunk
@@ -286,7 +314,7 @@ __device__ __forceinline__ void ntt_digit_row(const DevTables &T, int L, int row
     u64 *__restrict__ xd = S.x + (((size_t)bl * L + i) * (L + 1) + jj) * SC::N + (size_t)h * SC::H;
     // stream_x: the chunk's digit x modulus products exceed the Infinity Cache, so they are written (here) and read
     // (MAC) with streaming accesses that leave the caches to the rows that are reused -- digits, twiddles, key
-    if (stream_x) {
+    if (stream_x & 1) {
 #pragma unroll
         for (int r = 0; r < 16; r += 2) nt_store16(xd + C::idx_io(t, r), v[r], v[r + 1]);  // (r, r+1) are one record
     } else {
@@ -1933,6 +1961,13 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         mark(-1);
         return hipGetLastError();
     }
+    // heavy-first dispatch order of the digit transforms (ntt_digit_row) while the launch is a few resident waves:
+    // HEFX_HEAVY_FIRST=0 switches it off, HEFX_HEAVY_MAX=<workgroups> moves the bound.  Measured at L = 5 (C4 ring,
+    // profiles/r06/heavy_first_ab.txt): n = 8 80.3 -> 77.6 us, n = 12 90.9 -> 90.4, n = 16 even, n = 24 / 32 +1.5 / +2 us (several
+    // rounds of workgroups: the grouped order's L2 locality wins again) -- hence up to ~2.5 workgroups per CU
+    static const bool heavy_on = !(getenv("HEFX_HEAVY_FIRST") && atoi(getenv("HEFX_HEAVY_FIRST")) == 0);
+    static const int heavy_max = getenv("HEFX_HEAVY_MAX") ? atoi(getenv("HEFX_HEAVY_MAX")) : 640;
+    auto heavy_order = [&](int m) { return heavy_on && m * L * L * 2 <= heavy_max ? 2 : 0; };
     if (small && (quarter & KS_Q_ALL) && sub >= n) {
         static PerDeviceOnce attrq;
         const size_t ldsq = QuarterCfg<LOGN>::LDS_BYTES;
@@ -1956,7 +1991,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                                n * L, scr);
         else
             hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds_ntt, s, T, L,
-                               n * L, 0, 0, scr);
+                               n * L, 0, heavy_order(n), scr);
         mark(3);
         hipLaunchKernelGGL(ks_mac_kernel<false>, dim3(SC::N / 2 / 256, L + 1, (n + 1) / 2), dim3(256), 0, s, T, batch, L, rl, 0,
                            n, 0, scr);
@@ -2026,7 +2061,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         // x of this (sub-)chunk against the 256 MB Infinity Cache: beyond it, stream x (HEFX_STREAM_X=0/1 overrides)
         const int stream_x = stream_x_of(m);
         hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(m * L, L)), dim3(SC::T), lds_ntt, s, T, L, m * L,
-                           item0, stream_x, scr);
+                           item0, stream_x | heavy_order(m), scr);
         mark(3);
         if (stream_x)
             hipLaunchKernelGGL(ks_mac_kernel<true>, dim3(SC::N / 2 / 256, L + 1, (m + 1) / 2), dim3(256), 0, s, T, batch,

@@ -434,6 +434,22 @@ class Engine:
             self._h, L, ct.ptr, len(darr), darr, len(karr), capi.u32_array(key_elts), karr, out.ptr, stream))
         return out
 
+    def linear_transform_plain_many(self, L, cts, diag_pts, key_elts, keys, outs=None, stream=None):
+        """len(cts) transforms of one dimension and key set in lockstep (hefx_linear_transform_plain_many); diag_pts: the
+        diagonals of transform 0, then of transform 1, ... (a flat list or a prebuilt C pointer array)"""
+        count = len(cts)
+        if count < 1:
+            raise ValueError("linear_transform_plain_many: no inputs")
+        outs = outs if outs is not None else self.empty_many(count, (2, L, self.N))
+        karr = keys if isinstance(keys, C.Array) else capi.ptr_array([k.ptr for k in keys])
+        darr = diag_pts if isinstance(diag_pts, C.Array) else capi.ptr_array([p.ptr for p in diag_pts])
+        if len(darr) % count:
+            raise ValueError("linear_transform_plain_many: every transform needs the same number of diagonals")
+        capi.check(capi.lib().hefx_linear_transform_plain_many(
+            self._h, L, count, capi.ptr_array([c.ptr for c in cts]), len(darr) // count, darr, len(karr),
+            capi.u32_array(key_elts), karr, capi.ptr_array([o.ptr for o in outs]), stream))
+        return outs
+
     def linear_transform_plain_hoisted2_sparse(self, L, ct, d, steps, diag_pts_keylevel, key_elts, keys, out=None,
                                                stream=None):
         """double-hoisted transform over a subset of the diagonals (steps[0] == 0)"""

@@ -216,6 +216,9 @@ class GpuBackend:
     def linear_transform_plain(self, L, ct, diag_pts, key_elts, keys, hoisted=False):
         return self.engine.linear_transform_plain(L, ct, diag_pts, key_elts, keys, hoisted=hoisted)
 
+    def linear_transform_plain_many(self, L, cts, diag_pts, key_elts, keys):
+        return self.engine.linear_transform_plain_many(L, cts, diag_pts, key_elts, keys)
+
     def rotate_hoisted_batch(self, L, ct, elts, keys, pts=None):
         return self.engine.rotate_hoisted_batch(L, ct, elts, keys, pts)
 

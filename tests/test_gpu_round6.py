@@ -139,3 +139,53 @@ def test_cc_matrix_multiplication_n8_config5_dense_bit_exact(rescale_mode):
     assert (bits(eg, cg) == bits(eo, co)).all()
     got = decode(eg, cg, n * n).reshape(n, n)
     assert np.allclose(got, A @ B, rtol=1e-4, atol=1e-3), np.abs(got - A @ B).max()
+
+
+@pytest.mark.parametrize("setname,d,count,direct", [("C2", 9, 3, False), ("C3", 16, 2, False), ("C3", 40, 2, True), ("C2", 5, 5, False)])
+def test_linear_transform_plain_many_bit_exact(setname, d, count, direct):
+    """hefx_linear_transform_plain_many: `count` independent Linear_Transform_Plain calls in lockstep (the sigma / tau
+    transforms of CC_Matrix_Multiplication, matrix_multiplication.cpp:22-25) -- every output word for word what the
+    single-transform entry gives for that input, and what the oracle twin's op-by-op sequence gives; with the reference's
+    default keys (NAF forests) and with a direct key per step (the wide depth runs exactly hoisted per source)."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from tests.test_gpu_composites import make, bits, decode
+    N, bits_ = {"C2": (8192, [60, 40, 40, 60]), "C3": (16384, [60, 40, 40, 40, 40, 60])}[setname]
+    steps = ([-d] + list(range(1, d))) if direct else None
+    res = {}
+    rng = np.random.default_rng(d * 100 + count)
+    Ms = [rng.uniform(-1, 1, (d, d)) for _ in range(count)]
+    vs = [rng.uniform(-1, 1, d) for _ in range(count)]
+    for kind in ("gpu", "oracle"):
+        e = make(N, bits_, kind, seed=11, galois_steps=steps)
+        scale = 2.0 ** 40
+        cts = [e["enc"].encrypt(e["encoder"].encode(v, scale)) for v in vs]
+        diag_sets = [[e["encoder"].encode(x, scale) for x in alg.get_all_diagonals(M)] for M in Ms]
+        many = alg.linear_transforms_plain_many(e["ev"], cts, diag_sets, e["gk"])
+        one_by_one = [alg.linear_transform_plain(e["ev"], c, ds, e["gk"]) for c, ds in zip(cts, diag_sets)]
+        res[kind] = (e, many, one_by_one)
+    (eg, mg, og), (eo, mo, oo) = res["gpu"], res["oracle"]
+    assert eg["ctx"].backend.name == "hip" and hasattr(eg["ctx"].backend, "linear_transform_plain_many")
+    for t in range(count):
+        assert mg[t].scale == og[t].scale == mo[t].scale and mg[t].parms_id() == mo[t].parms_id()
+        assert (bits(eg, mg[t]) == bits(eg, og[t])).all(), t          # lockstep == one call per transform
+        assert (bits(eg, mg[t]) == bits(eo, mo[t])).all(), t          # == the oracle twin's op-by-op sequence
+        assert np.allclose(decode(eg, mg[t], d), Ms[t] @ vs[t], atol=1e-3)
+
+
+def test_linear_transform_plain_many_refuses_bad_arguments():
+    """count out of range, null pointers, a missing Galois key: HEFX_ERR_INVALID before anything runs"""
+    from seal_fyp_logistic_regression_amd import algorithms as alg, capi
+    from tests.test_gpu_composites import make
+    e = make(8192, [60, 40, 40, 60], "gpu", seed=5, galois_steps=[1, 2])
+    be, L = e["ctx"].backend, 3
+    scale = 2.0 ** 40
+    cts = [e["enc"].encrypt(e["encoder"].encode(np.ones(4), scale)) for _ in range(2)]
+    diags = [e["encoder"].encode(np.ones(4), scale) for _ in range(8)]
+    elts = sorted(e["gk"].keys)
+    keys = [e["gk"].key(x) for x in elts]
+    with pytest.raises(ValueError, match="Galois key not present"):   # -4 has no key and is a single NAF term (SEAL: invalid_argument)
+        be.linear_transform_plain_many(L, [c.data for c in cts], [p.data for p in diags], elts, keys)
+    with pytest.raises(ValueError):
+        be.linear_transform_plain_many(L, [], [], elts, keys)
+    with pytest.raises(ValueError, match="bad linear-transform arguments"):   # more than 64 transforms in one call
+        be.linear_transform_plain_many(L, [cts[0].data] * 65, [diags[0].data] * 65, elts, keys)
