@@ -153,6 +153,30 @@ int main()
         CHECK(throws_invalid([&] { GaloisKeys none; Ciphertext t; evaluator.hefx_linear_transform_plain(cv, diags, none, t); },
                              "Galois key not present"),
               "hefx_linear_transform_plain: missing keys throw");
+        // three independent d = 13 transforms in lockstep (hefx_linear_transform_plain_many: CC_Matrix_Multiplication's sigma
+        // and tau transforms, matrix_multiplication.cpp:22-25) == the op-by-op body, input by input
+        {
+            Plaintext pw;
+            encoder.encode(vector<double>{-2, 0.5, 3, 7, 1, 1, 4}, scale, pw);
+            Ciphertext cw;
+            encryptor.encrypt(pw, cw);
+            vector<Plaintext> e13(13);
+            for (int l = 0; l < 13; l++) {
+                vector<double> dv(13);
+                for (int i = 0; i < 13; i++) dv[i] = 0.03 * (i + 2) - 0.02 * l;
+                encoder.encode(dv, scale, e13[l]);
+            }
+            vector<Ciphertext> many;
+            evaluator.hefx_linear_transform_plain_many({cv, cw, cv}, {d13, e13, e13}, gk, many);
+            Ciphertext r0 = lt_plain(cv, d13, gk, params), r1 = lt_plain(cw, e13, gk, params), r2 = lt_plain(cv, e13, gk, params);
+            CHECK(many.size() == 3 && shim::download(many[0].buf) == shim::download(r0.buf) &&
+                      shim::download(many[1].buf) == shim::download(r1.buf) && shim::download(many[2].buf) == shim::download(r2.buf) &&
+                      many[1].scale() == r1.scale() && many[2].parms_id() == r2.parms_id(),
+                  "hefx_linear_transform_plain_many == three op-by-op transforms, bit for bit");
+            CHECK(throws_invalid([&] { vector<Ciphertext> t; evaluator.hefx_linear_transform_plain_many({cv, cw}, {d13, diags}, gk, t); },
+                                 "encrypteds parameter mismatch"),
+                  "hefx_linear_transform_plain_many: transforms of different dimensions are refused");
+        }
     }
 
     // extensions: product sum (Linear_Transform_CipherMatrix_PlainVector in one pass) and the baby-step / giant-step

@@ -2983,6 +2983,58 @@ public:
         dest.set(out, 2, ct.rows, ct.parms_id(), ns);
     }
 
+    // ---- EXTENSION: several INDEPENDENT Linear_Transform_Plain calls of one dimension in lockstep
+    // (hefx_linear_transform_plain_many): dests[t] = Linear_Transform_Plain(cts[t], diag_sets[t], gk), e.g. the sigma transform
+    // of ctA and the tau transform of ctB in CC_Matrix_Multiplication (matrix_multiplication.cpp:22-25) -- every dependent
+    // launch sequence carries the items of all inputs; checks, exceptions and result bits of the one-transform form.
+    void hefx_linear_transform_plain_many(const std::vector<Ciphertext> &cts, const std::vector<std::vector<Plaintext>> &diag_sets,
+                                          const GaloisKeys &gk, std::vector<Ciphertext> &dests) const
+    {
+        if (cts.empty() || cts.size() != diag_sets.size() || cts.size() > 64) throw std::invalid_argument("encrypteds cannot be empty");
+        const int d = (int)diag_sets[0].size();
+        if (d < 1) throw std::invalid_argument("encrypteds cannot be empty");
+        std::vector<const std::uint64_t *> in, pts;
+        std::vector<double> ns(cts.size(), 0.0);
+        for (std::size_t t = 0; t < cts.size(); ++t) {
+            const Ciphertext &ct = cts[t];
+            check_ct(ct);
+            if (ct.size() != 2) throw std::invalid_argument("encrypted size must be 2");
+            if (ct.parms_id() != cts[0].parms_id() || (int)diag_sets[t].size() != d)
+                throw std::invalid_argument("encrypteds parameter mismatch");
+            bool first = true;
+            for (const Plaintext &p : diag_sets[t]) {
+                check_pt(ct, p);
+                const double s = ct.scale() * p.scale();
+                check_scale(s, ct.parms_id());
+                if (!first && !close(ns[t], s)) throw std::invalid_argument("scale mismatch");
+                if (first) ns[t] = s;
+                first = false;
+                if (p.is_zero()) throw std::logic_error("result ciphertext is transparent");
+                pts.push_back(p.buf->p);
+            }
+            in.push_back(ct.buf->p);
+        }
+        std::vector<std::uint32_t> plan;  // SEAL's exceptions for missing keys / too large steps
+        rotation_plan(-d, gk, plan);
+        for (int l = 1; l < d; ++l) rotation_plan(l, gk, plan);
+        std::vector<std::uint32_t> elts;
+        std::vector<const std::uint64_t *> keys;
+        for (const auto &kv : gk.keys) {
+            elts.push_back(kv.first);
+            keys.push_back(kv.second->p);
+        }
+        std::vector<shim::BufPtr> outs;
+        std::vector<std::uint64_t *> op;
+        for (std::size_t t = 0; t < cts.size(); ++t) {
+            outs.push_back(shim::new_buf(eng(), words(2, cts[0].rows)));
+            op.push_back(outs.back()->p);
+        }
+        shim::check(::hefx_linear_transform_plain_many(eng()->live(), cts[0].rows, (int)cts.size(), in.data(), d, pts.data(),
+                                                       (int)keys.size(), elts.data(), keys.data(), op.data(), nullptr));
+        dests.resize(cts.size());
+        for (std::size_t t = 0; t < cts.size(); ++t) dests[t].set(outs[t], 2, cts[0].rows, cts[0].parms_id(), ns[t]);
+    }
+
     // ---- EXTENSION: add_many(multiply_plain(cts[i], pts[i])) in one pass over the operands
     // (hefx_multiply_plain_sum) -- the body of Linear_Transform_CipherMatrix_PlainVector (helper.h:265-278) with the
     // checks, exceptions and result bits of its op-by-op form.

@@ -1276,6 +1276,25 @@ __device__ static __forceinline__ void quarter_decode(int bid, int &p, int &part
     part = 3 - ((bid >> 3) & 3);  // the inverse kernels' heaviest quarter (two twiddled stages) is dispatched first
     p = ((bid >> 5) << 3) | (bid & 7);
 }
+// (8, fan, groups) grids of the quarter / pair kernels: the `fan` workgroups of group g share XCD g % 8 (they read one
+// source row; dispatch is x-fastest).  DENSE form (a 1-D grid of groups * fan blocks; small launches whose group count is
+// not a multiple of 8, round 6): block w = g * fan + slot, consecutive blocks on consecutive XCDs.  Two digits-per-item
+// example: n = 2, L = 5 on the pair path is 10 groups x 20 workgroups -- grouped, XCDs 0 and 1 get 40 workgroups for their
+// 32 CUs (one per CU at 190 VGPRs: a second round) and the other six 20; dense, every XCD gets 25 (55 -> 44 us per call).
+__host__ static inline dim3 fan_grid(int groups, int fan)
+{
+    return (groups % 8 != 0 && groups * fan <= 1024) ? dim3((unsigned)(groups * fan)) : dim3(8, (unsigned)fan, (unsigned)((groups + 7) / 8));
+}
+__device__ static __forceinline__ void fan_decode(int fan, int &g, int &slot)
+{
+    if (gridDim.y == 1 && gridDim.z == 1) {
+        g = (int)blockIdx.x / fan;
+        slot = (int)blockIdx.x - g * fan;
+    } else {
+        slot = blockIdx.y;
+        g = blockIdx.z * 8 + blockIdx.x;
+    }
+}
 // EO position of coefficient j (rows in coefficient form are stored [evens | odds], as the split-2 kernels do)
 template <int LOGN>
 __device__ static __forceinline__ int eo_pos(int j) { return (j & 1) * (1 << (LOGN - 1)) + (j >> 1); }
@@ -1336,7 +1355,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_ntt_digits_q_kernel(De
     HEFX_STAMP_AT(0);
     // grid (8, 4 L, groups) -> (digit g = (b, i), target slot jj, quarter): dispatched x-fastest, the 4 L workgroups of a
     // digit share an XCD (and no division sits between the kernel's entry and its first table loads)
-    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    int slot, g;
+    fan_decode(4 * L, g, slot);
     int jj = slot >> 2;
     const int part = slot & 3;
     if (g >= rows) return;
@@ -1479,7 +1499,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_moddown_finish_q_kerne
     HEFX_STAMP_KERNEL(4);
     HEFX_STAMP_AT(0);
     // grid (8, 4 L, groups), dispatched x-fastest: g = remainder polynomial (b, c)
-    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    int slot, g;
+    fan_decode(4 * L, g, slot);
     const int j = slot >> 2, part = slot & 3;
     if (g >= rows) return;
     const int t = threadIdx.x;
@@ -1548,7 +1569,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_pair_digits_kernel(Dev
     if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (int)threadIdx.x < n) items_out[threadIdx.x] = small.it[threadIdx.x];
     // grid (8, 4 L, groups), dispatched x-fastest: the 4 L workgroups of digit g = (b, i) share an XCD (they all gather the
     // same source row)
-    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    int slot, g;
+    fan_decode(4 * L, g, slot);
     int jj = slot >> 2;
     const int part = slot & 3;
     if (g >= rows) return;
@@ -1734,7 +1756,8 @@ __global__ __launch_bounds__(QuarterCfg<LOGN>::T) void ks_pair_moddown_kernel(De
     HEFX_STAMP_KERNEL(3);
     HEFX_STAMP_AT(0);
     // grid (8, 4 L, groups): g = remainder polynomial (b, c); every data prime j recomputes the quarter of INTT_P it needs
-    const int slot = blockIdx.y, g = blockIdx.z * 8 + blockIdx.x;
+    int slot, g;
+    fan_decode(4 * L, g, slot);
     const int j = slot >> 2, part = slot & 3;
     if (g >= rows) return;
     const int t = threadIdx.x;
@@ -1947,13 +1970,13 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
         }
         constexpr int TQ = QuarterCfg<LOGN>::T;
         mark(1);
-        hipLaunchKernelGGL((ks_pair_digits_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, *small,
+        hipLaunchKernelGGL((ks_pair_digits_kernel<LOGN>), fan_grid(n * L, 4 * L), dim3(TQ), ldsq, s, T, *small,
                            const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
         mark(3);
         hipLaunchKernelGGL((ks_pair_mac_kernel<LOGN>), dim3(SC::N / 4 / 256, 2 * (L + 1), n), dim3(256), 0, s, T, batch, L, rl,
                            scr);
         mark(4);
-        hipLaunchKernelGGL((ks_pair_moddown_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T, L, n * 2,
+        hipLaunchKernelGGL((ks_pair_moddown_kernel<LOGN>), fan_grid(n * 2, 4 * L), dim3(TQ), ldsq, s, T, L, n * 2,
                            scr);
         mark(5);
         hipLaunchKernelGGL((ks_pair_finish_kernel<LOGN>), dim3(SC::N / 4 / 256, 2 * L, n), dim3(256), 0, s, T, batch, L, rl,
@@ -1987,7 +2010,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                                const_cast<KsItem *>(batch), n, L, rl, n * L, scr);
         mark(2);
         if (quarter & KS_Q_NTT)
-            hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), dim3(8, 4 * L, (n * L + 7) / 8), dim3(TQ), ldsq, s, T, L,
+            hipLaunchKernelGGL((ks_ntt_digits_q_kernel<LOGN>), fan_grid(n * L, 4 * L), dim3(TQ), ldsq, s, T, L,
                                n * L, scr);
         else
             hipLaunchKernelGGL((ks_ntt_digits_kernel<LOGN>), dim3(group_grid(n * L, L)), dim3(SC::T), lds_ntt, s, T, L,
@@ -2004,7 +2027,7 @@ static hipError_t launch_keyswitch_chunk_t(const DevTables &T, int L, int n, con
                                scr);
         mark(5);
         if (quarter & KS_Q_FIN)
-            hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), dim3(8, 4 * L, (n * 2 + 7) / 8), dim3(TQ), ldsq, s, T,
+            hipLaunchKernelGGL((ks_moddown_finish_q_kernel<LOGN>), fan_grid(n * 2, 4 * L), dim3(TQ), ldsq, s, T,
                                batch, L, rl, n * 2, scr);
         else
             hipLaunchKernelGGL((ks_moddown_finish_kernel<LOGN>), dim3(group_grid(n * 2, L)), dim3(SC::T), lds_fin, s, T,
