@@ -872,12 +872,15 @@ extern "C" int hefx_check_transparent(hefx_context *c, void *stream)
     return HEFX_OK;
 }
 
-extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint64_t *const *in, uint64_t *out,
-                             void *stream)
+// pt0 (engine-internal; only for n <= 2 * ADD_MANY_GROUP, the sums that skip the table level): in[0] enters the sum
+// multiplied by that plaintext
+static int add_many_impl(hefx_context *c, int L, int size, int n, const uint64_t *const *in, const uint64_t *pt0, uint64_t *out,
+                         void *stream)
 {
     CTXCHK(c);
     if (int rc = check_level(c, L)) return rc;
     if (n < 1 || size < 1 || !in || !out) return fail(HEFX_ERR_INVALID, "bad add_many arguments");
+    if (pt0 && n > 2 * ADD_MANY_GROUP) return fail(HEFX_ERR_INVALID, "internal: a fused first product needs a direct sum");
     // wide sums: one launch reduces groups of 16 through a device pointer table (a ring slot of the key-switch
     // descriptors doubles as the table), then the partials are summed below
     constexpr int TABLE_GROUP = 16;
@@ -911,9 +914,14 @@ extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint
             if (!in[base + i]) return fail(HEFX_ERR_INVALID, "null ciphertext in add_many");
             g.p[i] = (const u64 *)in[base + i];
         }
-        HIPCHK(launch_add_many(c->T, L, size, g, cnt, base > 0, (u64 *)out, (hipStream_t)stream));
+        HIPCHK(launch_add_many(c->T, L, size, g, cnt, base > 0, (u64 *)out, (hipStream_t)stream, base == 0 ? (const u64 *)pt0 : nullptr));
     }
     return HEFX_OK;
+}
+extern "C" int hefx_add_many(hefx_context *c, int L, int size, int n, const uint64_t *const *in, uint64_t *out,
+                             void *stream)
+{
+    return add_many_impl(c, L, size, n, in, nullptr, out, stream);
 }
 
 extern "C" int hefx_multiply_plain_sum(hefx_context *c, int L, int size, int n, int group,
@@ -2472,8 +2480,12 @@ static int lt_impl(hefx_context *c, int L, int count, const uint64_t *const *cts
             for (int t = 0; t < count; ++t)
                 if (int rc = hefx_add(c, L, 2, 1, cts[t], cts[t], ct_new(t), stream)) return rc;
     }
-    // ---- res[0] = ct_new * diag[0]         (helper.h:250)
-    for (int t = 0; t < count; ++t)
+    // ---- res[0] = ct_new * diag[0]         (helper.h:250): up to 96 diagonals the product is formed inside the final sum
+    // (add_many_impl's pt0: one launch and the transparency bookkeeping of hefx_multiply_plain -- 15 us between the -d
+    // rotation and the forest at d = 16, profiles/r06/lt_naf_d16_timeline_before.txt -- off the critical path); wider
+    // transforms, whose sum goes through the table level, keep the launch
+    const bool fuse0 = d <= 2 * ADD_MANY_GROUP;
+    for (int t = 0; t < count && !fuse0; ++t)
         if (int rc = hefx_multiply_plain(c, L, 2, 1, ct_new(t), diag_pts[(size_t)t * d], prod0(t), stream)) return rc;
     lap("head submitted (rotate -d + add, product 0)");
     // ---- plans -> a forest of key-switch nodes rooted at ct_new, deduplicated per (parent, element, fused diagonal)
@@ -2532,9 +2544,9 @@ static int lt_impl(hefx_context *c, int L, int count, const uint64_t *const *cts
     std::vector<const uint64_t *> res(d);
     int rc = HEFX_OK;
     for (int t = 0; t < count && rc == HEFX_OK; ++t) {
-        res[0] = prod0(t);
+        res[0] = fuse0 ? ct_new(t) : prod0(t);
         for (int l = 1; l < d; ++l) res[l] = node_ptr(t, leaf[l]);
-        rc = hefx_add_many(c, L, 2, d, res.data(), outs[t], stream);
+        rc = add_many_impl(c, L, 2, d, res.data(), fuse0 ? diag_pts[(size_t)t * d] : nullptr, outs[t], stream);
     }
     lap("add_many submitted");
     return rc;

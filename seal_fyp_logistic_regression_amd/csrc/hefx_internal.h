@@ -121,8 +121,9 @@ enum EwOp { EW_ADD = 0, EW_SUB = 1, EW_NEG = 2, EW_MULPLAIN = 3, EW_ADDPLAIN = 4
 // For MULPLAIN/ADDPLAIN b is a plaintext [L][N] (per ciphertext stride 0).
 hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int count, const u64 *a,
                               const u64 *b, u64 *out, int *flag, hipStream_t s);
+// pt0 != nullptr (first group only): the first addend is g.p[0] (.) pt0
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
-                           u64 *out, hipStream_t s);
+                           u64 *out, hipStream_t s, const u64 *pt0 = nullptr);
 hipError_t launch_add_many_table(const DevTables &T, int L, int size, const u64 *const *d_ptrs, int n, int group,
                                  u64 *partial, hipStream_t s);
 // table: n ciphertext pointers | n plaintext pointers | ceil(n/group) output pointers (device memory)

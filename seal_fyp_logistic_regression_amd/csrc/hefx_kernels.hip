@@ -195,16 +195,27 @@ hipError_t launch_elementwise(const DevTables &T, EwOp op, int L, int size, int 
 }
 
 // add_many: out = (accumulate ? out : 0) + sum_{i<n} in[i]   (n <= ADD_MANY_GROUP pointers by value)
+// pt0 != nullptr: the FIRST addend is in[0] (.) pt0 (multiply_plain, plaintext [L][N]) -- Linear_Transform_Plain's
+// res[0] = ct_new * diag[0] (helper.h:250) formed inside its final sum (:259) instead of by a launch of its own
 __global__ __launch_bounds__(256) void add_many_kernel(DevTables T, int L, size_t total_pairs, PtrGroup g, int n,
-                                                       int accumulate, ulonglong2 *__restrict__ out)
+                                                       int accumulate, const ulonglong2 *__restrict__ pt0,
+                                                       ulonglong2 *__restrict__ out)
 {
     const int logn = T.logn;
     for (size_t w = (size_t)blockIdx.x * blockDim.x + threadIdx.x; w < total_pairs;
          w += (size_t)gridDim.x * blockDim.x) {
         const size_t row = w >> (logn - 1);
-        const u64 q = T.mods[(int)(row % (size_t)L)].q;
+        const int j = (int)(row % (size_t)L);
+        const u64 q = T.mods[j].q;
         ulonglong2 acc = accumulate ? out[w] : make_ulonglong2(0, 0);
-        for (int i = 0; i < n; ++i) {
+        if (pt0) {  // (workgroup-uniform)
+            const ModConst mc = T.mods[j];
+            const ulonglong2 x = gld16(g.p[0] + 2 * w);
+            const ulonglong2 y = pt0[((size_t)j << (logn - 1)) + (w & (((size_t)1 << (logn - 1)) - 1))];
+            acc.x = addmod(acc.x, mulmod(x.x, y.x, mc), q);
+            acc.y = addmod(acc.y, mulmod(x.y, y.y, mc), q);
+        }
+        for (int i = pt0 ? 1 : 0; i < n; ++i) {
             ulonglong2 x = gld16(g.p[i] + 2 * w);
             acc.x = addmod(acc.x, x.x, q);
             acc.y = addmod(acc.y, x.y, q);
@@ -313,13 +324,13 @@ hipError_t launch_mulplain_sum(const DevTables &T, int L, int size, const u64 *c
 }
 
 hipError_t launch_add_many(const DevTables &T, int L, int size, const PtrGroup &g, int n, bool accumulate,
-                           u64 *out, hipStream_t s)
+                           u64 *out, hipStream_t s, const u64 *pt0)
 {
     const size_t total_pairs = (size_t)size * L * ((size_t)1 << T.logn) / 2;
     int blocks = (int)((total_pairs + 255) / 256);
     if (blocks > 256 * 8) blocks = 256 * 8;
     hipLaunchKernelGGL(add_many_kernel, dim3(blocks), dim3(256), 0, s, T, L, total_pairs, g, n, accumulate ? 1 : 0,
-                       reinterpret_cast<ulonglong2 *>(out));
+                       reinterpret_cast<const ulonglong2 *>(pt0), reinterpret_cast<ulonglong2 *>(out));
     return hipGetLastError();
 }
 

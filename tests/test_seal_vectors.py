@@ -125,7 +125,8 @@ def test_generator_built_against_the_shim_roundtrips_through_the_format(tmp_path
         assert (vec.N, vec.k) == (n, k) and not vec.from_real_seal and "shim" in vec.producer
         for impl in (O.Oracle(vec.N, vec.primes), SV.EngineImpl(vec.N, vec.primes)):
             res = SV.check(vec, impl)
-            assert res.pop("rescale_mode") == "floor"      # the engine's default division
+            # the engine's default division: round-to-nearest since round 6 unless the knob says floor
+            assert res.pop("rescale_mode") == ("floor" if os.environ.get("SEAL_SHIM_RESCALE") == "floor" else "round")
             assert all(res.values()), (name, type(impl).__name__, {k_: v for k_, v in res.items() if not v})
         # the save() streams the shim wrote, against the layouts restated in tests/seal_vectors.py (SEAL 3.4.5's, "format
         # unpinned"): parms_id = SHA3-256 of the parameter words, header fields, the words of `ct`, the key-set framing
