@@ -1147,7 +1147,10 @@ static int ks_small_shape(int n, int L)
     if (qmask_force >= 0) return qmask_force & (KS_Q_ALL | KS_Q_PAIR);
     if (pair_force > 0 || (pair_force < 0 && quarter_force < 0 && n * L * L * 4 <= pair_max)) return KS_Q_PAIR;
     if (quarter_force >= 0) return quarter_force ? KS_Q_ALL : 0;
-    return (n * L * 4 <= 256 ? KS_Q_INTT : 0) | (n * L * L * 4 <= 256 ? KS_Q_NTT : 0) | (n * 2 * 4 <= 192 ? KS_Q_MDI : 0) |
+    // (round 6: all 16 masks over n = 6..32, L = 3..8 -- tools/qmask_sweep.py, profiles/r06/qmask_sweep.txt: this rule is within
+    // 1-2 us of the best mask at every point; the mod-down inverse on quarter rows up to 256 workgroups, i.e. n = 32, now
+    // measures 3 us better than split rows there)
+    return (n * L * 4 <= 256 ? KS_Q_INTT : 0) | (n * L * L * 4 <= 256 ? KS_Q_NTT : 0) | (n * 2 * 4 <= 256 ? KS_Q_MDI : 0) |
            (n * 2 * L * 4 <= 320 ? KS_Q_FIN : 0);
 }
 

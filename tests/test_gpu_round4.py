@@ -62,6 +62,15 @@ def test_bench_two_ranks_one_json_line_and_sharded_bits():
     assert line["secondary"] == {}
     assert line["sustained"]["steps"] >= 2 and line["sustained"]["value"] > 0
     assert len(line["libhefx_sha16"]) == 16 and len(line["csrc_sha16"]) == 16 and line["rescale_mode"] in ("floor", "round")
+    # round 6: SURVEY 8(d)'s scaling workloads ride in the same line -- serial and sharded, the sharded bits asserted equal
+    comp = line["composites"]
+    assert set(comp) == {"matmul_C3_n4", "matmul_C5_n8", "lr_rows_2000x8"}, comp
+    for name, rec in comp.items():
+        assert rec["bits_equal_serial"] is True and rec["serial_ms"] > 0 and rec["sharded_ms"] > 0, (name, rec)
+    assert comp["matmul_C3_n4"]["decrypts_to_AB"] is True and comp["matmul_C5_n8"]["decrypts_to_AB"] is True
+    assert comp["lr_rows_2000x8"]["decrypts_to_sigmoid_of_Xw"] is True
+    assert [r["batch"] for r in line["batch_ladder"]] == [1, 16, 256]   # (--batch 512: the ladder stops below it)
+    assert line["chain_level_us"]["n1"] > 0 and line["chain_level_us"]["n8"] > 0
 
 
 def test_bench_two_ranks_a_dead_rank_ends_the_run_non_zero():
