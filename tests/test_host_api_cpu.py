@@ -339,6 +339,68 @@ def test_shared_rotations_in_the_matrix_product_keep_the_bits_of_the_per_transfo
         assert a.parms_id() == b.parms_id() and a.scale == b.scale and (a.data == b.data).all()
 
 
+class _ForestTwin(OracleBackend):
+    """The oracle twin with the two engine entry points the lockstep composites look for -- a multi-root rotation forest and
+    the many-input linear transform -- each stated node by node / input by input on the oracle, so that the HOST logic of
+    algorithms._rotations_of_many / _linear_transforms_of_inputs / linear_transforms_plain_many (forest construction, leaf
+    bookkeeping, grouping of the product sums) runs on the CPU."""
+    calls = 0
+
+    def apply_galois_forest(self, L, parents, ext_ins, elts, keys, pts=None):
+        type(self).calls += 1
+        outs = []
+        for i, p in enumerate(parents):
+            assert p < i
+            src = ext_ins[i] if p < 0 else outs[p]
+            r = self.apply_galois_batch(L, [src], [elts[i]], [keys[i]])[0]
+            if pts is not None and pts[i] is not None:
+                r = self.multiply_plain(L, 2, r, pts[i])
+            outs.append(r)
+        return outs
+
+
+def test_lockstep_transforms_of_several_inputs_keep_the_bits_of_the_loops():
+    """Round 6: CC_Matrix_Multiplication runs the sigma / tau transforms and the V_k / W_k families in lockstep (one rotation
+    forest with two roots).  On a backend that offers the forest entry the merged composition must give the ciphertext
+    bits of the per-input loops -- and of the whole product as the plain twin computes it."""
+    n = 3
+    scale = 2.0 ** 40
+    rng = np.random.default_rng(9)
+    A, B = rng.standard_normal((n, n)), rng.standard_normal((n, n))
+    Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+
+    def run(backend_cls):
+        parms = S.EncryptionParameters("ckks")
+        parms.set_poly_modulus_degree(4096)
+        parms.set_coeff_modulus(S.CoeffModulus.Create(4096, [60, 40, 40, 40, 40, 60]))
+        ctx = S.SEALContext.Create(parms, backend=backend_cls(4096, parms.coeff_modulus()))
+        kg = S.KeyGenerator(ctx, 4)
+        enc, encoder, ev, gk = S.Encryptor(ctx, kg.public_key(), 5), S.CKKSEncoder(ctx), S.Evaluator(ctx), kg.galois_keys()
+        dense = lambda U: [encoder.encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)]
+        ctA, ctB = enc.encrypt(encoder.encode(A.reshape(-1), scale)), enc.encrypt(encoder.encode(B.reshape(-1), scale))
+        a0 = alg.linear_transform_plain(ev, ctA, dense(Us), gk)
+        b0 = alg.linear_transform_plain(ev, ctB, dense(Ut), gk)
+        Vd, Wd = [dense(v) for v in V], [dense(w) for w in W]
+        merged = alg._linear_transforms_of_inputs(ev, [a0, b0], [Vd, Wd], gk)
+        loops = [alg._linear_transforms_of_one_input(ev, a0, Vd, gk), alg._linear_transforms_of_one_input(ev, b0, Wd, gk)]
+        rots = alg._rotations_of_many(ev, [a0, b0], [1, 3, -2, 5], gk)
+        prod = alg.cc_matrix_multiplication(ev, ctA, ctB, n, dense(Us), dense(Ut), Vd, Wd, gk)
+        return merged, loops, rots, [[ev.rotate_vector(c, s, gk) for s in (1, 3, -2, 5)] for c in (a0, b0)], prod
+
+    _ForestTwin.calls = 0
+    merged, loops, rots, rot_ref, prod = run(_ForestTwin)
+    assert _ForestTwin.calls >= 3   # the merged paths were taken (two forests in _linear_transforms_of_inputs, one in _rotations_of_many, ...)
+    for fam_m, fam_l in zip(merged, loops):
+        assert len(fam_m) == len(fam_l) == n - 1
+        for a, b in zip(fam_m, fam_l):
+            assert a.parms_id() == b.parms_id() and a.scale == b.scale and (a.data == b.data).all()
+    for rr, ref in zip(rots, rot_ref):
+        for a, b in zip(rr, ref):
+            assert a.scale == b.scale and (a.data == b.data).all()
+    *_, prod_plain = run(OracleBackend)          # no forest entry: the per-input paths
+    assert prod.size() == prod_plain.size() == 3 and prod.scale == prod_plain.scale and (prod.data == prod_plain.data).all()
+
+
 @pytest.mark.parametrize("size", [8, 5, 7])
 def test_log_depth_window_sum_gives_the_same_dot_products(size):
     """cipher_dot_product_many(log_sum=True): about log2(size) rotations instead of size-1; slots 0..size-1 carry the
