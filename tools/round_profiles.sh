@@ -6,13 +6,13 @@
 out=${1:-gpurun_out/round}; mkdir -p $out
 export TMPDIR=/tmp
 python bench.py > $out/bench.json 2> $out/bench.err
-python bench.py --set C2 --batch 9216 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= > $out/bench_C2.json 2>/dev/null
-python bench.py --set C4 --batch 2304 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= > $out/bench_C4.json 2>/dev/null
-python bench.py --set C5 --batch 2304 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= > $out/bench_C5.json 2>/dev/null
+python bench.py --set C2 --batch 9216 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= --composites= --ladder= > $out/bench_C2.json 2>/dev/null
+python bench.py --set C4 --batch 2304 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= --composites= --ladder= > $out/bench_C4.json 2>/dev/null
+python bench.py --set C5 --batch 2304 --cpu-seconds 0 --lt= --lt-direct 0 --key-per-item 0 --secondary= --composites= --ladder= > $out/bench_C5.json 2>/dev/null
 for set in C3 C2; do
   case $set in C3) b=4608; per=256;; C2) b=9216; per=512;; esac
-  B="--set $set --batch $b --steps 5 --warmup 1 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --key-per-item 0 --lt-direct 0 --secondary= --sustain 0 --lt="
-  P="--set $set --batch $b --steps 2 --warmup 0 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --key-per-item 0 --lt-direct 0 --secondary= --sustain 0 --lt="
+  B="--set $set --batch $b --steps 5 --warmup 1 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --key-per-item 0 --lt-direct 0 --secondary= --sustain 0 --lt= --composites= --ladder="
+  P="--set $set --batch $b --steps 2 --warmup 0 --cpu-seconds 0 --variant-keys 0 --stream-keys 0 --key-per-item 0 --lt-direct 0 --secondary= --sustain 0 --lt= --composites= --ladder="
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/kt_$set -o kt -- python3 bench.py $B > /dev/null 2> $out/kt_$set.err
   HEFX_STREAMS=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kts_$set -o kts -- python3 bench.py $B > /dev/null 2> $out/kts_$set.err
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/pf_$set -o pf -- python3 bench.py $P > /dev/null 2> $out/pf_$set.err
