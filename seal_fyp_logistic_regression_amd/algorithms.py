@@ -467,33 +467,54 @@ def _linear_transforms_of_one_input(ev: Evaluator, ct: Ciphertext, diag_sets: Se
     return ev.multiply_plain_sum(terms_ct, terms_pt, group=d)        # :250, :256, :259
 
 
-def _rotations_of_many(ev: Evaluator, cts: Sequence[Ciphertext], steps: Sequence[int],
-                       gal_keys: KSwitchKeys) -> List[List[Ciphertext]]:
+def _rotations_of_many(ev: Evaluator, cts: Sequence[Ciphertext], steps: Sequence[int], gal_keys: KSwitchKeys,
+                       pts_per_input: Sequence[Sequence[Plaintext]] = None) -> List[List[Ciphertext]]:
     """[[rotate_vector(ct, l) for l in steps] for ct in cts] with the NAF forests of all inputs in ONE engine call
     (hefx_apply_galois_forest takes any number of roots): the depths of the forests run side by side, so k inputs cost the
-    dependent launch sequences of one.  Backends without the forest entry, a single input or a zero step take the
-    per-input path."""
+    dependent launch sequences of one.  pts_per_input[t][i] (optional): multiply_plain of input t's rotation by steps[i],
+    fused into the last key switch of its plan, with the checks of the op-by-op product (as _rotations_batched does for one
+    input).  Backends without the forest entry, a single input or a zero step take the per-input path."""
     be = ev.be
-    if len(cts) < 2 or not hasattr(be, "apply_galois_forest") or any(s == 0 for s in steps) or \
+    if len(cts) < 2 or not hasattr(be, "apply_galois_forest") or any(s == 0 for s in steps) or not steps or \
             len({c.parms_id() for c in cts}) != 1 or any(c.size() != 2 for c in cts):
-        return [_rotations_batched(ev, c, steps, gal_keys) for c in cts]
+        return [_rotations_batched(ev, c, steps, gal_keys, pts_per_input[t] if pts_per_input is not None else None)
+                for t, c in enumerate(cts)]
     L = cts[0].parms_id()
     plans = [ev.rotation_plan(s, gal_keys) for s in steps]
-    parents, ext, elts = [], [], []
+    parents, ext, elts, node_pts = [], [], [], []
     leaf = [[-1] * len(plans) for _ in cts]
     for t, ct in enumerate(cts):
         index = {}
         for i, p in enumerate(plans):
             c = -1
-            for elt in p:
-                j = index.get((c, elt))
+            for depth, elt in enumerate(p):
+                fuse = pts_per_input is not None and depth == len(p) - 1
+                key = (c, elt, i if fuse else -1)
+                j = index.get(key)
                 if j is None:
-                    j = index[(c, elt)] = len(parents)
+                    j = index[key] = len(parents)
                     parents.append(c), ext.append(ct.data if c < 0 else None), elts.append(elt)
+                    node_pts.append(pts_per_input[t][i].data if fuse else None)
                 c = j
             leaf[t][i] = c
-    outs = be.apply_galois_forest(L, parents, ext, elts, [gal_keys.key(e) for e in elts], None)
-    return [[Ciphertext()._set(outs[j], 2, L, ct.scale) for j in leaf[t]] for t, ct in enumerate(cts)]
+    outs = be.apply_galois_forest(L, parents, ext, elts, [gal_keys.key(e) for e in elts],
+                                  node_pts if pts_per_input is not None else None)
+    res = []
+    for t, ct in enumerate(cts):
+        row = []
+        for i, j in enumerate(leaf[t]):
+            scale = ct.scale
+            if pts_per_input is not None:
+                p = pts_per_input[t][i]
+                scale *= p.scale
+                ev._check_scale(scale, L)
+                if p.parms_id() != L:
+                    raise ValueError("encrypted_ntt and plain_ntt parameter mismatch")
+                if p.is_zero:
+                    raise RuntimeError("result ciphertext is transparent")
+            row.append(Ciphertext()._set(outs[j], 2, L, scale))
+        res.append(row)
+    return res
 
 
 def _linear_transforms_of_inputs(ev: Evaluator, cts: Sequence[Ciphertext],

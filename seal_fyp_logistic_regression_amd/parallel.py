@@ -213,6 +213,36 @@ def linear_transform_plain_sharded(ev: Evaluator, ct: Ciphertext, U_diagonals: S
     return allreduce_ciphertext(ev, partial, group)
 
 
+def linear_transforms_plain_sharded_many(ev: Evaluator, cts: Sequence[Ciphertext],
+                                         diag_sets: Sequence[Sequence[Plaintext]], gal_keys: KSwitchKeys,
+                                         group=None) -> List[Ciphertext]:
+    """[linear_transform_plain_sharded(ct, diags) for ct, diags] for INDEPENDENT transforms of one dimension (the sigma / tau
+    transforms of CC_Matrix_Multiplication, matrix_multiplication.cpp:22-25) with this rank's share of BOTH in lockstep:
+    the -d rotations as one batch, the rank's diagonals of every input in one rotation forest (alg._rotations_of_many), then
+    one all-reduce per transform.  Per transform the operations of linear_transform_plain_sharded: same bits."""
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    d = len(diag_sets[0]) if diag_sets else 0
+    if len(cts) < 2 or any(len(ds) != d for ds in diag_sets):
+        return [linear_transform_plain_sharded(ev, c, ds, gal_keys, group) for c, ds in zip(cts, diag_sets)]
+    dup = alg._rotations_of_many(ev, cts, [-d], gal_keys)                          # replicated: helper.h:244
+    ct_news = [ev.add(c, r[0]) for c, r in zip(cts, dup)]                          # :247
+    mine = list(shard(d, rank, world))
+    steps = [l for l in mine if l > 0]
+    prods = alg._rotations_of_many(ev, ct_news, steps, gal_keys, [[ds[l] for l in steps] for ds in diag_sets]) \
+        if steps else [[] for _ in cts]
+    outs = []
+    for ct_new, ds, pr in zip(ct_news, diag_sets, prods):
+        res = ([ev.multiply_plain(ct_new, ds[0])] if 0 in mine else []) + list(pr)
+        if res:
+            partial = ev.add_many(res)
+        else:  # more ranks than diagonals: the zero ciphertext at the right level / scale
+            z = ev.multiply_plain(ct_new, ds[0])
+            partial = ev.sub(z, z)
+        outs.append(allreduce_ciphertext(ev, partial, group))
+    return outs
+
+
 def _zero_like(ev: Evaluator, ct: Ciphertext) -> Ciphertext:
     """the zero ciphertext at ct's size / level / scale (a rank's contribution when it owns no unit)"""
     return ev.sub(ct, ct)
@@ -229,13 +259,15 @@ def cc_matrix_multiplication_sharded(ev: Evaluator, ctA: Ciphertext, ctB: Cipher
     addition is associative and commutative, so the bits equal the serial order of :123-129."""
     import torch.distributed as dist
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    ctA0 = linear_transform_plain_sharded(ev, ctA, U_sigma, gal_keys, group)      # :22
-    ctB0 = linear_transform_plain_sharded(ev, ctB, U_tau, gal_keys, group)        # :25
+    ctA0, ctB0 = linear_transforms_plain_sharded_many(ev, [ctA, ctB], [U_sigma, U_tau], gal_keys, group)   # :22, :25
     mine = list(shard(dimension - 1, rank, world))
-    # this rank's transforms of ctA0 / ctB0 share the rotations of their input (alg._linear_transforms_of_one_input, as the
-    # serial form does for all n-1): same bits as transform by transform, 1 / len(mine) of the key switches
-    ctAk = alg._linear_transforms_of_one_input(ev, ctA0, [V_diagonals[k] for k in mine], gal_keys)   # :42
-    ctBk = alg._linear_transforms_of_one_input(ev, ctB0, [W_diagonals[k] for k in mine], gal_keys)   # :43
+    # this rank's transforms of ctA0 / ctB0 share the rotations of their inputs, and the two inputs run in lockstep
+    # (alg._linear_transforms_of_inputs, as the serial form does for all n-1): same bits as transform by transform
+    if mine:
+        ctAk, ctBk = alg._linear_transforms_of_inputs(ev, [ctA0, ctB0], [[V_diagonals[k] for k in mine],
+                                                                          [W_diagonals[k] for k in mine]], gal_keys)   # :42, :43
+    else:
+        ctAk, ctBk = [], []
     ev.rescale_to_next_many_inplace(ctAk)                                          # :69-73
     ev.rescale_to_next_many_inplace(ctBk)
     ctAB = ev.multiply(ctA0, ctB0)                                                 # :104

@@ -384,6 +384,14 @@ def test_lockstep_transforms_of_several_inputs_keep_the_bits_of_the_loops():
         merged = alg._linear_transforms_of_inputs(ev, [a0, b0], [Vd, Wd], gk)
         loops = [alg._linear_transforms_of_one_input(ev, a0, Vd, gk), alg._linear_transforms_of_one_input(ev, b0, Wd, gk)]
         rots = alg._rotations_of_many(ev, [a0, b0], [1, 3, -2, 5], gk)
+        # ... and with the plaintext product fused into the last key switch of every plan (the sharded transforms' form)
+        pts = [[Vd[0][l] for l in (1, 3, 2, 5)], [Wd[0][l] for l in (1, 3, 2, 5)]]
+        fused = alg._rotations_of_many(ev, [a0, b0], [1, 3, -2, 5], gk, pts)
+        fused_ref = [[ev.multiply_plain(ev.rotate_vector(c, s, gk), p) for s, p in zip((1, 3, -2, 5), pp)]
+                     for c, pp in zip((a0, b0), pts)]
+        for rr, ref in zip(fused, fused_ref):
+            for x, y in zip(rr, ref):
+                assert x.scale == y.scale and (x.data == y.data).all()
         prod = alg.cc_matrix_multiplication(ev, ctA, ctB, n, dense(Us), dense(Ut), Vd, Wd, gk)
         return merged, loops, rots, [[ev.rotate_vector(c, s, gk) for s in (1, 3, -2, 5)] for c in (a0, b0)], prod
 
