@@ -141,12 +141,15 @@ def test_cc_matrix_multiplication_n8_config5_dense_bit_exact(rescale_mode):
     assert np.allclose(got, A @ B, rtol=1e-4, atol=1e-3), np.abs(got - A @ B).max()
 
 
-@pytest.mark.parametrize("setname,d,count,direct", [("C2", 9, 3, False), ("C3", 16, 2, False), ("C3", 40, 2, True), ("C2", 5, 5, False)])
+@pytest.mark.parametrize("setname,d,count,direct", [("C2", 9, 3, False), ("C3", 16, 2, False), ("C3", 40, 2, True), ("C2", 5, 5, False),
+                                                   ("C2", 1, 2, False), ("C2", 2, 3, False), ("C2", 100, 2, False)])
 def test_linear_transform_plain_many_bit_exact(setname, d, count, direct):
     """hefx_linear_transform_plain_many: `count` independent Linear_Transform_Plain calls in lockstep (the sigma / tau
     transforms of CC_Matrix_Multiplication, matrix_multiplication.cpp:22-25) -- every output word for word what the
     single-transform entry gives for that input, and what the oracle twin's op-by-op sequence gives; with the reference's
-    default keys (NAF forests) and with a direct key per step (the wide depth runs exactly hoisted per source)."""
+    default keys (NAF forests) and with a direct key per step (the wide depth runs exactly hoisted per source); d = 1 (no
+    rotation below ct_new), d = 2, and d = 100 (beyond 96 diagonals the first product is a launch of its own and the final sum
+    goes through its table level)."""
     from seal_fyp_logistic_regression_amd import algorithms as alg
     from tests.test_gpu_composites import make, bits, decode
     N, bits_ = {"C2": (8192, [60, 40, 40, 60]), "C3": (16384, [60, 40, 40, 40, 40, 60])}[setname]
