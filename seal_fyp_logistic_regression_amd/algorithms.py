@@ -437,8 +437,7 @@ def _matmul_step3(ev: Evaluator, ctA0: Ciphertext, ctB0: Ciphertext, ctAk: List[
     """matrix_multiplication.cpp:69-129: rescale the 2(n-1) transforms, A0*B0 + sum_k A_k*B_k.  The rescales and the
     products of the n-1 pairs are independent, so each kind is one launch over its list; the chain of add_inplace
     (:128) is one n-way sum -- canonical residues of the same integers, hence the same bits."""
-    ev.rescale_to_next_many_inplace(ctAk)                            # :69-73
-    ev.rescale_to_next_many_inplace(ctBk)
+    ev.rescale_to_next_many_inplace(list(ctAk) + list(ctBk))         # :69-73 (one launch pair over both families)
     ctAB = ev.multiply(ctA0, ctB0)                                   # :104
     ev.mod_switch_to_next_inplace(ctAB)                              # :112
     for c in ctAk + ctBk:
