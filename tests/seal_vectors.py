@@ -37,6 +37,10 @@ class VectorFile:
     def has(self, tag) -> bool:
         return any(r.tag == tag for r in self.records)
 
+    def all(self, tag) -> List[Record]:
+        """the records of a list (tools/gen_composite_vectors.cpp: the index rides in aux), in index order"""
+        return sorted((r for r in self.records if r.tag == tag), key=lambda r: r.aux)
+
     def ct(self, tag) -> np.ndarray:
         r = self.get(tag)
         assert r.kind == KIND_CT
@@ -101,6 +105,16 @@ def write(path: str, N: int, primes, producer: str, records: List[Record]):
 
 
 def golden_files() -> List[str]:
+    """files of tools/gen_seal_vectors.cpp (Evaluator members)"""
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "seal_*.bin")))
+
+
+def golden_composite_files() -> List[str]:
+    """files of tools/gen_composite_vectors.cpp (the reference's own composite functions)"""
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "composites_*.bin")))
+
+
+def all_golden_files() -> List[str]:
     return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.bin")))
 
 
@@ -244,3 +258,94 @@ def check_streams(vec: VectorFile) -> Dict[str, bool]:
         ok = found[e1].size == vec.key("gk", e1).size
     out["gk1_stream"] = bool(ok)
     return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# Composite files (tools/gen_composite_vectors.cpp, drivers/xcheck_lr.cpp): the answers are the results of the REFERENCE'S
+# OWN functions (helper.h, matrix_multiplication.cpp, logistic_regression_ckks.cpp, compiled from where they lie); the
+# replay below sends the file's inputs through this repository's composition, seal_fyp_logistic_regression_amd/algorithms.py,
+# on the HIP engine ("gpu") or on the CPU oracle ("oracle")
+# ------------------------------------------------------------------------------------------------------------------
+class CompositeSide:
+    """seal.py containers over one backend, filled from a vector file"""
+
+    def __init__(self, vec: VectorFile, kind: str, rounded: bool):
+        from seal_fyp_logistic_regression_amd import seal as S
+        parms = S.EncryptionParameters("ckks")
+        parms.set_poly_modulus_degree(vec.N)
+        parms.set_coeff_modulus(vec.primes)
+        self.S, self.vec, self.kind = S, vec, kind
+        backend = None
+        if kind == "oracle":
+            from tests.oracle_backend import OracleBackend
+            backend = OracleBackend(vec.N, vec.primes)
+        self.ctx = S.SEALContext.Create(parms, backend=backend)
+        self.be, self.ev = self.ctx.backend, S.Evaluator(self.ctx)
+        self.be.rescale_rounded = bool(rounded)
+        # device encode on the engine (the shim's CKKSEncoder is the same entry point), host encode on the oracle
+        self.encoder = S.CKKSEncoder(self.ctx, device_encode=kind != "oracle")
+        self.gk, self.rk = S.KSwitchKeys(), S.KSwitchKeys()
+        for r in vec.records:
+            if r.kind == KIND_KEY:
+                assert r.size == vec.k - 1 and r.rows == vec.k, "key layout is not [k-1][2][k][N]"
+                (self.rk if r.tag == "rk" else self.gk).keys[r.aux] = self.be.from_host(r.words.reshape(vec.k - 1, 2, vec.k, vec.N))
+
+    def ct(self, rec: Record):
+        return self.S.Ciphertext()._set(self.be.from_host(rec.words.reshape(rec.size, rec.rows, self.vec.N)), rec.size, rec.rows, rec.scale)
+
+    def pt(self, rec: Record):
+        p = self.S.Plaintext()
+        p.data, p._parms_id, p.scale = self.be.from_host(rec.words.reshape(rec.rows, self.vec.N)), rec.rows, rec.scale
+        return p
+
+    def cts(self, tag):
+        return [self.ct(r) for r in self.vec.all(tag)]
+
+    def pts(self, tag):
+        return [self.pt(r) for r in self.vec.all(tag)]
+
+    def same(self, got, rec: Record) -> bool:
+        """size, level, scale and every word"""
+        if (got.size(), got.parms_id()) != (rec.size, rec.rows) or got.scale != rec.scale:
+            return False
+        words = self.be.to_host(got.data).reshape(-1)
+        return bool(words.shape == rec.words.shape and (words == rec.words).all())
+
+
+def check_composites(vec: VectorFile, kind: str, rounded: bool) -> Dict[str, bool]:
+    """-> {answer tag: equal?} for every composite answer the file holds (sets c2 / c3 of tools/gen_composite_vectors.cpp).
+    C_Matrix_Decode encodes its masks inside the function: on the oracle side the masks come from the host encoder, which
+    may differ from SEAL's / the engine's in a last bit of a coefficient, so `dec_row` is replayed on the engine only."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    s = CompositeSide(vec, kind, rounded)
+    res: Dict[str, bool] = {}
+    for name in ("lt4", "lt16"):
+        if vec.has(name + "_plain"):
+            res[name + "_plain"] = s.same(alg.linear_transform_plain(s.ev, s.ct(vec.get(name + "_ct")), s.pts(name + "_diag"), s.gk),
+                                          vec.get(name + "_plain"))
+    if vec.has("lt4_cipher"):
+        cdiags = s.cts("lt4_cdiag")
+        res["lt4_cipher"] = s.same(alg.linear_transform_cipher(s.ev, s.ct(vec.get("lt4_ct")), cdiags, s.gk), vec.get("lt4_cipher"))
+        res["lt4_cmpv"] = s.same(alg.linear_transform_ciphermatrix_plainvector(s.ev, s.pts("lt4_ptrot"), cdiags), vec.get("lt4_cmpv"))
+    if vec.has("enc_packed"):
+        res["enc_packed"] = s.same(alg.c_matrix_encode(s.ev, s.cts("enc_row"), s.gk), vec.get("enc_packed"))
+        if kind != "oracle":
+            rows = vec.all("dec_row")
+            back = alg.c_matrix_decode(s.ev, s.encoder, s.ct(vec.get("enc_packed")), len(rows), vec.get("enc_row").scale, s.gk)
+            res["dec_row"] = len(back) == len(rows) > 0 and all(s.same(g, r) for g, r in zip(back, rows))
+    if vec.has("dot"):
+        res["dot"] = s.same(alg.cipher_dot_product(s.ev, s.ct(vec.get("dot_a")), s.ct(vec.get("dot_b")), 8, s.rk, s.gk), vec.get("dot"))
+    if vec.has("pow"):
+        recs = vec.all("pow")
+        powers = alg.compute_all_powers(s.ev, s.ct(vec.get("pow_ct")), max(r.aux for r in recs), s.rk)
+        res["pow"] = all(s.same(powers[r.aux], r) for r in recs)
+    if vec.has("mm_out"):
+        usig = s.pts("mm_usig")
+        n = int(round(len(usig) ** 0.5))
+        v, w = s.pts("mm_v"), s.pts("mm_w")
+        assert len(usig) == n * n and len(v) == len(w) == (n - 1) * n * n
+        V = [v[k * n * n:(k + 1) * n * n] for k in range(n - 1)]
+        W = [w[k * n * n:(k + 1) * n * n] for k in range(n - 1)]
+        out = alg.cc_matrix_multiplication(s.ev, s.ct(vec.get("mm_a")), s.ct(vec.get("mm_b")), n, usig, s.pts("mm_utau"), V, W, s.gk)
+        res["mm_out"] = s.same(out, vec.get("mm_out"))
+    return res
