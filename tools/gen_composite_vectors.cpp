@@ -38,6 +38,7 @@
 //     mm_a, mm_b, mm_usig[16], mm_utau[16], mm_v[3*16] (aux = 16 (k-1) + i), mm_w[3*16], mm_out = CC_Matrix_Multiplication (n = 4)
 #include <unistd.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -101,8 +102,12 @@ void put_galois_keys(Writer &w, const GaloisKeys &gk, std::size_t n)
         elts.push_back(elt_from_step(-(long long)s, n));
     }
     elts.push_back((std::uint32_t)(2 * n - 1));
-    for (std::uint32_t e : elts)
-        if (gk.has_key(e)) put_key(w, "gk", gk.key(e), e);
+    std::vector<std::uint32_t> done;  // steps +N/4 and -N/4 are one element
+    for (std::uint32_t e : elts) {
+        if (!gk.has_key(e) || std::find(done.begin(), done.end(), e) != done.end()) continue;
+        put_key(w, "gk", gk.key(e), e);
+        done.push_back(e);
+    }
 }
 
 void generate_c2(const std::string &dir)
