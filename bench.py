@@ -1011,11 +1011,11 @@ def main():
 
         def bail():  # the headline line still goes out, but a wedged exchange is a FAILED run: exit 3 on every rank
             if rank == 0:
-                line["lt_sharded"] = {"error": "timed out after 300 s (the headline measurement is unaffected)"}
+                line["lt_sharded"] = {"error": "timed out after 180 s (the headline measurement is unaffected)"}
                 emit()
             os._exit(3)
 
-        dog = threading.Timer(300.0, bail)
+        dog = threading.Timer(180.0, bail)
         dog.daemon = True
         dog.start()
         try:
@@ -1033,11 +1033,11 @@ def main():
 
         def bail2():
             if rank == 0:
-                line["composites"] = {"error": "timed out after 600 s (the headline measurement is unaffected)"}
+                line["composites"] = {"error": "timed out after 300 s (the headline measurement is unaffected)"}
                 emit()
             os._exit(3)
 
-        dog = threading.Timer(600.0, bail2)
+        dog = threading.Timer(300.0, bail2)
         dog.daemon = True
         dog.start()
         try:
