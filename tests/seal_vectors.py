@@ -312,8 +312,11 @@ class CompositeSide:
         return bool(words.shape == rec.words.shape and (words == rec.words).all())
 
 
-def check_composites(vec: VectorFile, kind: str, rounded: bool) -> Dict[str, bool]:
-    """-> {answer tag: equal?} for every composite answer the file holds (sets c2 / c3 of tools/gen_composite_vectors.cpp).
+def check_composites(vec: VectorFile, kind: str, rounded: bool, derived: dict = None) -> Dict[str, bool]:
+    """-> {answer tag: equal?} for every composite answer the file holds (sets c2 / c3 / c5 of tools/gen_composite_vectors.cpp).
+    `derived` (optional dict, shared between the calls for one file): plaintext words one side had to encode itself -- set c5
+    carries no diagonals -- are left there by the side that encoded them (the engine: the encoder the file's producer used)
+    and taken from there by the other, so that both sides replay the same inputs.
     C_Matrix_Decode encodes its masks inside the function: on the oracle side the masks come from the host encoder, which
     may differ from SEAL's / the engine's in a last bit of a coefficient, so `dec_row` is replayed on the engine only."""
     from seal_fyp_logistic_regression_amd import algorithms as alg
@@ -340,12 +343,29 @@ def check_composites(vec: VectorFile, kind: str, rounded: bool) -> Dict[str, boo
         powers = alg.compute_all_powers(s.ev, s.ct(vec.get("pow_ct")), max(r.aux for r in recs), s.rk)
         res["pow"] = all(s.same(powers[r.aux], r) for r in recs)
     if vec.has("mm_out"):
-        usig = s.pts("mm_usig")
-        n = int(round(len(usig) ** 0.5))
-        v, w = s.pts("mm_v"), s.pts("mm_w")
-        assert len(usig) == n * n and len(v) == len(w) == (n - 1) * n * n
-        V = [v[k * n * n:(k + 1) * n * n] for k in range(n - 1)]
-        W = [w[k * n * n:(k + 1) * n * n] for k in range(n - 1)]
-        out = alg.cc_matrix_multiplication(s.ev, s.ct(vec.get("mm_a")), s.ct(vec.get("mm_b")), n, usig, s.pts("mm_utau"), V, W, s.gk)
-        res["mm_out"] = s.same(out, vec.get("mm_out"))
+        out_rec = vec.get("mm_out")
+        n = out_rec.aux or int(round(len(vec.all("mm_usig")) ** 0.5))
+        top, scale = vec.get("mm_a").rows, vec.get("mm_a").scale
+        sets = None
+        if derived is not None and "mm" in derived:  # words another side encoded (the oracle side of a file without diagonals)
+            sets = [[s.pt(Record("", KIND_PT, 1, top, 0, scale, w)) for w in ws] for ws in derived["mm"]]
+        elif not vec.has("mm_usig") or kind != "oracle":
+            # the diagonals as the driver forms them (matrix_multiplication.cpp:205-297): U_sigma, U_tau, V_k, W_k of
+            # helper.h:702-851, every diagonal, plus 1e-8 -- derived here and encoded by this side's encoder
+            Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+            sets = [[s.encoder.encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)] for U in [Us, Ut] + list(V) + list(W)]
+            if derived is not None:
+                derived["mm"] = [[s.be.to_host(p.data).reshape(-1) for p in ps] for ps in sets]
+        if vec.has("mm_usig"):
+            filed = [s.pts("mm_usig"), s.pts("mm_utau")]
+            v, w = s.pts("mm_v"), s.pts("mm_w")
+            assert len(filed[0]) == n * n and len(v) == len(w) == (n - 1) * n * n
+            filed += [v[k * n * n:(k + 1) * n * n] for k in range(n - 1)] + [w[k * n * n:(k + 1) * n * n] for k in range(n - 1)]
+            if sets is not None:  # this repository's permutation matrices and encoder give the reference's plaintext words
+                res["mm_diagonals"] = all((s.be.to_host(a.data).reshape(-1) == s.be.to_host(b.data).reshape(-1)).all() and a.scale == b.scale
+                                          for fa, fb in zip(sets, filed) for a, b in zip(fa, fb))
+            sets = filed
+        out = alg.cc_matrix_multiplication(s.ev, s.ct(vec.get("mm_a")), s.ct(vec.get("mm_b")), n, sets[0], sets[1], sets[2:n + 1],
+                                           sets[n + 1:], s.gk)
+        res["mm_out"] = s.same(out, out_rec)
     return res

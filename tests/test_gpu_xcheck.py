@@ -33,8 +33,9 @@ def _generate(tmp_path, which, mode):
 
 def _replay(vec, mode, expect):
     from tests import seal_vectors as SV
+    derived = {}
     for kind in ("gpu", "oracle"):
-        res = SV.check_composites(vec, kind, rounded=mode == "round")
+        res = SV.check_composites(vec, kind, rounded=mode == "round", derived=derived)
         want = set(expect) - ({"dec_row"} if kind == "oracle" else set())
         assert set(res) == want, (kind, sorted(res))
         assert all(res.values()), (kind, mode, {k: v for k, v in res.items() if not v})
@@ -58,7 +59,20 @@ def test_reference_composites_c3_same_words_as_this_repository(tmp_path, mode):
     vec = _generate(tmp_path, "c3", mode)
     assert (vec.N, len(vec.primes)) == (16384, 6)
     assert [r.aux for r in vec.all("pow")] == [2, 3, 4, 5] and len(vec.all("mm_v")) == len(vec.all("mm_w")) == 48
-    _replay(vec, mode, ["pow", "mm_out"])
+    # mm_diagonals: this repository's U_sigma / U_tau / V_k / W_k (algorithms.matmul_permutation_matrices) and encoder
+    # reproduce the 128 plaintexts the reference's get_U_* + CKKSEncoder produced, word for word
+    _replay(vec, mode, ["pow", "mm_diagonals", "mm_out"])
+
+
+def test_reference_matrix_product_config5_same_words_as_this_repository(tmp_path):
+    """config 5 in the survey's reading (n = 8: 64 x 64 U matrices at N = 32768, all 1024 diagonals with their epsilon): the
+    reference's CC_Matrix_Multiplication (matrix_multiplication.cpp:11-132 = matrix_mult_benchmark.cpp:13-71) through the shim
+    against algorithms.py on the engine and on the oracle.  The file carries the inputs, the keys of the steps up to 64 and
+    the result; the 1024 diagonal plaintexts (1.3 GB) are derived on the engine side, whose encoder is the producer's, and
+    handed to the oracle side."""
+    vec = _generate(tmp_path, "c5", "round")
+    assert (vec.N, len(vec.primes)) == (32768, 6) and vec.get("mm_out").aux == 8 and not vec.has("mm_usig")
+    _replay(vec, "round", ["mm_out"])
 
 
 def test_a_wrong_word_or_a_wrong_scale_is_caught(tmp_path):

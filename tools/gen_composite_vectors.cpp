@@ -35,7 +35,11 @@
 //     dot_a, dot_b, dot = cipher_dot_product(dot_a, dot_b, 8)
 //   set c3 (N = 16384, {60,40,40,40,40,60}, scale 2^40)
 //     pow_ct, pow[2..5] = compute_all_powers(pow_ct, 5)
-//     mm_a, mm_b, mm_usig[16], mm_utau[16], mm_v[3*16] (aux = 16 (k-1) + i), mm_w[3*16], mm_out = CC_Matrix_Multiplication (n = 4)
+//     mm_a, mm_b, mm_usig[16], mm_utau[16], mm_v[3*16] (aux = 16 (k-1) + i), mm_w[3*16],
+//     mm_out = CC_Matrix_Multiplication (n = 4; aux = n)
+//   set c5 (N = 32768, {60,40,40,40,40,60}; not in the default list: 220 MB)
+//     gk for the steps +-1 .. +-64 only, mm_a, mm_b, mm_out (n = 8) -- the 1024 encoded diagonals are NOT in the file: the
+//     replay derives them (diagonals of U_sigma / U_tau / V_k / W_k plus 1e-8, encoded at the scale of mm_a)
 #include <unistd.h>
 
 #include <algorithm>
@@ -93,15 +97,16 @@ struct Env {
     }
 };
 
-// every key of the default set: 3^(+-2^i) and 2N - 1
-void put_galois_keys(Writer &w, const GaloisKeys &gk, std::size_t n)
+// the keys of the default set 3^(+-2^i) and 2N - 1 (max_step > 0: only the steps up to that size, no conjugation --
+// what the NAF plans of rotations below 2 max_step use)
+void put_galois_keys(Writer &w, const GaloisKeys &gk, std::size_t n, std::size_t max_step = 0)
 {
     std::vector<std::uint32_t> elts;
-    for (std::size_t s = 1; s < n / 2; s <<= 1) {
+    for (std::size_t s = 1; s < n / 2 && (!max_step || s <= max_step); s <<= 1) {
         elts.push_back(elt_from_step((long long)s, n));
         elts.push_back(elt_from_step(-(long long)s, n));
     }
-    elts.push_back((std::uint32_t)(2 * n - 1));
+    if (!max_step) elts.push_back((std::uint32_t)(2 * n - 1));
     std::vector<std::uint32_t> done;  // steps +N/4 and -N/4 are one element
     for (std::uint32_t e : elts) {
         if (!gk.has_key(e) || std::find(done.begin(), done.end(), e) != done.end()) continue;
@@ -208,6 +213,47 @@ void generate_c2(const std::string &dir)
     std::printf("%s/composites_c2.bin: N=%zu k=%zu (%s)\n", dir.c_str(), e.n, e.k, PRODUCER);
 }
 
+// CC_Matrix_Multiplication, set up as Matrix_Multiplication() does (matrix_multiplication.cpp:134-412; the function is
+// word for word matrix_mult_benchmark.cpp:13-71 as well).  with_diagonals = false leaves the (2 + 2(dim-1)) dim^2 encoded
+// diagonals out of the file (1.3 GB at dim = 8, N = 32768): they are a deterministic function of dim and the scale -- the
+// diagonals of U_sigma, U_tau, V_k, W_k plus 1e-8 -- which the replay re-derives and encodes itself.
+void matrix_product(Writer &w, const Env &e, Encryptor &encryptor, CKKSEncoder &encoder, const GaloisKeys &gk, int dim,
+                    bool with_diagonals)
+{
+    const int dsq = dim * dim;
+    std::vector<std::vector<double>> A(dim, std::vector<double>(dim));
+    double filler = 1;
+    for (auto &row : A)
+        for (double &x : row) x = filler++;
+    const double epsilon = 0.00000001;  // :239
+    auto encode_diagonals = [&](std::vector<std::vector<double>> U, const std::string &tag, int base) {
+        std::vector<std::vector<double>> dg = get_all_diagonals(U);
+        std::vector<Plaintext> out(dsq);
+        for (int i = 0; i < dsq; ++i) {
+            for (double &x : dg[i]) x += epsilon;
+            encoder.encode(dg[i], e.scale, out[i]);
+            if (with_diagonals) put_pt(w, tag, out[i], e.n, (std::uint32_t)(base + i));
+        }
+        return out;
+    };
+    std::vector<Plaintext> usig = encode_diagonals(get_U_sigma(A), "mm_usig", 0);
+    std::vector<Plaintext> utau = encode_diagonals(get_U_tau(A), "mm_utau", 0);
+    std::vector<std::vector<Plaintext>> V(dim - 1), W(dim - 1);
+    for (int k = 1; k < dim; ++k) V[k - 1] = encode_diagonals(get_V_k(A, k), "mm_v", dsq * (k - 1));
+    for (int k = 1; k < dim; ++k) W[k - 1] = encode_diagonals(get_W_k(A, k), "mm_w", dsq * (k - 1));
+    std::vector<double> flat;
+    for (auto &row : A) flat.insert(flat.end(), row.begin(), row.end());
+    Plaintext pa;
+    encoder.encode(flat, e.scale, pa);
+    Ciphertext ctA, ctB;
+    encryptor.encrypt(pa, ctA);
+    encryptor.encrypt(pa, ctB);
+    put_ct(w, "mm_a", ctA);
+    put_ct(w, "mm_b", ctB);
+    Ciphertext out = CC_Matrix_Multiplication(ctA, ctB, dim, usig, utau, V, W, gk, e.params);  // matrix_multiplication.cpp:11
+    put_ct(w, "mm_out", out, (std::uint32_t)dim);
+}
+
 void generate_c3(const std::string &dir)
 {
     Env e(16384, {60, 40, 40, 40, 40, 60}, std::pow(2.0, 40));
@@ -234,41 +280,24 @@ void generate_c3(const std::string &dir)
         compute_all_powers(cb, 5, evaluator, rk, powers);
         for (int i = 2; i <= 5; ++i) put_ct(w, "pow", powers[i], (std::uint32_t)i);
     }
-    {  // CC_Matrix_Multiplication, set up as Matrix_Multiplication() does (matrix_multiplication.cpp:134-412), n = 4
-        const int dim = 4, dsq = dim * dim;
-        std::vector<std::vector<double>> A(dim, std::vector<double>(dim));
-        double filler = 1;
-        for (auto &row : A)
-            for (double &x : row) x = filler++;
-        const double epsilon = 0.00000001;  // :239
-        auto encode_diagonals = [&](std::vector<std::vector<double>> U, const std::string &tag, int base) {
-            std::vector<std::vector<double>> dg = get_all_diagonals(U);
-            std::vector<Plaintext> out(dsq);
-            for (int i = 0; i < dsq; ++i) {
-                for (double &x : dg[i]) x += epsilon;
-                encoder.encode(dg[i], e.scale, out[i]);
-                put_pt(w, tag, out[i], e.n, (std::uint32_t)(base + i));
-            }
-            return out;
-        };
-        std::vector<Plaintext> usig = encode_diagonals(get_U_sigma(A), "mm_usig", 0);
-        std::vector<Plaintext> utau = encode_diagonals(get_U_tau(A), "mm_utau", 0);
-        std::vector<std::vector<Plaintext>> V(dim - 1), W(dim - 1);
-        for (int k = 1; k < dim; ++k) V[k - 1] = encode_diagonals(get_V_k(A, k), "mm_v", dsq * (k - 1));
-        for (int k = 1; k < dim; ++k) W[k - 1] = encode_diagonals(get_W_k(A, k), "mm_w", dsq * (k - 1));
-        std::vector<double> flat;
-        for (auto &row : A) flat.insert(flat.end(), row.begin(), row.end());
-        Plaintext pa;
-        encoder.encode(flat, e.scale, pa);
-        Ciphertext ctA, ctB;
-        encryptor.encrypt(pa, ctA);
-        encryptor.encrypt(pa, ctB);
-        put_ct(w, "mm_a", ctA);
-        put_ct(w, "mm_b", ctB);
-        Ciphertext out = CC_Matrix_Multiplication(ctA, ctB, dim, usig, utau, V, W, gk, e.params);  // matrix_multiplication.cpp:11
-        put_ct(w, "mm_out", out);
-    }
+    matrix_product(w, e, encryptor, encoder, gk, 4, true);
     std::printf("%s/composites_c3.bin: N=%zu k=%zu (%s)\n", dir.c_str(), e.n, e.k, PRODUCER);
+}
+
+// config 5 in the survey's reading: n = 8 (64 x 64 U matrices, 1024 diagonals) at N = 32768
+void generate_c5(const std::string &dir)
+{
+    Env e(32768, {60, 40, 40, 40, 40, 60}, std::pow(2.0, 40));
+    KeyGenerator keygen(e.context);
+    PublicKey pk = keygen.public_key();
+    GaloisKeys gk = keygen.galois_keys();
+    Encryptor encryptor(e.context, pk);
+    CKKSEncoder encoder(e.context);
+    Writer w(dir + "/composites_c5.bin");
+    put_header(w, e.context, PRODUCER);
+    put_galois_keys(w, gk, e.n, 64);  // rotations by 1..63 and -64: NAF terms up to 64
+    matrix_product(w, e, encryptor, encoder, gk, 8, false);
+    std::printf("%s/composites_c5.bin: N=%zu k=%zu (%s)\n", dir.c_str(), e.n, e.k, PRODUCER);
 }
 
 }  // namespace
@@ -276,7 +305,7 @@ void generate_c3(const std::string &dir)
 int main(int argc, char **argv)
 {
     if (argc < 2) {
-        std::fprintf(stderr, "usage: %s <output dir> [c2 c3]\n", argv[0]);
+        std::fprintf(stderr, "usage: %s <output dir> [c2 c3 c5]\n", argv[0]);
         return 2;
     }
     std::vector<std::string> want;
@@ -288,6 +317,8 @@ int main(int argc, char **argv)
                 generate_c2(argv[1]);
             else if (name == "c3")
                 generate_c3(argv[1]);
+            else if (name == "c5")
+                generate_c5(argv[1]);
             else
                 throw std::invalid_argument("unknown set " + name);
         }
