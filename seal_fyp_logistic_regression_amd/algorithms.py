@@ -786,6 +786,8 @@ def cipher_dot_product_many(ev: Evaluator, As: Sequence[Ciphertext], Bs: Sequenc
     (size 8: 3 instead of 7).  Slots 0..size-1 hold the same replicated dot product as the reference's chain; slots
     size..2*size-1 differ (they carry one more copy of the products), which no caller reads."""
     be, n = ev.be, len(As)
+    if n == 0:  # a rank of a row-sharded prediction that owns no row (parallel.predict_cipher_weights_sharded)
+        return []
     mults = ev.multiply_many(As, Bs)                                 # :432
     ev.relinearize_many_inplace(mults, relin_keys)                   # :440
     ev.rescale_to_next_many_inplace(mults)                           # :441

@@ -42,7 +42,7 @@ def _worker(rank, world, port, d, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("d,world", [(8, 2), (1, 2), (3, 4)])
+@pytest.mark.parametrize("d,world", [(8, 2), (1, 2), (3, 4), (16, 8)])
 def test_sharded_linear_transform_world2(d, world):
     """world 4 with d = 3: one rank owns no diagonal and contributes the zero ciphertext (the 8-GPU node's case whenever a
     transform has fewer units than ranks)"""
@@ -125,11 +125,14 @@ def _worker_matmul_lr(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_sharded_matrix_product_and_lr_predict_world2():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_matrix_product_and_lr_predict_world2(world):
+    """world 8 (the node the scaling run uses): four Step-2 transforms and three observation rows over eight ranks -- most
+    ranks own nothing in one or the other and contribute the zero ciphertext"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_matmul_lr, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_matmul_lr, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = []
@@ -142,7 +145,7 @@ def test_sharded_matrix_product_and_lr_predict_world2():
         p.join(timeout=30)
         if p.is_alive():
             p.terminate()
-    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
+    assert len(out) == world and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
     for rank, mm_same, mm_val, lr_same in sorted(out):
         assert mm_same, f"rank {rank}: sharded matrix product differs from the serial one"
         assert mm_val
@@ -179,14 +182,14 @@ def _worker_sparse_matmul(rank, world, port, n, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n", [3, 2])
-def test_sharded_sparse_matrix_product_world2(n):
+@pytest.mark.parametrize("n,world", [(3, 2), (2, 2), (3, 8)])
+def test_sharded_sparse_matrix_product_world2(n, world):
     """config 5's form of the matrix product (non-zero diagonals only) with Step 2 split by k over two ranks -- n = 2
     leaves rank 1 without a unit -- with sigma / tau replicated and diagonal-sharded: bits of the serial sparse product."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker_sparse_matmul, args=(r, 2, port, n, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker_sparse_matmul, args=(r, world, port, n, q)) for r in range(world)]
     for p in procs:
         p.start()
     out = []
@@ -199,7 +202,7 @@ def test_sharded_sparse_matrix_product_world2(n):
         p.join(timeout=30)
         if p.is_alive():
             p.terminate()
-    assert len(out) == 2 and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
+    assert len(out) == world and all(p.exitcode == 0 for p in procs), "a worker failed (see its traceback above)"
     for rank, res in sorted(out):
         for step1, (same, val) in zip((False, True), res):
             assert same, f"rank {rank}, shard_step1={step1}: sharded sparse product differs from the serial one"
