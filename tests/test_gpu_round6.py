@@ -7,6 +7,7 @@
   fix: forward and inverse at every degree against the oracle's transform, both arithmetic policies in one call.
 """
 import ctypes
+import json
 import os
 import subprocess
 import sys
@@ -192,3 +193,28 @@ def test_linear_transform_plain_many_refuses_bad_arguments():
         be.linear_transform_plain_many(L, [], [], elts, keys)
     with pytest.raises(ValueError, match="bad linear-transform arguments"):   # more than 64 transforms in one call
         be.linear_transform_plain_many(L, [cts[0].data] * 65, [diags[0].data] * 65, elts, keys)
+
+
+def test_bench_eight_ranks_share_one_gpu_sharded_legs_keep_the_serial_bits():
+    """The driver's scaling run goes to eight ranks; this box has one MI355X, so the eight ranks share it (gloo rendezvous
+    and exchange, as in tests/test_gpu_round4.py's two-rank run) with workloads cut to fit: what is exercised is every
+    sharded leg's PARTITION at world 8 on the HIP engine -- a 16-diagonal transform (2 diagonals per rank), the n = 4 matrix
+    product (6 Step-2 transforms over 8 ranks: two ranks own none), a five-row prediction (three ranks own no row) -- each
+    with the bits of its serial form.  (The 2000-row leg at this world size needs the eight devices: on one GPU the ranks'
+    allocations contend for seconds per slab.)"""
+    from tests.test_gpu_round4 import _bench
+    r, _ = _bench({}, "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "256", "--cpu-seconds", "0", "--lt", "16",
+                  "--ladder", "", "--composites", "matmul_C3_n4,lr_rows_5x8", "--secondary", "", "--sustain", "0",
+                  "--key-per-item", "0", "--lt-direct", "0", timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 8 and line["verified"] is True and line["value"] > 0
+    d16 = line["lt_sharded"]["d16"]
+    assert d16["bits_equal_serial"] is True and d16["decrypts_to_Mv"] is True
+    comp = line["composites"]
+    assert set(comp) == {"matmul_C3_n4", "lr_rows_5x8"}, comp
+    for name, rec in comp.items():
+        assert rec["bits_equal_serial"] is True and rec["sharded_ms"] > 0, (name, rec)
+    assert comp["matmul_C3_n4"]["decrypts_to_AB"] is True and comp["lr_rows_5x8"]["decrypts_to_sigmoid_of_Xw"] is True
