@@ -169,3 +169,139 @@ def test_generator_built_against_the_shim_roundtrips_through_the_format(tmp_path
         # unpinned"): parms_id = SHA3-256 of the parameter words, header fields, the words of `ct`, the key-set framing
         st = SV.check_streams(vec)
         assert all(st.values()), (name, st)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the composite checker on the CPU: a file whose answers come from the reference's loops written out op by op
+# ------------------------------------------------------------------------------------------------------------------
+def _loop_composites_file(path, rounded):
+    """A composites file (sets c2 / c3 of tools/gen_composite_vectors.cpp, at toy size) made on the oracle: inputs from
+    seal.py's KeyGenerator / Encryptor / encoder, ANSWERS from the reference's functions restated here one Evaluator call per
+    line -- helper.h:237-262, :212-234, :265-278, :307-322, :416-502, :505-547 and matrix_multiplication.cpp:11-132 read
+    literally, none of algorithms.py's restructurings (shared rotation sets, lockstep forests, fused products, one-pass sums)."""
+    from seal_fyp_logistic_regression_amd import algorithms as alg
+    from seal_fyp_logistic_regression_amd import seal as S
+    from tests.oracle_backend import OracleBackend
+    N, bits, scale = 2048, [60, 40, 40, 40, 40, 60], 2.0 ** 40
+    parms = S.EncryptionParameters("ckks")
+    parms.set_poly_modulus_degree(N)
+    parms.set_coeff_modulus(S.CoeffModulus.Create(N, bits))
+    be = OracleBackend(N, parms.coeff_modulus())
+    be.rescale_rounded = rounded
+    ctx = S.SEALContext.Create(parms, backend=be)
+    kg = S.KeyGenerator(ctx, 3)
+    enc, encoder, ev = S.Encryptor(ctx, kg.public_key(), 4), S.CKKSEncoder(ctx, device_encode=False), S.Evaluator(ctx)
+    gk, rk = kg.galois_keys(), kg.relin_keys()
+    k, recs = ctx.k, []
+    R = SV.Record
+    ct_rec = lambda tag, c, aux=0: recs.append(R(tag, 1, c.size(), c.parms_id(), aux, c.scale, be.to_host(c.data).reshape(-1)))
+    pt_rec = lambda tag, p, aux=0: recs.append(R(tag, 2, 1, p.parms_id(), aux, p.scale, be.to_host(p.data).reshape(-1)))
+    for e, key in gk.keys.items():
+        recs.append(R("gk", 3, k - 1, k, e, 1.0, be.to_host(key).reshape(-1)))
+    recs.append(R("rk", 3, k - 1, k, 0, 1.0, be.to_host(rk.key(0)).reshape(-1)))
+
+    def lt_plain(ct, diags):  # helper.h:237-262
+        ct_new = ev.add(ct, ev.rotate_vector(ct, -len(diags), gk))
+        res = [ev.multiply_plain(ct_new, diags[0])]
+        for l in range(1, len(diags)):
+            res.append(ev.multiply_plain(ev.rotate_vector(ct_new, l, gk), diags[l]))
+        return ev.add_many(res)
+
+    rng = np.random.default_rng(12)
+    d = 4
+    M, v = rng.uniform(-1, 1, (d, d)), rng.uniform(-1, 1, d)
+    diags = [encoder.encode(x, scale) for x in alg.get_all_diagonals(M)]
+    ct = enc.encrypt(encoder.encode(v, scale))
+    for i, p in enumerate(diags):
+        pt_rec("lt4_diag", p, i)
+    ct_rec("lt4_ct", ct)
+    ct_rec("lt4_plain", lt_plain(ct, diags))
+    cdiags = [enc.encrypt(p) for p in diags]
+    for i, c in enumerate(cdiags):
+        ct_rec("lt4_cdiag", c, i)
+    ct_new = ev.add(ct, ev.rotate_vector(ct, -d, gk))                 # helper.h:212-234
+    res = [ev.multiply(ct_new, cdiags[0])]
+    for l in range(1, d):
+        res.append(ev.multiply(ev.rotate_vector(ct_new, l, gk), cdiags[l]))
+    ct_rec("lt4_cipher", ev.add_many(res))
+    ptrot = [encoder.encode(np.roll(v, -i), scale) for i in range(d)]
+    for i, p in enumerate(ptrot):
+        pt_rec("lt4_ptrot", p, i)
+    ct_rec("lt4_cmpv", ev.add_many([ev.multiply_plain(cdiags[i], ptrot[i]) for i in range(d)]))   # helper.h:265-278
+    rows = [enc.encrypt(encoder.encode(np.arange(3) + 10.0 * i, scale)) for i in range(3)]
+    for i, c in enumerate(rows):
+        ct_rec("enc_row", c, i)
+    ct_rec("enc_packed", ev.add_many([rows[0]] + [ev.rotate_vector(rows[i], -3 * i, gk) for i in (1, 2)]))   # helper.h:307-322
+    a, b = enc.encrypt(encoder.encode(np.arange(1.0, 9.0), scale)), enc.encrypt(encoder.encode(np.linspace(-1, 1, 8), scale))
+    ct_rec("dot_a", a)
+    ct_rec("dot_b", b)
+    mult = ev.multiply(a, b)                                          # helper.h:416-502
+    ev.relinearize_inplace(mult, rk)
+    ev.rescale_to_next_inplace(mult)
+    dup = ev.add(mult, ev.rotate_vector(mult, -8, gk))
+    for _ in range(1, 8):
+        dup = ev.rotate_vector(dup, 1, gk)
+        mult = ev.add(mult, dup)
+    mult.scale = 2.0 ** int(np.log2(mult.scale))
+    ct_rec("dot", mult)
+    ct_rec("pow_ct", b)
+    powers, levels = [None, b] + [None] * 4, [0, 0] + [0] * 4        # helper.h:505-547
+    for i in range(2, 6):
+        cand, minlevel = -1, i
+        for j in range(1, i // 2 + 1):
+            newlevel = max(levels[j], levels[i - j]) + 1
+            if newlevel < minlevel:
+                cand, minlevel = j, newlevel
+        levels[i] = minlevel
+        temp = powers[cand].copy()
+        ev.mod_switch_to_inplace(temp, powers[i - cand].parms_id())
+        powers[i] = ev.multiply(temp, powers[i - cand])
+        ev.relinearize_inplace(powers[i], rk)
+        ev.rescale_to_next_inplace(powers[i])
+        ct_rec("pow", powers[i], i)
+    n = 2                                                              # matrix_multiplication.cpp:11-132
+    A = np.arange(1.0, n * n + 1).reshape(n, n)
+    Us, Ut, V, W = alg.matmul_permutation_matrices(n)
+    sets = [[encoder.encode(dg + 1e-8, scale) for dg in alg.get_all_diagonals(U)] for U in [Us, Ut] + list(V) + list(W)]
+    for tag, ps, base in [("mm_usig", sets[0], 0), ("mm_utau", sets[1], 0)] + \
+            [("mm_v", sets[2 + i], n * n * i) for i in range(n - 1)] + [("mm_w", sets[n + 1 + i], n * n * i) for i in range(n - 1)]:
+        for i, p in enumerate(ps):
+            pt_rec(tag, p, base + i)
+    ctA = enc.encrypt(encoder.encode(A.reshape(-1), scale))
+    ctB = enc.encrypt(encoder.encode(A.reshape(-1), scale))
+    ct_rec("mm_a", ctA)
+    ct_rec("mm_b", ctB)
+    cA, cB = [lt_plain(ctA, sets[0])], [lt_plain(ctB, sets[1])]
+    for kk in range(1, n):
+        cA.append(lt_plain(cA[0], sets[1 + kk]))
+        cB.append(lt_plain(cB[0], sets[n + kk]))
+    for i in range(1, n):
+        ev.rescale_to_next_inplace(cA[i])
+        ev.rescale_to_next_inplace(cB[i])
+    ctAB = ev.multiply(cA[0], cB[0])
+    ev.mod_switch_to_next_inplace(ctAB)
+    for i in range(1, n):
+        cA[i].scale = 2.0 ** int(np.log2(cA[i].scale))
+        cB[i].scale = 2.0 ** int(np.log2(cB[i].scale))
+    for kk in range(1, n):
+        ctAB = ev.add(ctAB, ev.multiply(cA[kk], cB[kk]))
+    ct_rec("mm_out", ctAB, n)
+    SV.write(path, N, ctx.primes, "hefx oracle, the reference's loops op by op (NOT Microsoft SEAL: pins nothing)", recs)
+
+
+@pytest.mark.parametrize("rounded", [True, False])
+def test_composite_checker_selfcheck_against_op_by_op_loops(tmp_path, rounded):
+    """tests/seal_vectors.py::check_composites (the replay behind tests/test_gpu_xcheck.py and the composites_*.bin slot) on the
+    CPU: algorithms.py's restructured composition against the reference's loops written out call by call, through the file
+    format.  Also: the other division is told apart, and a flipped word is caught."""
+    path = str(tmp_path / "composites_loops.bin")
+    _loop_composites_file(path, rounded)
+    vec = SV.load(path)
+    assert not vec.from_real_seal
+    res = SV.check_composites(vec, "oracle", rounded=rounded)
+    assert set(res) == {"lt4_plain", "lt4_cipher", "lt4_cmpv", "enc_packed", "dot", "pow", "mm_out"}, sorted(res)
+    assert all(res.values()), {k_: v for k_, v in res.items() if not v}
+    other = SV.check_composites(vec, "oracle", rounded=not rounded)
+    assert other["lt4_plain"] and not other["dot"] and not other["pow"] and not other["mm_out"]   # only what crosses a rescale differs
+    vec.get("lt4_cmpv").words[3] ^= 1
+    assert SV.check_composites(vec, "oracle", rounded=rounded)["lt4_cmpv"] is False
